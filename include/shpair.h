@@ -1,0 +1,145 @@
+/*
+ * shpair.h — C ABI of the MI355X-native `pair_style sh` contact path.
+ *
+ * Drop-in boundary for the SPHERHARM pair style (BASELINE.json north_star:
+ * "keeping LAMMPS's pair_style / compute() plugin API ... calling hand-written
+ * HIP kernels through a thin C-ABI layer").
+ *
+ * Reference citations: the reference mount holds only /root/reference/README.md:1
+ * ("SPHERHARM Package to simulate complex shaped granular particles"); the
+ * PairSH sources these entry points stand in for are ABSENT FROM MOUNT
+ * (SURVEY.md §0, §8b), so each entry point names the LAMMPS `Pair` virtual it
+ * serves instead of a file:line.  The LAMMPS-side adapter that binds them is
+ * lammps-spherharm_amd/lammps/pair_sh.{h,cpp}; see INTEGRATION.md.
+ *
+ * Conventions: plain pointers and sizes, no C++/torch types, no exceptions.
+ * Every function returns 0 (SHPAIR_OK) or a negative SHPAIR_E* code;
+ * shpair_strerror() names it and shpair_last_error() gives the detail string
+ * of the last failure on a context.  One context per rank/GPU; a context is
+ * not re-entrant.  There is NO CPU fallback: without a usable HIP device
+ * shpair_create() fails with SHPAIR_ENODEV.
+ */
+#ifndef SHPAIR_H
+#define SHPAIR_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SHPAIR_OK 0
+#define SHPAIR_EINVAL -1   /* bad argument                              */
+#define SHPAIR_ENODEV -2   /* no HIP device / device id out of range    */
+#define SHPAIR_EHIP -3     /* a HIP runtime call failed                 */
+#define SHPAIR_ESTATE -4   /* call order: shapes/coeffs/neighbours unset */
+#define SHPAIR_ENOMEM -5
+#define SHPAIR_ELMAX -6    /* lmax or nq above the compiled limits      */
+
+#define SHPAIR_MAX_LMAX 20 /* L <= 12 run unrolled kernels, 13..20 the loop kernel */
+#define SHPAIR_MAX_NQ 128
+#define SHPAIR_NEIGHMASK 0x1FFFFFFF /* LAMMPS NEIGHMASK: low 29 bits of a neighbour entry */
+
+typedef struct shpair_ctx shpair_ctx;
+
+/* Per-call statistics of the last compute (shpair_get_stats). */
+typedef struct shpair_stats {
+  long long n_candidates;   /* pairs in the half list                         */
+  long long n_contact;      /* pairs whose bounding spheres overlap (metric)  */
+  long long n_touching;     /* pairs with a non-zero force this call          */
+  double kernel_ms;         /* device time of the pair kernels (hipEvents)    */
+  double total_ms;          /* device time incl. staging copies, 0 if unknown */
+} shpair_stats;
+
+/* ---- lifetime ------------------------------------------------------------ */
+
+/* PairSH::PairSH(LAMMPS*) — allocate a context bound to HIP device `device_id`
+ * (one non-blocking stream of its own). */
+int shpair_create(shpair_ctx **out, int device_id);
+/* PairSH::~PairSH() */
+void shpair_destroy(shpair_ctx *ctx);
+const char *shpair_strerror(int code);
+const char *shpair_last_error(const shpair_ctx *ctx);
+/* Library identification: "shpair <version> gfx950". */
+const char *shpair_version(void);
+
+/* ---- setup: PairSH::settings() / coeff() / init_style() / init_one() ------ */
+
+/* PairSH::settings(): `pair_style sh <nq>` — Gauss order of the cap
+ * quadrature (Q = 2 nq^2 nodes per pair), 1 <= nq <= SHPAIR_MAX_NQ. */
+int shpair_settings(shpair_ctx *ctx, int nq);
+
+/* Sizes the tables: `ntypes` LAMMPS atom types (1-based in pair_coeff) and
+ * `nshapes` shape-table entries (0-based `shtype`).  Clears earlier shapes
+ * and coefficients. */
+int shpair_set_ntypes(shpair_ctx *ctx, int ntypes, int nshapes);
+
+/* One entry of the per-shape table the reference's atom style owns
+ * (coefficients a_nm, m >= 0, n-major: anm[2k]=Re, anm[2k+1]=Im,
+ * k = n(n+1)/2+m; (lmax+1)(lmax+2) doubles; docs/SPEC.md §1).
+ * rmax > 0 sets the bounding radius, rmax <= 0 asks for the default
+ * (1.01 x grid maximum).  Caller keeps ownership of anm. */
+int shpair_set_shape(shpair_ctx *ctx, int ishape, int lmax, const double *anm, double rmax);
+
+/* PairSH::coeff(): `pair_coeff I J kn exponent` for ONE (itype, jtype)
+ * (1-based; the adapter expands wildcards and mirrors i<->j). */
+int shpair_set_coeff(shpair_ctx *ctx, int itype, int jtype, double kn, double exponent);
+
+/* PairSH::init_one(i,j) support: bounding radius of a shape. */
+int shpair_get_rmax(const shpair_ctx *ctx, int ishape, double *rmax);
+
+/* Stateless host helpers (no device needed): radius of a shape in body-frame
+ * unit direction u[3], and the default bounding radius. */
+int shpair_shape_radius(int lmax, const double *anm, const double *u, double *r);
+int shpair_shape_default_rmax(int lmax, const double *anm, double *rmax);
+
+/* ---- neighbour list: consumed after Neighbor::build() --------------------- */
+
+/* LAMMPS NeighList layout (half list): inum, ilist[inum], numneigh[] and
+ * firstneigh[] indexed by ATOM index i = ilist[ii].  Entries are masked with
+ * SHPAIR_NEIGHMASK.  Host pointers; copied. */
+int shpair_set_neighbors(shpair_ctx *ctx, int inum, const int *ilist, const int *numneigh,
+                         const int *const *firstneigh);
+/* Same list in CSR form: offsets[inum+1] into jlist. Host pointers; copied. */
+int shpair_set_neighbors_csr(shpair_ctx *ctx, int inum, const int *ilist, const int *offsets,
+                             const int *jlist);
+
+/* ---- PairSH::compute(eflag, vflag) --------------------------------------- */
+
+/* Host-pointer form, LAMMPS layout: x[nall][3], quat[nall][4] (w,x,y,z),
+ * type[nall] (1-based), shtype[nall] (0-based), nall = nlocal + nghost.
+ * ADDS into f[nall][3] and torque[nall][3] (LAMMPS' force_clear() zeroes them).
+ * eng_vdwl / virial[6] (xx,yy,zz,xy,xz,yz) are ADDED to when eflag / vflag
+ * are non-zero (may be NULL otherwise). Blocks until the result is on the host. */
+int shpair_compute(shpair_ctx *ctx, int nlocal, int nghost, const double *x, const double *quat,
+                   const int *type, const int *shtype, int newton_pair, int eflag, int vflag,
+                   double *f, double *torque, double *eng_vdwl, double *virial);
+
+/* Device-pointer form: all arrays already resident in HBM (the measured
+ * path). Same layout and ADD semantics; ev_dev (nullable) is 7 doubles on the
+ * device: [0] += energy, [1..6] += virial.  stream: a hipStream_t, or NULL
+ * for the context's own stream.  Asynchronous: returns after enqueueing. */
+int shpair_compute_device(shpair_ctx *ctx, int nlocal, int nghost, const double *x_dev,
+                          const double *quat_dev, const int *type_dev, const int *shtype_dev,
+                          int newton_pair, int eflag, int vflag, double *f_dev, double *torque_dev,
+                          double *ev_dev, void *stream);
+
+/* Options. key = "force_volume" (1: always run the overlap-volume root finder,
+ * even when exponent == 1 and eflag == 0), "timing" (1: bracket the pair
+ * kernels with hipEvents for shpair_get_stats), "count" (1: count contact
+ * pairs every call), "variant" (kernel variant selector). */
+int shpair_set_option(shpair_ctx *ctx, const char *key, int value);
+
+/* Blocks until the last compute finished, then fills `out`. */
+int shpair_get_stats(shpair_ctx *ctx, shpair_stats *out);
+
+/* Optional per-pair diagnostics of the next computes: pair_out_dev holds
+ * 7 doubles per half-list entry (V, S_n[3], T_n[3], docs/SPEC.md §2), device
+ * memory owned by the caller; NULL disables. */
+int shpair_set_pair_output(shpair_ctx *ctx, double *pair_out_dev);
+
+/* Wait for everything enqueued on the context's stream. */
+int shpair_synchronize(shpair_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SHPAIR_H */

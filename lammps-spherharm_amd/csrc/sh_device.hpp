@@ -1,0 +1,311 @@
+// sh_device.hpp — device-side spherical-harmonic radius evaluation for gfx950.
+//
+// docs/SPEC.md §1 in the angle-free polynomial form: for a unit vector (x,y,z)
+//   r = sum_m Re[ W_m(z) (x+iy)^m ],  W_m(z) = sum_n Q_n^m(z) cw_nm
+// with the z-polynomials Q_n^m from a two-term recurrence rescaled so that the
+// coefficient of Q_{n-2} is exactly 1 (one v_mul_f64 + one v_fma_f64 per term):
+//   Q_m^m = Pi_m^m (constant), Q_{m+1}^m = a1 z, Q_n^m = a'_nm z Q_{n-1}^m - Q_{n-2}^m.
+//
+// Where the operands live (one wavefront per pair, so all of them are
+// wave-uniform):
+//  * recurrence constants a', a1, Pi_m^m: shape independent, so for the
+//    compiled orders they are C++ constant expressions (sh_const.hpp) that the
+//    compiler materialises with s_mov_b32 on the scalar unit — no memory, no
+//    VGPR, no LDS.  The run-time-order kernel reads them from the rc table.
+//  * shape coefficients cw: scalar loads (s_load_dwordx16) through the scalar
+//    data cache into SGPRs, four complex terms at a time, software pipelined.
+//
+// Table layout (built on the host by sh_tables.cpp), m-major so that the
+// constants of one m-block are contiguous: k = sh_index(L, n, m)
+//   rc[k]                 : n == m   -> Pi_m^m ; n == m+1 -> a1 ; n >= m+2 -> a'_nm
+//   cw[2k], cw[2k+1]      : (2-delta_m0) a_nm s_nm, for n == m additionally
+//                           multiplied by Pi_m^m so that W_m starts at cw.
+// Reference: the SH math helpers of the reference are ABSENT FROM MOUNT
+// (SURVEY.md §2.2); this is the build's own formulation.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "sh_const.hpp"
+
+namespace shp {
+
+// Makes a wave-uniform pointer opaque to the optimiser. The tables are loop
+// invariant, so without this LICM hoists every scalar load out of the node
+// loop and the register allocator spills ~170 SGPR pairs into VGPR lanes
+// (v_writelane/v_readlane, 256+ VGPRs, 1 wave/SIMD). Laundered per m-block,
+// the loads stay next to their use and live only for that block.
+// The result is typed as a constant-address-space (AS4) pointer: after the asm
+// the compiler no longer knows the pointer is global, and a generic pointer
+// would be read with per-lane flat_load into VGPRs instead of s_load.
+typedef const double __attribute__((address_space(4))) * cdptr;
+__device__ __forceinline__ cdptr launder_uniform(const double* p)
+{
+  asm volatile("" : "+s"(p));
+  return (cdptr)p;
+}
+
+struct ShAcc {
+  double Wr, Wi, Zr, Zi;   // W_m and dW_m/dz
+  double p1, p2, d1, d2;   // Q_{n-1}, Q_{n-2} and their z-derivatives
+};
+
+// A compile-time double as an SGPR pair, materialised by two s_mov_b32 on the
+// scalar unit at the point of use.  `volatile` keeps LICM from hoisting the
+// (loop-invariant) constant out of the node loop into a long-lived VGPR pair —
+// with 21 (L=6) to 78 (L=12) constants that alone would cost 42..156 VGPRs.
+template <unsigned LO, unsigned HI>
+__device__ __forceinline__ double sgpr_const_bits()
+{
+  unsigned lo, hi;
+  asm volatile("s_mov_b32 %0, %2\n\ts_mov_b32 %1, %3" : "=s"(lo), "=s"(hi) : "i"(LO), "i"(HI));
+  return __hiloint2double((int)hi, (int)lo);
+}
+#define SHP_SGPR_CONST(cexpr)                                                              \
+  ::shp::sgpr_const_bits<(unsigned)(__builtin_bit_cast(unsigned long long, (cexpr)) & 0xffffffffull), \
+                         (unsigned)(__builtin_bit_cast(unsigned long long, (cexpr)) >> 32)>()
+
+// Shape coefficients travel in chunks of 4 complex terms = one s_load_dwordx16
+// through the scalar data cache.  The load is an ordinary AS4 load (so the
+// compiler tracks it with a counted s_waitcnt and may keep it in flight), taken
+// through a laundered pointer (so it cannot be hoisted out of the node loop).
+// Chunks are software pipelined: chunk k+1 is requested before the terms of
+// chunk k are computed, across m-block boundaries as well, and a
+// sched_barrier after every chunk keeps the request where it was written.
+// A chunk may run past the end of its m-block (it then holds the head of the
+// next block, unused) and the last one past the end of the shape's table,
+// which the host pads (sh_chunk_stride()).
+typedef double sh_d8 __attribute__((ext_vector_type(8)));
+typedef sh_d8 sh_d8_u __attribute__((aligned(8)));
+typedef const sh_d8_u __attribute__((address_space(4))) * cd8ptr;
+__device__ __forceinline__ sh_d8 sload_chunk(const double* p)
+{
+  asm volatile("" : "+s"(p));
+  return *(cd8ptr)p;
+}
+
+// One (n, m) term with its coefficient (cr, ci) already in SGPRs.
+template <int L, int M, int N, bool GRAD>
+__device__ __forceinline__ void sh_term(const double cr, const double ci, const double z, ShAcc& s)
+{
+  if constexpr (N > L) {
+    return;
+  } else if constexpr (N == M) {
+    s.Wr = cr;   // cw already carries Pi_m^m
+    s.Wi = (M > 0) ? ci : 0.0;
+    s.Zr = 0.0;
+    s.Zi = 0.0;
+    s.p1 = 0.0; s.p2 = 0.0; s.d1 = 0.0; s.d2 = 0.0;
+  } else if constexpr (N == M + 1) {
+    const double a1 = SHP_SGPR_CONST(sh_const::aprime(M + 1, M));
+    s.p2 = SHP_SGPR_CONST(sh_const::pmm(M));
+    s.p1 = a1 * z;
+    s.d2 = 0.0;
+    s.d1 = a1;
+    s.Wr = fma(cr, s.p1, s.Wr);
+    if constexpr (M > 0) s.Wi = fma(ci, s.p1, s.Wi);
+    if constexpr (GRAD) {
+      s.Zr = cr * s.d1;
+      if constexpr (M > 0) s.Zi = ci * s.d1;
+    }
+  } else {
+    const double a = SHP_SGPR_CONST(sh_const::aprime(N, M));
+    const double p = fma(a, z * s.p1, -s.p2);
+    s.Wr = fma(cr, p, s.Wr);
+    if constexpr (M > 0) s.Wi = fma(ci, p, s.Wi);
+    if constexpr (GRAD) {
+      const double e = fma(z, s.d1, s.p1);
+      const double dp = (N == M + 2) ? a * e : fma(a, e, -s.d2);
+      s.Zr = fma(cr, dp, s.Zr);
+      if constexpr (M > 0) s.Zi = fma(ci, dp, s.Zi);
+      s.d2 = s.d1;
+      s.d1 = dp;
+    }
+    s.p2 = s.p1;
+    s.p1 = p;
+  }
+}
+
+struct ShState {
+  double Cm, Sm, Cp, Sp;   // E_m and E_{m-1}
+  double r, gx, gy, gz;
+  ShAcc a;
+};
+
+// Block m is complete: fold W_m, W_m' into r and the gradient, advance E_m.
+template <int L, int M, bool GRAD>
+__device__ __forceinline__ void sh_block_end(const double x, const double y, ShState& t)
+{
+  const ShAcc& s = t.a;
+  if constexpr (M == 0) {
+    t.r = s.Wr;
+    if constexpr (GRAD) t.gz = s.Zr;
+  } else {
+    t.r = fma(s.Wr, t.Cm, t.r);
+    t.r = fma(-s.Wi, t.Sm, t.r);
+    if constexpr (GRAD) {
+      t.gz = fma(s.Zr, t.Cm, t.gz);
+      t.gz = fma(-s.Zi, t.Sm, t.gz);
+      if constexpr (M == 1) {
+        t.gx += s.Wr;
+        t.gy -= s.Wi;
+      } else {
+        const double tr = (double)M * s.Wr, ti = (double)M * s.Wi;
+        t.gx = fma(tr, t.Cp, t.gx);
+        t.gx = fma(-ti, t.Sp, t.gx);
+        t.gy = fma(-tr, t.Sp, t.gy);
+        t.gy = fma(-ti, t.Cp, t.gy);
+      }
+    }
+  }
+  if constexpr (M < L) {  // E_{m+1} = E_m (x + i y)
+    if constexpr (M == 0) {
+      t.Cm = x;
+      t.Sm = y;
+    } else {
+      t.Cp = t.Cm;
+      t.Sp = t.Sm;
+      t.Cm = fma(t.Cp, x, -(t.Sp * y));
+      t.Sm = fma(t.Cp, y, t.Sp * x);
+    }
+  }
+}
+
+// The chunk that starts at term (N0, M), its coefficients already requested in
+// `cur`; requests its successor, computes its terms, recurses.
+template <int L, int M, int N0, bool GRAD>
+struct ShStep {
+  static __device__ __forceinline__ void run(const double* cw_in, const sh_d8 cur, const double x, const double y,
+                                             const double z, ShState& t)
+  {
+    constexpr bool block_done = (N0 + 4 > L);
+    constexpr bool has_next = !block_done || (M + 1 <= L);
+    constexpr int Mn = block_done ? M + 1 : M;
+    constexpr int Nn = block_done ? M + 1 : N0 + 4;
+    sh_d8 nxt = cur;
+    if constexpr (has_next) nxt = sload_chunk(cw_in + 2 * sh_index(L, Nn, Mn));
+    sh_term<L, M, N0, GRAD>(cur[0], cur[1], z, t.a);
+    sh_term<L, M, N0 + 1, GRAD>(cur[2], cur[3], z, t.a);
+    sh_term<L, M, N0 + 2, GRAD>(cur[4], cur[5], z, t.a);
+    sh_term<L, M, N0 + 3, GRAD>(cur[6], cur[7], z, t.a);
+    if constexpr (block_done) sh_block_end<L, M, GRAD>(x, y, t);
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (has_next) ShStep<L, Mn, Nn, GRAD>::run(cw_in, nxt, x, y, z, t);
+  }
+};
+
+// ---- run-time order (L < 0): plain loops over the rc / cw tables.
+template <bool GRAD>
+__device__ __forceinline__ void sh_eval_rt(const double* rc_in, const double* cw_in, const int LL, const double x,
+                                           const double y, const double z, double& r, double& gx, double& gy,
+                                           double& gz)
+{
+  double Cm = 1.0, Sm = 0.0, Cp = 1.0, Sp = 0.0;
+  for (int m = 0; m <= LL; ++m) {
+    const int o = sh_moff(LL, m);
+    const cdptr rc = launder_uniform(rc_in + o);
+    const cdptr cw = launder_uniform(cw_in + 2 * o);
+    double Wr = cw[0], Wi = cw[1];
+    double Zr = 0.0, Zi = 0.0;
+    if (m + 1 <= LL) {
+      const double a1 = rc[1];
+      double p2 = rc[0];
+      double p1 = a1 * z;
+      double d2 = 0.0, d1 = a1;
+      Wr = fma(cw[2], p1, Wr);
+      Wi = fma(cw[3], p1, Wi);
+      if (GRAD) {
+        Zr = cw[2] * a1;
+        Zi = cw[3] * a1;
+      }
+      for (int n = m + 2; n <= LL; ++n) {
+        const int k = n - m;
+        const double a = rc[k];
+        const double p = fma(a, z * p1, -p2);
+        Wr = fma(cw[2 * k], p, Wr);
+        Wi = fma(cw[2 * k + 1], p, Wi);
+        if (GRAD) {
+          const double e = fma(z, d1, p1);
+          const double dp = fma(a, e, -d2);
+          Zr = fma(cw[2 * k], dp, Zr);
+          Zi = fma(cw[2 * k + 1], dp, Zi);
+          d2 = d1;
+          d1 = dp;
+        }
+        p2 = p1;
+        p1 = p;
+      }
+    }
+    r = fma(Wr, Cm, r);
+    r = fma(-Wi, Sm, r);
+    if (GRAD) {
+      gz = fma(Zr, Cm, gz);
+      gz = fma(-Zi, Sm, gz);
+      if (m > 0) {
+        const double tr = (double)m * Wr, ti = (double)m * Wi;
+        gx = fma(tr, Cp, gx);
+        gx = fma(-ti, Sp, gx);
+        gy = fma(-tr, Sp, gy);
+        gy = fma(-ti, Cp, gy);
+      }
+    }
+    if (m > 0) {
+      Cp = Cm;
+      Sp = Sm;
+    }
+    const double c = fma(Cm, x, -(Sm * y)), sn = fma(Cm, y, Sm * x);
+    Cm = c;
+    Sm = sn;
+  }
+}
+
+// r (and, if GRAD, the Cartesian gradient of the polynomial F) at unit (x,y,z).
+// L >= 0: compile-time order, fully unrolled. L < 0: run-time order lrt.
+template <int L, bool GRAD>
+__device__ __forceinline__ void sh_eval(const double* rc_in, const double* cw_in, const int lrt, const double x,
+                                        const double y, const double z, double& r, double& gx, double& gy,
+                                        double& gz)
+{
+  r = 0.0;
+  gx = 0.0;
+  gy = 0.0;
+  gz = 0.0;
+  if constexpr (L >= 0) {
+    ShState t;
+    t.Cm = 1.0; t.Sm = 0.0; t.Cp = 1.0; t.Sp = 0.0;
+    t.r = 0.0; t.gx = 0.0; t.gy = 0.0; t.gz = 0.0;
+    const sh_d8 first = sload_chunk(cw_in);
+    __builtin_amdgcn_sched_barrier(0);
+    ShStep<L, 0, 0, GRAD>::run(cw_in, first, x, y, z, t);
+    r = t.r;
+    if constexpr (GRAD) { gx = t.gx; gy = t.gy; gz = t.gz; }
+  } else {
+    sh_eval_rt<GRAD>(rc_in, cw_in, lrt, x, y, z, r, gx, gy, gz);
+  }
+  // Pin the results here. Without a fixed use the optimiser sinks the whole
+  // VALU body of the evaluation into whichever later conditional first reads
+  // the result, away from its (immovable) s_load / s_mov statements, and has to
+  // carry every SGPR operand there through VGPR lanes.
+  asm volatile("" : "+v"(r));
+  if constexpr (GRAD) asm volatile("" : "+v"(gx), "+v"(gy), "+v"(gz));
+}
+
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+// LAMMPS quaternion (w,x,y,z) -> rotation matrix, row-major R[3*a+b], body->space.
+__device__ __forceinline__ void quat_to_mat(const double q0, const double q1, const double q2, const double q3,
+                                            double* R)
+{
+  const double w2 = q0 * q0, i2 = q1 * q1, j2 = q2 * q2, k2 = q3 * q3;
+  const double twoij = 2.0 * q1 * q2, twoik = 2.0 * q1 * q3, twojk = 2.0 * q2 * q3;
+  const double twoiw = 2.0 * q1 * q0, twojw = 2.0 * q2 * q0, twokw = 2.0 * q3 * q0;
+  R[0] = w2 + i2 - j2 - k2; R[1] = twoij - twokw;     R[2] = twojw + twoik;
+  R[3] = twoij + twokw;     R[4] = w2 - i2 + j2 - k2; R[5] = twojk - twoiw;
+  R[6] = twoik - twojw;     R[7] = twojk + twoiw;     R[8] = w2 - i2 - j2 + k2;
+}
+
+}  // namespace shp

@@ -1,0 +1,137 @@
+// sh_tables.cpp — host-side table construction (docs/SPEC.md §1).
+#include "sh_tables.hpp"
+
+#include "sh_const.hpp"
+
+#include <cmath>
+
+namespace shp {
+
+static const long double kPi = 3.14159265358979323846264338327950288L;
+
+static inline int idx(int n, int m) { return n * (n + 1) / 2 + m; }
+
+void gauss_legendre(int n, std::vector<double>& t, std::vector<double>& w)
+{
+  t.assign(n, 0.0);
+  w.assign(n, 0.0);
+  for (int i = 0; i < (n + 1) / 2; ++i) {
+    long double xx = cosl(kPi * (i + 0.75L) / (n + 0.5L));
+    long double pp = 1.0L;
+    for (int it = 0; it < 100; ++it) {
+      long double p0 = 1.0L, p1 = xx;
+      for (int k = 2; k <= n; ++k) {
+        const long double pk = ((2.0L * k - 1.0L) * xx * p1 - (k - 1.0L) * p0) / k;
+        p0 = p1;
+        p1 = pk;
+      }
+      pp = n * (xx * p1 - p0) / (xx * xx - 1.0L);
+      const long double dx = p1 / pp;
+      xx -= dx;
+      if (fabsl(dx) < 1e-19L) break;
+    }
+    long double p0 = 1.0L, p1 = xx;
+    for (int k = 2; k <= n; ++k) {
+      const long double pk = ((2.0L * k - 1.0L) * xx * p1 - (k - 1.0L) * p0) / k;
+      p0 = p1;
+      p1 = pk;
+    }
+    pp = n * (xx * p1 - p0) / (xx * xx - 1.0L);
+    t[i] = (double)(-xx);
+    t[n - 1 - i] = (double)xx;
+    w[i] = w[n - 1 - i] = (double)(2.0L / ((1.0L - xx * xx) * pp * pp));
+  }
+  if (n % 2 == 1) t[n / 2] = 0.0;
+}
+
+void build_recurrence(int L, std::vector<double>& rc, std::vector<double>& scale)
+{
+  // n-major (k = n(n+1)/2+m); values from sh_const.hpp so that the host-folded
+  // scale and the constants compiled into the kernels agree bit for bit.
+  const int T = (L + 1) * (L + 2) / 2;
+  rc.assign(T, 0.0);
+  scale.assign(T, 1.0);
+  for (int m = 0; m <= L; ++m) {
+    rc[idx(m, m)] = sh_const::pmm(m);
+    for (int n = m + 1; n <= L; ++n) {
+      rc[idx(n, m)] = sh_const::aprime(n, m);
+      scale[idx(n, m)] = sh_const::scale(n, m);
+    }
+  }
+}
+
+void build_coefficients(int L, int lmax, const double* anm, const std::vector<double>& rc,
+                        const std::vector<double>& scale, std::vector<double>& cw)
+{
+  const int T = (L + 1) * (L + 2) / 2;
+  cw.assign(2 * T, 0.0);
+  for (int n = 0; n <= lmax && n <= L; ++n)
+    for (int m = 0; m <= n; ++m) {
+      const int k = idx(n, m);
+      const double fac = (m == 0) ? 1.0 : 2.0;
+      double sc = scale[k];
+      if (n == m) sc = rc[k];  // W_m starts at cw * Pi_m^m
+      cw[2 * k] = fac * anm[2 * k] * sc;
+      cw[2 * k + 1] = (m == 0) ? 0.0 : fac * anm[2 * k + 1] * sc;
+    }
+}
+
+void to_m_major(int L, int width, const std::vector<double>& src, std::vector<double>& dst)
+{
+  dst.assign(src.size(), 0.0);
+  for (int m = 0; m <= L; ++m)
+    for (int n = m; n <= L; ++n) {
+      const int kd = m * (L + 1) - m * (m - 1) / 2 + (n - m);
+      for (int a = 0; a < width; ++a) dst[(size_t)width * kd + a] = src[(size_t)width * idx(n, m) + a];
+    }
+}
+
+double host_radius(int lmax, const double* anm, const double u[3])
+{
+  // r = sum_m Re[W_m (x+iy)^m] with the plain normalised recurrence
+  const double x = u[0], y = u[1], z = u[2];
+  double Cm = 1.0, Sm = 0.0, r = 0.0;
+  double pmm = std::sqrt(1.0 / (4.0 * (double)kPi));
+  for (int m = 0; m <= lmax; ++m) {
+    if (m > 0) pmm = -pmm * std::sqrt((2.0 * m + 1.0) / (2.0 * m));
+    const double fac = (m == 0) ? 1.0 : 2.0;
+    double p2 = 0.0, p1 = pmm;
+    double Wr = anm[2 * idx(m, m)] * p1, Wi = anm[2 * idx(m, m) + 1] * p1;
+    for (int n = m + 1; n <= lmax; ++n) {
+      const double a = std::sqrt((4.0 * n * n - 1.0) / ((double)n * n - (double)m * m));
+      const double b = (n - m < 2) ? 0.0
+                                   : std::sqrt(((2.0 * n + 1.0) * (n + m - 1.0) * (n - m - 1.0)) /
+                                               ((double)(n - m) * (n + m) * (2.0 * n - 3.0)));
+      const double p = a * z * p1 - b * p2;
+      Wr += anm[2 * idx(n, m)] * p;
+      Wi += anm[2 * idx(n, m) + 1] * p;
+      p2 = p1;
+      p1 = p;
+    }
+    r += fac * (Wr * Cm - (m == 0 ? 0.0 : Wi * Sm));
+    const double c = Cm * x - Sm * y, s = Cm * y + Sm * x;
+    Cm = c;
+    Sm = s;
+  }
+  return r;
+}
+
+double default_rmax(int lmax, const double* anm)
+{
+  const int nt = 6 * (lmax + 1) + 2, np = 2 * nt;
+  std::vector<double> t, w;
+  gauss_legendre(nt, t, w);
+  double best = 0.0;
+  for (int a = 0; a < nt; ++a) {
+    const double ct = t[a], st = std::sqrt(1.0 - ct * ct);
+    for (int b = 0; b < np; ++b) {
+      const double ph = 2.0 * (double)kPi * b / np;
+      const double u[3] = {st * std::cos(ph), st * std::sin(ph), ct};
+      const double r = host_radius(lmax, anm, u);
+      if (r > best) best = r;
+    }
+  }
+  return 1.01 * best;
+}
+
+}  // namespace shp

@@ -1,0 +1,576 @@
+// shpair_api.hip — the C ABI of include/shpair.h on top of the HIP kernels.
+//
+// Host side of the drop-in boundary: owns the per-shape tables, the expanded
+// half list and (for the host-pointer entry point) the staging buffers.
+// There is no CPU fallback in this library: every compute path launches the
+// gfx950 kernels of pair_kernel.hpp.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/shpair.h"
+#include "pair_kernel.hpp"
+#include "sh_const.hpp"
+#include "sh_tables.hpp"
+
+namespace shp {
+#define SHP_DECL(L) void shp_launch_L##L(const PairParams&, bool, hipStream_t);
+SHP_DECL(0) SHP_DECL(1) SHP_DECL(2) SHP_DECL(3) SHP_DECL(4) SHP_DECL(5) SHP_DECL(6)
+SHP_DECL(7) SHP_DECL(8) SHP_DECL(9) SHP_DECL(10) SHP_DECL(11) SHP_DECL(12)
+#undef SHP_DECL
+void shp_launch_Lrt(const PairParams&, bool, hipStream_t);
+
+constexpr int kMaxUnrolledL = 12;
+static const pair_launch_fn kLaunch[kMaxUnrolledL + 1] = {
+    shp_launch_L0, shp_launch_L1, shp_launch_L2, shp_launch_L3, shp_launch_L4, shp_launch_L5, shp_launch_L6,
+    shp_launch_L7, shp_launch_L8, shp_launch_L9, shp_launch_L10, shp_launch_L11, shp_launch_L12};
+
+__global__ void count_contact_kernel(const double* __restrict__ x, const int* __restrict__ shtype,
+                                     const double* __restrict__ rmax, const int* __restrict__ pair_i,
+                                     const int* __restrict__ pair_j, int npairs, unsigned long long* out)
+{
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  bool hit = false;
+  if (p < npairs) {
+    const int i = pair_i[p], j = pair_j[p];
+    const double d0 = x[3 * j] - x[3 * i], d1 = x[3 * j + 1] - x[3 * i + 1], d2 = x[3 * j + 2] - x[3 * i + 2];
+    const double rs = rmax[shtype[i]] + rmax[shtype[j]];
+    hit = sqrt(d0 * d0 + d1 * d1 + d2 * d2) < rs;
+  }
+  const unsigned long long m = __ballot(hit);
+  if ((threadIdx.x & 63) == 0 && m) atomicAdd(out, (unsigned long long)__popcll(m));
+}
+
+template <typename T>
+struct DevBuf {
+  T* p = nullptr;
+  size_t cap = 0;
+  hipError_t ensure(size_t n)
+  {
+    if (n <= cap) return hipSuccess;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+    size_t want = n + n / 8 + 16;
+    hipError_t e = hipMalloc((void**)&p, want * sizeof(T));
+    if (e == hipSuccess) cap = want;
+    return e;
+  }
+  void release()
+  {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+};
+
+struct Shape {
+  int lmax = -1;
+  std::vector<double> anm;
+  double rmax = 0.0;
+};
+
+}  // namespace shp
+
+using namespace shp;
+
+struct shpair_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::string err;
+
+  int nq = 16;
+  int ntypes = 0, nshapes = 0;
+  std::vector<Shape> shapes;
+  std::vector<double> kn, expo;
+  bool tables_dirty = true, quad_dirty = true;
+  bool any_nonunit_exponent = false;
+  int lmax = -1, cstride = 0;
+
+  DevBuf<double> d_rc, d_coef, d_rmax, d_kn, d_expo, d_quad;
+  DevBuf<int> d_pair_i, d_pair_j;
+  int npairs = 0;
+  bool have_neighbors = false;
+
+  // staging for the host-pointer entry point
+  DevBuf<double> d_x, d_quat, d_f, d_torque, d_ev;
+  DevBuf<int> d_type, d_shtype;
+  double *h_ft = nullptr;  // pinned: f then torque
+  size_t h_ft_cap = 0;
+  double *h_ev = nullptr;  // pinned 7
+
+  DevBuf<unsigned long long> d_counters;
+  unsigned long long* h_counters = nullptr;  // pinned 2
+
+  int opt_force_volume = 0, opt_timing = 0, opt_count = 0, opt_variant = 0;
+  double* pair_out = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr, evA = nullptr, evB = nullptr;
+  bool timed_last = false, counted_last = false, total_timed_last = false;
+  shpair_stats stats{};
+};
+
+#define CTX_FAIL(ctx, code, ...)                         \
+  do {                                                   \
+    char _b[512];                                        \
+    snprintf(_b, sizeof(_b), __VA_ARGS__);               \
+    (ctx)->err = _b;                                     \
+    return (code);                                       \
+  } while (0)
+
+#define HIPCHK(ctx, call)                                                                          \
+  do {                                                                                             \
+    hipError_t _e = (call);                                                                        \
+    if (_e != hipSuccess)                                                                          \
+      CTX_FAIL(ctx, SHPAIR_EHIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(_e), __FILE__, __LINE__); \
+  } while (0)
+
+extern "C" {
+
+const char* shpair_version(void) { return "shpair 0.1 gfx950"; }
+
+const char* shpair_strerror(int code)
+{
+  switch (code) {
+    case SHPAIR_OK: return "ok";
+    case SHPAIR_EINVAL: return "invalid argument";
+    case SHPAIR_ENODEV: return "no usable HIP device (this library has no CPU fallback)";
+    case SHPAIR_EHIP: return "HIP runtime error";
+    case SHPAIR_ESTATE: return "call order error: shapes, coefficients or neighbour list not set";
+    case SHPAIR_ENOMEM: return "out of memory";
+    case SHPAIR_ELMAX: return "lmax or nq above the compiled limit";
+    default: return "unknown shpair error";
+  }
+}
+
+const char* shpair_last_error(const shpair_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int shpair_create(shpair_ctx** out, int device_id)
+{
+  if (!out) return SHPAIR_EINVAL;
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return SHPAIR_ENODEV;
+  if (device_id < 0 || device_id >= ndev) return SHPAIR_ENODEV;
+  if (hipSetDevice(device_id) != hipSuccess) return SHPAIR_ENODEV;
+  shpair_ctx* c = new (std::nothrow) shpair_ctx();
+  if (!c) return SHPAIR_ENOMEM;
+  c->device = device_id;
+  if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess ||
+      hipEventCreate(&c->evA) != hipSuccess || hipEventCreate(&c->evB) != hipSuccess ||
+      hipHostMalloc((void**)&c->h_ev, 7 * sizeof(double)) != hipSuccess ||
+      hipHostMalloc((void**)&c->h_counters, 2 * sizeof(unsigned long long)) != hipSuccess ||
+      c->d_counters.ensure(2) != hipSuccess || c->d_ev.ensure(7) != hipSuccess) {
+    shpair_destroy(c);
+    return SHPAIR_EHIP;
+  }
+  *out = c;
+  return SHPAIR_OK;
+}
+
+void shpair_destroy(shpair_ctx* c)
+{
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  c->d_rc.release(); c->d_coef.release(); c->d_rmax.release(); c->d_kn.release(); c->d_expo.release();
+  c->d_quad.release(); c->d_pair_i.release(); c->d_pair_j.release();
+  c->d_x.release(); c->d_quat.release(); c->d_f.release(); c->d_torque.release(); c->d_ev.release();
+  c->d_type.release(); c->d_shtype.release(); c->d_counters.release();
+  if (c->h_ft) (void)hipHostFree(c->h_ft);
+  if (c->h_ev) (void)hipHostFree(c->h_ev);
+  if (c->h_counters) (void)hipHostFree(c->h_counters);
+  if (c->ev0) (void)hipEventDestroy(c->ev0);
+  if (c->ev1) (void)hipEventDestroy(c->ev1);
+  if (c->evA) (void)hipEventDestroy(c->evA);
+  if (c->evB) (void)hipEventDestroy(c->evB);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+int shpair_settings(shpair_ctx* c, int nq)
+{
+  if (!c) return SHPAIR_EINVAL;
+  if (nq < 1) CTX_FAIL(c, SHPAIR_EINVAL, "pair_style sh: nq must be >= 1 (got %d)", nq);
+  if (nq > SHPAIR_MAX_NQ) CTX_FAIL(c, SHPAIR_ELMAX, "pair_style sh: nq %d > %d", nq, SHPAIR_MAX_NQ);
+  c->nq = nq;
+  c->quad_dirty = true;
+  return SHPAIR_OK;
+}
+
+int shpair_set_ntypes(shpair_ctx* c, int ntypes, int nshapes)
+{
+  if (!c) return SHPAIR_EINVAL;
+  if (ntypes < 1 || nshapes < 1) CTX_FAIL(c, SHPAIR_EINVAL, "ntypes (%d) and nshapes (%d) must be >= 1", ntypes, nshapes);
+  c->ntypes = ntypes;
+  c->nshapes = nshapes;
+  c->shapes.assign(nshapes, Shape());
+  c->kn.assign((size_t)(ntypes + 1) * (ntypes + 1), std::nan(""));
+  c->expo.assign((size_t)(ntypes + 1) * (ntypes + 1), std::nan(""));
+  c->tables_dirty = true;
+  return SHPAIR_OK;
+}
+
+int shpair_set_shape(shpair_ctx* c, int ishape, int lmax, const double* anm, double rmax)
+{
+  if (!c) return SHPAIR_EINVAL;
+  if (c->nshapes <= 0) CTX_FAIL(c, SHPAIR_ESTATE, "shpair_set_ntypes() must come first");
+  if (ishape < 0 || ishape >= c->nshapes) CTX_FAIL(c, SHPAIR_EINVAL, "shape index %d outside [0,%d)", ishape, c->nshapes);
+  if (!anm) CTX_FAIL(c, SHPAIR_EINVAL, "null coefficient pointer");
+  if (lmax < 0) CTX_FAIL(c, SHPAIR_EINVAL, "lmax %d < 0", lmax);
+  if (lmax > SHPAIR_MAX_LMAX) CTX_FAIL(c, SHPAIR_ELMAX, "lmax %d > %d", lmax, SHPAIR_MAX_LMAX);
+  const int n = (lmax + 1) * (lmax + 2);
+  for (int k = 0; k < n; ++k)
+    if (!std::isfinite(anm[k])) CTX_FAIL(c, SHPAIR_EINVAL, "shape %d: coefficient %d is not finite", ishape, k);
+  Shape& s = c->shapes[ishape];
+  s.lmax = lmax;
+  s.anm.assign(anm, anm + n);
+  s.rmax = (rmax > 0.0) ? rmax : default_rmax(lmax, anm);
+  if (!(s.rmax > 0.0) || !std::isfinite(s.rmax)) CTX_FAIL(c, SHPAIR_EINVAL, "shape %d: bounding radius %g is not positive", ishape, s.rmax);
+  c->tables_dirty = true;
+  return SHPAIR_OK;
+}
+
+int shpair_set_coeff(shpair_ctx* c, int itype, int jtype, double kn, double exponent)
+{
+  if (!c) return SHPAIR_EINVAL;
+  if (c->ntypes <= 0) CTX_FAIL(c, SHPAIR_ESTATE, "shpair_set_ntypes() must come first");
+  if (itype < 1 || itype > c->ntypes || jtype < 1 || jtype > c->ntypes)
+    CTX_FAIL(c, SHPAIR_EINVAL, "pair_coeff types %d %d outside [1,%d]", itype, jtype, c->ntypes);
+  if (!(kn >= 0.0) || !std::isfinite(kn)) CTX_FAIL(c, SHPAIR_EINVAL, "pair_coeff: kn %g must be finite and >= 0", kn);
+  if (!(exponent >= 1.0) || !std::isfinite(exponent)) CTX_FAIL(c, SHPAIR_EINVAL, "pair_coeff: exponent %g must be finite and >= 1", exponent);
+  c->kn[(size_t)itype * (c->ntypes + 1) + jtype] = kn;
+  c->expo[(size_t)itype * (c->ntypes + 1) + jtype] = exponent;
+  c->tables_dirty = true;
+  return SHPAIR_OK;
+}
+
+int shpair_get_rmax(const shpair_ctx* c, int ishape, double* rmax)
+{
+  if (!c || !rmax) return SHPAIR_EINVAL;
+  if (ishape < 0 || ishape >= c->nshapes || c->shapes[ishape].lmax < 0) return SHPAIR_EINVAL;
+  *rmax = c->shapes[ishape].rmax;
+  return SHPAIR_OK;
+}
+
+int shpair_shape_radius(int lmax, const double* anm, const double* u, double* r)
+{
+  if (lmax < 0 || lmax > SHPAIR_MAX_LMAX || !anm || !u || !r) return SHPAIR_EINVAL;
+  *r = host_radius(lmax, anm, u);
+  return SHPAIR_OK;
+}
+
+int shpair_shape_default_rmax(int lmax, const double* anm, double* rmax)
+{
+  if (lmax < 0 || lmax > SHPAIR_MAX_LMAX || !anm || !rmax) return SHPAIR_EINVAL;
+  *rmax = default_rmax(lmax, anm);
+  return SHPAIR_OK;
+}
+
+static int upload_pairs(shpair_ctx* c, const std::vector<int>& pi, const std::vector<int>& pj)
+{
+  const size_t n = pi.size();
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, c->d_pair_i.ensure(n ? n : 1));
+  HIPCHK(c, c->d_pair_j.ensure(n ? n : 1));
+  // the previous list may still be in use by an enqueued compute
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (n) {
+    HIPCHK(c, hipMemcpy(c->d_pair_i.p, pi.data(), n * sizeof(int), hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->d_pair_j.p, pj.data(), n * sizeof(int), hipMemcpyHostToDevice));
+  }
+  c->npairs = (int)n;
+  c->have_neighbors = true;
+  return SHPAIR_OK;
+}
+
+int shpair_set_neighbors(shpair_ctx* c, int inum, const int* ilist, const int* numneigh, const int* const* firstneigh)
+{
+  if (!c) return SHPAIR_EINVAL;
+  if (inum < 0 || (inum > 0 && (!ilist || !numneigh || !firstneigh))) CTX_FAIL(c, SHPAIR_EINVAL, "bad neighbour list arguments");
+  size_t tot = 0;
+  for (int ii = 0; ii < inum; ++ii) {
+    const int n = numneigh[ilist[ii]];
+    if (n < 0) CTX_FAIL(c, SHPAIR_EINVAL, "numneigh[%d] = %d", ilist[ii], n);
+    tot += (size_t)n;
+  }
+  if (tot > 0x7fffffffULL) CTX_FAIL(c, SHPAIR_EINVAL, "half list too long (%zu pairs)", tot);
+  std::vector<int> pi, pj;
+  pi.reserve(tot);
+  pj.reserve(tot);
+  for (int ii = 0; ii < inum; ++ii) {
+    const int i = ilist[ii];
+    const int* jl = firstneigh[i];
+    const int n = numneigh[i];
+    if (n > 0 && !jl) CTX_FAIL(c, SHPAIR_EINVAL, "firstneigh[%d] is null", i);
+    for (int jj = 0; jj < n; ++jj) {
+      pi.push_back(i);
+      pj.push_back(jl[jj] & SHPAIR_NEIGHMASK);
+    }
+  }
+  return upload_pairs(c, pi, pj);
+}
+
+int shpair_set_neighbors_csr(shpair_ctx* c, int inum, const int* ilist, const int* offsets, const int* jlist)
+{
+  if (!c) return SHPAIR_EINVAL;
+  if (inum < 0 || (inum > 0 && (!ilist || !offsets))) CTX_FAIL(c, SHPAIR_EINVAL, "bad neighbour list arguments");
+  std::vector<int> pi, pj;
+  if (inum > 0) {
+    if (offsets[0] != 0) CTX_FAIL(c, SHPAIR_EINVAL, "offsets[0] must be 0");
+    const int tot = offsets[inum];
+    if (tot < 0 || (tot > 0 && !jlist)) CTX_FAIL(c, SHPAIR_EINVAL, "bad CSR neighbour list");
+    pi.reserve(tot);
+    pj.reserve(tot);
+    for (int ii = 0; ii < inum; ++ii) {
+      if (offsets[ii + 1] < offsets[ii]) CTX_FAIL(c, SHPAIR_EINVAL, "offsets not monotone at %d", ii);
+      for (int p = offsets[ii]; p < offsets[ii + 1]; ++p) {
+        pi.push_back(ilist[ii]);
+        pj.push_back(jlist[p] & SHPAIR_NEIGHMASK);
+      }
+    }
+  }
+  return upload_pairs(c, pi, pj);
+}
+
+static int upload_tables(shpair_ctx* c)
+{
+  if (c->nshapes <= 0 || c->ntypes <= 0) CTX_FAIL(c, SHPAIR_ESTATE, "shpair_set_ntypes() not called");
+  int L = -1;
+  for (int s = 0; s < c->nshapes; ++s) {
+    if (c->shapes[s].lmax < 0) CTX_FAIL(c, SHPAIR_ESTATE, "shape %d was never set", s);
+    if (c->shapes[s].lmax > L) L = c->shapes[s].lmax;
+  }
+  c->any_nonunit_exponent = false;
+  for (int a = 1; a <= c->ntypes; ++a)
+    for (int b = 1; b <= c->ntypes; ++b) {
+      const double k = c->kn[(size_t)a * (c->ntypes + 1) + b], m = c->expo[(size_t)a * (c->ntypes + 1) + b];
+      if (std::isnan(k) || std::isnan(m)) CTX_FAIL(c, SHPAIR_ESTATE, "pair_coeff for types %d %d was never set", a, b);
+      if (m != 1.0) c->any_nonunit_exponent = true;
+    }
+  std::vector<double> rc_n, rc, scale, cw_n, cw, all, rmax;
+  build_recurrence(L, rc_n, scale);
+  to_m_major(L, 1, rc_n, rc);
+  const int T = (L + 1) * (L + 2) / 2;
+  all.reserve((size_t)c->nshapes * 2 * T);
+  for (int s = 0; s < c->nshapes; ++s) {
+    build_coefficients(L, c->shapes[s].lmax, c->shapes[s].anm.data(), rc_n, scale, cw_n);
+    to_m_major(L, 2, cw_n, cw);
+    cw.resize(sh_chunk_stride(L), 0.0);
+    all.insert(all.end(), cw.begin(), cw.end());
+    rmax.push_back(c->shapes[s].rmax);
+  }
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, c->d_rc.ensure(rc.size()));
+  HIPCHK(c, c->d_coef.ensure(all.size()));
+  HIPCHK(c, c->d_rmax.ensure(rmax.size()));
+  HIPCHK(c, c->d_kn.ensure(c->kn.size()));
+  HIPCHK(c, c->d_expo.ensure(c->expo.size()));
+  HIPCHK(c, hipMemcpy(c->d_rc.p, rc.data(), rc.size() * sizeof(double), hipMemcpyHostToDevice));
+  HIPCHK(c, hipMemcpy(c->d_coef.p, all.data(), all.size() * sizeof(double), hipMemcpyHostToDevice));
+  HIPCHK(c, hipMemcpy(c->d_rmax.p, rmax.data(), rmax.size() * sizeof(double), hipMemcpyHostToDevice));
+  // unset entries were rejected above; upload as is
+  HIPCHK(c, hipMemcpy(c->d_kn.p, c->kn.data(), c->kn.size() * sizeof(double), hipMemcpyHostToDevice));
+  HIPCHK(c, hipMemcpy(c->d_expo.p, c->expo.data(), c->expo.size() * sizeof(double), hipMemcpyHostToDevice));
+  c->lmax = L;
+  c->cstride = sh_chunk_stride(L);
+  (void)T;
+  c->tables_dirty = false;
+  return SHPAIR_OK;
+}
+
+static int upload_quadrature(shpair_ctx* c)
+{
+  const int nq = c->nq, npsi = 2 * nq;
+  std::vector<double> t, w, q(2 * nq + 2 * npsi);
+  gauss_legendre(nq, t, w);
+  for (int k = 0; k < nq; ++k) {
+    q[k] = t[k];
+    q[nq + k] = w[k];
+  }
+  for (int l = 0; l < npsi; ++l) {
+    const double psi = 2.0 * 3.14159265358979323846264338327950288 * (l + 0.5) / npsi;
+    q[2 * nq + l] = std::cos(psi);
+    q[2 * nq + npsi + l] = std::sin(psi);
+  }
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, c->d_quad.ensure(q.size()));
+  HIPCHK(c, hipMemcpy(c->d_quad.p, q.data(), q.size() * sizeof(double), hipMemcpyHostToDevice));
+  c->quad_dirty = false;
+  return SHPAIR_OK;
+}
+
+int shpair_compute_device(shpair_ctx* c, int nlocal, int nghost, const double* x, const double* quat, const int* type,
+                          const int* shtype, int newton_pair, int eflag, int vflag, double* f, double* torque,
+                          double* ev, void* stream)
+{
+  if (!c) return SHPAIR_EINVAL;
+  if (nlocal < 0 || nghost < 0) CTX_FAIL(c, SHPAIR_EINVAL, "negative atom counts");
+  if (!c->have_neighbors) CTX_FAIL(c, SHPAIR_ESTATE, "no neighbour list: call shpair_set_neighbors() first");
+  if ((eflag || vflag) && !ev) CTX_FAIL(c, SHPAIR_EINVAL, "eflag/vflag set but ev_dev is null");
+  HIPCHK(c, hipSetDevice(c->device));
+  if (c->tables_dirty) {
+    const int rc = upload_tables(c);
+    if (rc) return rc;
+  }
+  if (c->quad_dirty) {
+    const int rc = upload_quadrature(c);
+    if (rc) return rc;
+  }
+  c->timed_last = false;
+  c->counted_last = false;
+  c->stats.n_candidates = c->npairs;
+  if (c->npairs == 0) return SHPAIR_OK;
+  if (!x || !quat || !type || !shtype || !f || !torque) CTX_FAIL(c, SHPAIR_EINVAL, "null atom array");
+  hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+
+  PairParams P;
+  P.x = x; P.quat = quat; P.type = type; P.shtype = shtype; P.f = f; P.torque = torque;
+  P.pair_i = c->d_pair_i.p; P.pair_j = c->d_pair_j.p; P.npairs = c->npairs;
+  P.nlocal = nlocal; P.newton_pair = newton_pair ? 1 : 0;
+  P.rc = c->d_rc.p; P.coef = c->d_coef.p; P.rmax = c->d_rmax.p; P.cstride = c->cstride; P.lmax = c->lmax;
+  P.kn = c->d_kn.p; P.expo = c->d_expo.p; P.ntypes = c->ntypes;
+  const int nq = c->nq;
+  P.glt = c->d_quad.p; P.glw = c->d_quad.p + nq; P.cpsi = c->d_quad.p + 2 * nq; P.spsi = c->d_quad.p + 4 * nq;
+  P.nq = nq;
+  P.ev = ev; P.pair_out = c->pair_out;
+  P.counters = nullptr;
+  P.eflag = eflag ? 1 : 0; P.vflag = vflag ? 1 : 0; P.force_volume = c->opt_force_volume;
+  if (c->opt_count) {
+    HIPCHK(c, hipMemsetAsync(c->d_counters.p, 0, 2 * sizeof(unsigned long long), st));
+    P.counters = c->d_counters.p;
+  }
+  const bool needv = c->opt_force_volume || eflag || c->any_nonunit_exponent;
+  if (c->opt_timing) HIPCHK(c, hipEventRecord(c->ev0, st));
+  if (c->lmax <= kMaxUnrolledL && c->opt_variant != 1) kLaunch[c->lmax](P, needv, st);
+  else shp_launch_Lrt(P, needv, st);
+  HIPCHK(c, hipGetLastError());
+  if (c->opt_timing) {
+    HIPCHK(c, hipEventRecord(c->ev1, st));
+    c->timed_last = true;
+  }
+  if (c->opt_count) {
+    HIPCHK(c, hipMemcpyAsync(c->h_counters, c->d_counters.p, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipEventRecord(c->evB, st));
+    c->counted_last = true;
+  }
+  return SHPAIR_OK;
+}
+
+int shpair_compute(shpair_ctx* c, int nlocal, int nghost, const double* x, const double* quat, const int* type,
+                   const int* shtype, int newton_pair, int eflag, int vflag, double* f, double* torque,
+                   double* eng_vdwl, double* virial)
+{
+  if (!c) return SHPAIR_EINVAL;
+  if (nlocal < 0 || nghost < 0) CTX_FAIL(c, SHPAIR_EINVAL, "negative atom counts");
+  if (!c->have_neighbors) CTX_FAIL(c, SHPAIR_ESTATE, "no neighbour list: call shpair_set_neighbors() first");
+  const size_t nall = (size_t)nlocal + (size_t)nghost;
+  if (nall == 0 || c->npairs == 0) {
+    c->stats.n_candidates = c->npairs;
+    c->timed_last = c->counted_last = false;
+    return SHPAIR_OK;
+  }
+  if (!x || !quat || !type || !shtype || !f || !torque) CTX_FAIL(c, SHPAIR_EINVAL, "null atom array");
+  if (eflag && !eng_vdwl) CTX_FAIL(c, SHPAIR_EINVAL, "eflag set but eng_vdwl is null");
+  if (vflag && !virial) CTX_FAIL(c, SHPAIR_EINVAL, "vflag set but virial is null");
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, c->d_x.ensure(3 * nall));
+  HIPCHK(c, c->d_quat.ensure(4 * nall));
+  HIPCHK(c, c->d_type.ensure(nall));
+  HIPCHK(c, c->d_shtype.ensure(nall));
+  HIPCHK(c, c->d_f.ensure(3 * nall));
+  HIPCHK(c, c->d_torque.ensure(3 * nall));
+  if (c->h_ft_cap < 6 * nall) {
+    if (c->h_ft) (void)hipHostFree(c->h_ft);
+    c->h_ft = nullptr;
+    c->h_ft_cap = 0;
+    HIPCHK(c, hipHostMalloc((void**)&c->h_ft, (6 * nall + 64) * sizeof(double)));
+    c->h_ft_cap = 6 * nall + 64;
+  }
+  hipStream_t st = c->stream;
+  HIPCHK(c, hipEventRecord(c->evA, st));
+  HIPCHK(c, hipMemcpyAsync(c->d_x.p, x, 3 * nall * sizeof(double), hipMemcpyHostToDevice, st));
+  HIPCHK(c, hipMemcpyAsync(c->d_quat.p, quat, 4 * nall * sizeof(double), hipMemcpyHostToDevice, st));
+  HIPCHK(c, hipMemcpyAsync(c->d_type.p, type, nall * sizeof(int), hipMemcpyHostToDevice, st));
+  HIPCHK(c, hipMemcpyAsync(c->d_shtype.p, shtype, nall * sizeof(int), hipMemcpyHostToDevice, st));
+  HIPCHK(c, hipMemsetAsync(c->d_f.p, 0, 3 * nall * sizeof(double), st));
+  HIPCHK(c, hipMemsetAsync(c->d_torque.p, 0, 3 * nall * sizeof(double), st));
+  HIPCHK(c, hipMemsetAsync(c->d_ev.p, 0, 7 * sizeof(double), st));
+  const int rc = shpair_compute_device(c, nlocal, nghost, c->d_x.p, c->d_quat.p, c->d_type.p, c->d_shtype.p,
+                                       newton_pair, eflag, vflag, c->d_f.p, c->d_torque.p, c->d_ev.p, st);
+  if (rc) return rc;
+  HIPCHK(c, hipMemcpyAsync(c->h_ft, c->d_f.p, 3 * nall * sizeof(double), hipMemcpyDeviceToHost, st));
+  HIPCHK(c, hipMemcpyAsync(c->h_ft + 3 * nall, c->d_torque.p, 3 * nall * sizeof(double), hipMemcpyDeviceToHost, st));
+  HIPCHK(c, hipMemcpyAsync(c->h_ev, c->d_ev.p, 7 * sizeof(double), hipMemcpyDeviceToHost, st));
+  HIPCHK(c, hipEventRecord(c->evB, st));
+  HIPCHK(c, hipStreamSynchronize(st));
+  c->total_timed_last = true;
+  for (size_t k = 0; k < 3 * nall; ++k) {
+    f[k] += c->h_ft[k];
+    torque[k] += c->h_ft[3 * nall + k];
+  }
+  if (eflag) *eng_vdwl += c->h_ev[0];
+  if (vflag)
+    for (int a = 0; a < 6; ++a) virial[a] += c->h_ev[1 + a];
+  return SHPAIR_OK;
+}
+
+int shpair_set_option(shpair_ctx* c, const char* key, int value)
+{
+  if (!c || !key) return SHPAIR_EINVAL;
+  if (!strcmp(key, "force_volume")) c->opt_force_volume = value ? 1 : 0;
+  else if (!strcmp(key, "timing")) c->opt_timing = value ? 1 : 0;
+  else if (!strcmp(key, "count")) c->opt_count = value ? 1 : 0;
+  else if (!strcmp(key, "variant")) c->opt_variant = value;
+  else CTX_FAIL(c, SHPAIR_EINVAL, "unknown option '%s'", key);
+  return SHPAIR_OK;
+}
+
+int shpair_get_stats(shpair_ctx* c, shpair_stats* out)
+{
+  if (!c || !out) return SHPAIR_EINVAL;
+  HIPCHK(c, hipSetDevice(c->device));
+  c->stats.kernel_ms = 0.0;
+  c->stats.total_ms = 0.0;
+  c->stats.n_contact = -1;
+  c->stats.n_touching = -1;
+  if (c->timed_last) {
+    HIPCHK(c, hipEventSynchronize(c->ev1));
+    float ms = 0.f;
+    HIPCHK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
+    c->stats.kernel_ms = ms;
+  }
+  if (c->counted_last) {
+    HIPCHK(c, hipEventSynchronize(c->evB));
+    c->stats.n_contact = (long long)c->h_counters[0];
+    c->stats.n_touching = (long long)c->h_counters[1];
+  }
+  if (c->total_timed_last) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, c->evA, c->evB) == hipSuccess) c->stats.total_ms = ms;
+  }
+  *out = c->stats;
+  return SHPAIR_OK;
+}
+
+int shpair_set_pair_output(shpair_ctx* c, double* pair_out_dev)
+{
+  if (!c) return SHPAIR_EINVAL;
+  c->pair_out = pair_out_dev;
+  return SHPAIR_OK;
+}
+
+int shpair_synchronize(shpair_ctx* c)
+{
+  if (!c) return SHPAIR_EINVAL;
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return SHPAIR_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,81 @@
+"""Deterministic synthetic packed beds and half neighbour lists.
+
+Stand-in for the reference's gravity-settled beds (no integrator is in scope):
+centres on a jittered HCP lattice at `spacing` x mean radius, orientations
+uniform on SO(3), LAMMPS-layout half neighbour list with cutoff
+Rmax_i + Rmax_j + skin.  Setup code only; no force evaluation happens here.
+"""
+import numpy as np
+
+SEED0 = 20261004
+
+
+def random_quaternions(n, rng):
+    q = rng.normal(size=(n, 4))
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    return q
+
+
+def hcp_lattice(n_target, spacing, aspect=(1.0, 1.0, 1.0)):
+    """>= n_target HCP sites with nearest-neighbour distance `spacing`, trimmed to n_target."""
+    dx, dy, dz = spacing, spacing * np.sqrt(3.0) / 2.0, spacing * np.sqrt(2.0 / 3.0)
+    vol = n_target * dx * dy * dz
+    s = (vol / (aspect[0] * aspect[1] * aspect[2])) ** (1.0 / 3.0)
+    nx = max(1, int(np.ceil(aspect[0] * s / dx)))
+    ny = max(1, int(np.ceil(aspect[1] * s / dy)))
+    nz = max(1, int(np.ceil(aspect[2] * s / dz)))
+    while nx * ny * nz < n_target:
+        nz += 1
+    k, j, i = np.meshgrid(np.arange(nz), np.arange(ny), np.arange(nx), indexing="ij")
+    x = (i + 0.5 * (j % 2) + 0.5 * (k % 2)) * dx
+    y = (j + (k % 2) / 3.0) * dy
+    z = k * dz
+    pts = np.stack([x.ravel(), y.ravel(), z.ravel()], axis=1)
+    return pts[:n_target].copy()
+
+
+def make_bed(n, rmax_by_shape, nshapes=1, spacing=1.9, jitter=0.04, seed=SEED0, aspect=(1.0, 1.0, 1.0)):
+    """Returns dict(x, quat, type, shtype). Mean radius is 1 by construction of the shapes."""
+    rng = np.random.default_rng(seed)
+    x = hcp_lattice(n, spacing, aspect)
+    x += rng.uniform(-jitter, jitter, size=x.shape)
+    quat = random_quaternions(n, rng)
+    shtype = rng.integers(0, nshapes, size=n).astype(np.int32) if nshapes > 1 else np.zeros(n, np.int32)
+    type_ = np.ones(n, dtype=np.int32)
+    return dict(x=np.ascontiguousarray(x), quat=np.ascontiguousarray(quat), type=type_, shtype=shtype,
+                rmax=np.asarray(rmax_by_shape, dtype=np.float64))
+
+
+def half_neighbor_list(x, shtype, rmax_by_shape, skin=0.1, nlocal=None, owner_rule=None):
+    """LAMMPS-layout half list in CSR form: (ilist, offsets, jlist).
+
+    Every unordered pair within Rmax_i + Rmax_j + skin appears once, stored with
+    the lower index as i (newton on).  With `nlocal`, only pairs with at least
+    one local atom are kept, i is always local, and `owner_rule(i, j)` (bool
+    array) may drop local-ghost pairs that another rank evaluates.
+    """
+    from scipy.spatial import cKDTree
+    rmax = np.asarray(rmax_by_shape, dtype=np.float64)
+    n = x.shape[0]
+    nlocal = n if nlocal is None else nlocal
+    rcut = 2.0 * rmax.max() + skin
+    pairs = cKDTree(x).query_pairs(rcut, output_type="ndarray")
+    a, b = pairs[:, 0], pairs[:, 1]
+    d = np.linalg.norm(x[a] - x[b], axis=1)
+    keep = d < rmax[shtype[a]] + rmax[shtype[b]] + skin
+    a, b = a[keep], b[keep]
+    # i must be local: swap pairs whose lower index is a ghost
+    sw = a >= nlocal
+    a, b = np.where(sw, b, a), np.where(sw, a, b)
+    keep = a < nlocal
+    if owner_rule is not None:
+        gh = b >= nlocal
+        keep &= ~gh | owner_rule(a, b)
+    a, b = a[keep], b[keep]
+    order = np.lexsort((b, a))
+    a, b = a[order], b[order]
+    counts = np.bincount(a, minlength=nlocal)[:nlocal]
+    offsets = np.zeros(nlocal + 1, dtype=np.int32)
+    np.cumsum(counts, out=offsets[1:])
+    ilist = np.arange(nlocal, dtype=np.int32)
+    return ilist, offsets, b.astype(np.int32)

@@ -1,0 +1,226 @@
+"""ctypes binding of include/shpair.h (the C ABI of the HIP contact path).
+
+Mirrors the LAMMPS call order of the reference's PairSH (sources ABSENT FROM
+MOUNT): settings() -> coeff() -> init_style()/init_one() ->
+[neighbour build] -> compute(eflag, vflag).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int)
+
+
+class ShPairError(RuntimeError):
+    def __init__(self, code, detail=""):
+        self.code = code
+        msg = load_library().shpair_strerror(code).decode()
+        super().__init__(f"shpair error {code}: {msg}" + (f" — {detail}" if detail else ""))
+
+
+class Stats(C.Structure):
+    _fields_ = [("n_candidates", C.c_longlong), ("n_contact", C.c_longlong), ("n_touching", C.c_longlong),
+                ("kernel_ms", C.c_double), ("total_ms", C.c_double)]
+
+
+# every symbol include/shpair.h declares: name -> (restype, argtypes)
+SYMBOLS = {
+    "shpair_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int]),
+    "shpair_destroy": (None, [C.c_void_p]),
+    "shpair_strerror": (C.c_char_p, [C.c_int]),
+    "shpair_last_error": (C.c_char_p, [C.c_void_p]),
+    "shpair_version": (C.c_char_p, []),
+    "shpair_settings": (C.c_int, [C.c_void_p, C.c_int]),
+    "shpair_set_ntypes": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "shpair_set_shape": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _dp, C.c_double]),
+    "shpair_set_coeff": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double]),
+    "shpair_get_rmax": (C.c_int, [C.c_void_p, C.c_int, _dp]),
+    "shpair_shape_radius": (C.c_int, [C.c_int, _dp, _dp, _dp]),
+    "shpair_shape_default_rmax": (C.c_int, [C.c_int, _dp, _dp]),
+    "shpair_set_neighbors": (C.c_int, [C.c_void_p, C.c_int, _ip, _ip, C.POINTER(_ip)]),
+    "shpair_set_neighbors_csr": (C.c_int, [C.c_void_p, C.c_int, _ip, _ip, _ip]),
+    "shpair_compute": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _dp, _dp, _ip, _ip, C.c_int, C.c_int, C.c_int,
+                                 _dp, _dp, _dp, _dp]),
+    "shpair_compute_device": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                        C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                        C.c_void_p, C.c_void_p]),
+    "shpair_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
+    "shpair_get_stats": (C.c_int, [C.c_void_p, C.POINTER(Stats)]),
+    "shpair_set_pair_output": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "shpair_synchronize": (C.c_int, [C.c_void_p]),
+}
+
+
+def library_path():
+    return os.path.join(_HERE, "libshpair.so")
+
+
+def load_library():
+    """Loads libshpair.so. Raises (never falls back) if it is not built."""
+    global _LIB
+    if _LIB is None:
+        path = library_path()
+        if not os.path.exists(path):
+            raise ImportError(f"{path} is not built: run `make -C lammps-spherharm_amd/csrc` "
+                              "(or __graft_entry__.build()); there is no CPU fallback")
+        lib = C.CDLL(path)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(lib, name)  # AttributeError if the ABI lost a symbol
+            fn.restype = res
+            fn.argtypes = args
+        _LIB = lib
+    return _LIB
+
+
+def _d(a):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    return a, a.ctypes.data_as(_dp)
+
+
+def _i(a):
+    a = np.ascontiguousarray(a, dtype=np.int32)
+    return a, a.ctypes.data_as(_ip)
+
+
+def shape_radius(lmax, anm, u):
+    anm, pa = _d(anm)
+    u, pu = _d(u)
+    r = C.c_double()
+    rc = load_library().shpair_shape_radius(lmax, pa, pu, C.byref(r))
+    if rc:
+        raise ShPairError(rc)
+    return r.value
+
+
+def shape_default_rmax(lmax, anm):
+    anm, pa = _d(anm)
+    r = C.c_double()
+    rc = load_library().shpair_shape_default_rmax(lmax, pa, C.byref(r))
+    if rc:
+        raise ShPairError(rc)
+    return r.value
+
+
+class ShPair:
+    """One context = one rank's `pair_style sh` instance on one GPU."""
+
+    def __init__(self, device=0):
+        self._lib = load_library()
+        h = C.c_void_p()
+        rc = self._lib.shpair_create(C.byref(h), device)
+        if rc:
+            raise ShPairError(rc, "shpair_create")
+        self._h = h
+        self.nshapes = 0
+        self.ntypes = 0
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.shpair_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def _chk(self, rc):
+        if rc:
+            raise ShPairError(rc, self._lib.shpair_last_error(self._h).decode())
+
+    # --- PairSH::settings / coeff ------------------------------------------------
+    def settings(self, nq):
+        self._chk(self._lib.shpair_settings(self._h, int(nq)))
+
+    def set_ntypes(self, ntypes, nshapes):
+        self._chk(self._lib.shpair_set_ntypes(self._h, int(ntypes), int(nshapes)))
+        self.ntypes, self.nshapes = ntypes, nshapes
+
+    def set_shape(self, ishape, lmax, anm, rmax=0.0):
+        anm, pa = _d(anm)
+        if anm.size != (lmax + 1) * (lmax + 2):
+            raise ValueError(f"anm has {anm.size} doubles, expected {(lmax + 1) * (lmax + 2)}")
+        self._chk(self._lib.shpair_set_shape(self._h, int(ishape), int(lmax), pa, float(rmax)))
+
+    def coeff(self, itype, jtype, kn, exponent):
+        """`pair_coeff I J kn exponent`; itype/jtype may be '*' or int; mirrored i<->j."""
+        its = range(1, self.ntypes + 1) if itype == "*" else [int(itype)]
+        jts = range(1, self.ntypes + 1) if jtype == "*" else [int(jtype)]
+        for a in its:
+            for b in jts:
+                self._chk(self._lib.shpair_set_coeff(self._h, a, b, float(kn), float(exponent)))
+                self._chk(self._lib.shpair_set_coeff(self._h, b, a, float(kn), float(exponent)))
+
+    def rmax(self, ishape):
+        r = C.c_double()
+        self._chk(self._lib.shpair_get_rmax(self._h, int(ishape), C.byref(r)))
+        return r.value
+
+    def init_one(self, ishape, jshape):
+        """Cutoff of a shape pair, as PairSH::init_one returns it."""
+        return self.rmax(ishape) + self.rmax(jshape)
+
+    # --- neighbour list -----------------------------------------------------------
+    def set_neighbors_csr(self, ilist, offsets, jlist):
+        ilist, pi = _i(ilist)
+        offsets, po = _i(offsets)
+        jlist, pj = _i(jlist)
+        if offsets.size != ilist.size + 1:
+            raise ValueError("offsets must have inum+1 entries")
+        self._chk(self._lib.shpair_set_neighbors_csr(self._h, ilist.size, pi, po, pj))
+
+    def set_neighbors(self, ilist, numneigh, firstneigh):
+        """LAMMPS layout: numneigh/firstneigh indexed by atom id; firstneigh = list of int32 arrays."""
+        ilist, pi = _i(ilist)
+        numneigh, pn = _i(numneigh)
+        keep = [np.ascontiguousarray(a, dtype=np.int32) for a in firstneigh]
+        arr = (_ip * len(keep))(*[a.ctypes.data_as(_ip) for a in keep])
+        self._chk(self._lib.shpair_set_neighbors(self._h, ilist.size, pi, pn, arr))
+
+    # --- PairSH::compute ------------------------------------------------------------
+    def compute(self, nlocal, x, quat, type_, shtype, newton_pair=True, eflag=False, vflag=False,
+                f=None, torque=None):
+        """Host-pointer entry point. Returns (f, torque, eng_vdwl, virial[6]); adds into f/torque if given."""
+        x, px = _d(x)
+        quat, pq = _d(quat)
+        type_, pt = _i(type_)
+        shtype, ps = _i(shtype)
+        nall = x.shape[0]
+        if quat.shape != (nall, 4) or type_.size != nall or shtype.size != nall:
+            raise ValueError("atom arrays disagree on nall")
+        if f is None:
+            f = np.zeros((nall, 3))
+        if torque is None:
+            torque = np.zeros((nall, 3))
+        assert f.flags.c_contiguous and torque.flags.c_contiguous and f.dtype == np.float64
+        eng = C.c_double(0.0)
+        vir = np.zeros(6)
+        self._chk(self._lib.shpair_compute(self._h, int(nlocal), int(nall - nlocal), px, pq, pt, ps,
+                                           int(newton_pair), int(eflag), int(vflag),
+                                           f.ctypes.data_as(_dp), torque.ctypes.data_as(_dp),
+                                           C.byref(eng), vir.ctypes.data_as(_dp)))
+        return f, torque, eng.value, vir
+
+    def compute_device(self, nlocal, nghost, x, quat, type_, shtype, f, torque, newton_pair=True,
+                       eflag=False, vflag=False, ev=None, stream=None):
+        """Device-pointer entry point: arguments are raw device addresses (ints). Asynchronous."""
+        self._chk(self._lib.shpair_compute_device(self._h, int(nlocal), int(nghost), x, quat, type_, shtype,
+                                                  int(newton_pair), int(eflag), int(vflag), f, torque,
+                                                  ev, stream))
+
+    def set_option(self, key, value):
+        self._chk(self._lib.shpair_set_option(self._h, key.encode(), int(value)))
+
+    def set_pair_output(self, dev_ptr):
+        self._chk(self._lib.shpair_set_pair_output(self._h, dev_ptr))
+
+    def stats(self):
+        s = Stats()
+        self._chk(self._lib.shpair_get_stats(self._h, C.byref(s)))
+        return dict(n_candidates=s.n_candidates, n_contact=s.n_contact, n_touching=s.n_touching,
+                    kernel_ms=s.kernel_ms, total_ms=s.total_ms)
+
+    def synchronize(self):
+        self._chk(self._lib.shpair_synchronize(self._h))
