@@ -47,7 +47,7 @@ struct PairParams {
   // outputs / flags
   double* ev;           // 7 doubles or null
   double* pair_out;     // 7 doubles per slot or null
-  unsigned long long* counters;  // [0] contact pairs, [1] touching pairs; or null
+  unsigned char* flags;  // per slot: 1 = contact pair, 2 = touching pair; or null (stats only)
   int eflag;
   int vflag;
   int force_volume;
@@ -247,11 +247,11 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock, SHP_MIN_WAVES) pair_conta
     double* o = P.pair_out + 7 * (size_t)w;
     o[0] = aV; o[1] = S0; o[2] = S1; o[3] = S2; o[4] = T0; o[5] = T1; o[6] = T2;
   }
-  if (P.counters) atomicAdd(&P.counters[0], 1ULL);
-
   const bool touched = NEEDV ? (aV > 0.0) : (S0 != 0.0 || S1 != 0.0 || S2 != 0.0);
+  // statistics go through a byte per slot, summed by count_flags_kernel: one
+  // atomic per pair on a shared counter costs more than the whole kernel
+  if (P.flags) P.flags[w] = touched ? 2 : 1;
   if (!touched) return;
-  if (P.counters) atomicAdd(&P.counters[1], 1ULL);
 
   // SPEC §2.7 force law
   const int ti = P.type[i], tj = P.type[j];

@@ -30,20 +30,17 @@ static const pair_launch_fn kLaunch[kMaxUnrolledL + 1] = {
     shp_launch_L0, shp_launch_L1, shp_launch_L2, shp_launch_L3, shp_launch_L4, shp_launch_L5, shp_launch_L6,
     shp_launch_L7, shp_launch_L8, shp_launch_L9, shp_launch_L10, shp_launch_L11, shp_launch_L12};
 
-__global__ void count_contact_kernel(const double* __restrict__ x, const int* __restrict__ shtype,
-                                     const double* __restrict__ rmax, const int* __restrict__ pair_i,
-                                     const int* __restrict__ pair_j, int npairs, unsigned long long* out)
+// Sums the per-slot flags the pair kernel wrote: out[0] = contact pairs
+// (flag >= 1), out[1] = touching pairs (flag == 2). One atomic per wave.
+__global__ void count_flags_kernel(const unsigned char* __restrict__ flags, int npairs, unsigned long long* out)
 {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
-  bool hit = false;
-  if (p < npairs) {
-    const int i = pair_i[p], j = pair_j[p];
-    const double d0 = x[3 * j] - x[3 * i], d1 = x[3 * j + 1] - x[3 * i + 1], d2 = x[3 * j + 2] - x[3 * i + 2];
-    const double rs = rmax[shtype[i]] + rmax[shtype[j]];
-    hit = sqrt(d0 * d0 + d1 * d1 + d2 * d2) < rs;
+  const unsigned char fl = (p < npairs) ? flags[p] : 0;
+  const unsigned long long m1 = __ballot(fl >= 1), m2 = __ballot(fl == 2);
+  if ((threadIdx.x & 63) == 0) {
+    if (m1) atomicAdd(&out[0], (unsigned long long)__popcll(m1));
+    if (m2) atomicAdd(&out[1], (unsigned long long)__popcll(m2));
   }
-  const unsigned long long m = __ballot(hit);
-  if ((threadIdx.x & 63) == 0 && m) atomicAdd(out, (unsigned long long)__popcll(m));
 }
 
 template <typename T>
@@ -105,6 +102,7 @@ struct shpair_ctx {
   double *h_ev = nullptr;  // pinned 7
 
   DevBuf<unsigned long long> d_counters;
+  DevBuf<unsigned char> d_flags;
   unsigned long long* h_counters = nullptr;  // pinned 2
 
   int opt_force_volume = 0, opt_timing = 0, opt_count = 0, opt_variant = 0;
@@ -181,7 +179,7 @@ void shpair_destroy(shpair_ctx* c)
   c->d_rc.release(); c->d_coef.release(); c->d_rmax.release(); c->d_kn.release(); c->d_expo.release();
   c->d_quad.release(); c->d_pair_i.release(); c->d_pair_j.release();
   c->d_x.release(); c->d_quat.release(); c->d_f.release(); c->d_torque.release(); c->d_ev.release();
-  c->d_type.release(); c->d_shtype.release(); c->d_counters.release();
+  c->d_type.release(); c->d_shtype.release(); c->d_counters.release(); c->d_flags.release();
   if (c->h_ft) (void)hipHostFree(c->h_ft);
   if (c->h_ev) (void)hipHostFree(c->h_ev);
   if (c->h_counters) (void)hipHostFree(c->h_counters);
@@ -439,11 +437,13 @@ int shpair_compute_device(shpair_ctx* c, int nlocal, int nghost, const double* x
   P.glt = c->d_quad.p; P.glw = c->d_quad.p + nq; P.cpsi = c->d_quad.p + 2 * nq; P.spsi = c->d_quad.p + 4 * nq;
   P.nq = nq;
   P.ev = ev; P.pair_out = c->pair_out;
-  P.counters = nullptr;
+  P.flags = nullptr;
   P.eflag = eflag ? 1 : 0; P.vflag = vflag ? 1 : 0; P.force_volume = c->opt_force_volume;
   if (c->opt_count) {
+    HIPCHK(c, c->d_flags.ensure(c->npairs));
     HIPCHK(c, hipMemsetAsync(c->d_counters.p, 0, 2 * sizeof(unsigned long long), st));
-    P.counters = c->d_counters.p;
+    HIPCHK(c, hipMemsetAsync(c->d_flags.p, 0, c->npairs, st));
+    P.flags = c->d_flags.p;
   }
   const bool needv = c->opt_force_volume || eflag || c->any_nonunit_exponent;
   if (c->opt_timing) HIPCHK(c, hipEventRecord(c->ev0, st));
@@ -455,6 +455,9 @@ int shpair_compute_device(shpair_ctx* c, int nlocal, int nghost, const double* x
     c->timed_last = true;
   }
   if (c->opt_count) {
+    hipLaunchKernelGGL(count_flags_kernel, dim3((c->npairs + 255) / 256), dim3(256), 0, st, c->d_flags.p, c->npairs,
+                       c->d_counters.p);
+    HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(c->h_counters, c->d_counters.p, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipEventRecord(c->evB, st));
     c->counted_last = true;

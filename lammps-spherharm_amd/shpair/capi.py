@@ -68,6 +68,15 @@ def load_library():
         if not os.path.exists(path):
             raise ImportError(f"{path} is not built: run `make -C lammps-spherharm_amd/csrc` "
                               "(or __graft_entry__.build()); there is no CPU fallback")
+        # PyTorch-ROCm bundles its own libamdhip64.so.7 (same SONAME as /opt/rocm's).
+        # Whichever is loaded first serves the whole process, and torch cannot see the
+        # GPU behind the system runtime ("No HIP GPUs are available"). So when torch is
+        # installed it is imported first and libshpair.so binds to torch's runtime; a
+        # LAMMPS process (no torch) binds to /opt/rocm's through the library's RUNPATH.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         lib = C.CDLL(path)
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(lib, name)  # AttributeError if the ABI lost a symbol

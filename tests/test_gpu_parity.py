@@ -1,0 +1,353 @@
+"""GPU parity tests proper: the HIP path, called through the C ABI
+(include/shpair.h via ctypes), against the CPU oracle on identical seeded
+inputs and against the committed golden vectors.
+
+Tolerance (docs/SPEC.md §4): |dF| <= 1e-9 max|F|, same for torque scaled by
+max(|F|,|tau|); the task's bar is 1e-6.  Both sides are FP64 and differ only
+in operation order / FMA contraction; measured differences are ~1e-15.
+"""
+import ctypes
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from common import make_case, coeff_tables, oracle_compute, rel_err
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-9
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLDEN = sorted(glob.glob(os.path.join(HERE, "golden", "*.npz")))
+
+
+def make_ctx(case, nq, K, E, rmax=None):
+    from shpair import ShPair
+    sp = ShPair(0)
+    sp.settings(nq)
+    nt = K.shape[0] - 1
+    sp.set_ntypes(nt, len(case["shapes"]))
+    for s, a in enumerate(case["shapes"]):
+        sp.set_shape(s, case["lmax"], a, 0.0 if rmax is None else rmax[s])
+    for i in range(1, nt + 1):
+        for j in range(1, nt + 1):
+            sp.coeff(i, j, K[i, j], E[i, j])
+    sp.set_neighbors_csr(case["ilist"], case["offsets"], case["jlist"])
+    return sp
+
+
+def check(f, tq, o):
+    fs = np.abs(o["f"]).max()
+    ts = max(fs, np.abs(o["torque"]).max())
+    assert fs > 0
+    assert rel_err(f, o["f"], fs) < TOL
+    assert rel_err(tq, o["torque"], ts) < TOL
+
+
+@pytest.mark.parametrize("lmax,nq,nshapes,expo,fv", [
+    (0, 8, 1, 1.0, 1), (1, 6, 1, 1.0, 0), (2, 8, 2, 1.5, 0), (3, 7, 1, 1.0, 1), (4, 10, 1, 1.0, 0),
+    (5, 9, 3, 1.25, 0), (6, 16, 1, 1.0, 0), (6, 16, 4, 1.0, 1), (6, 16, 1, 1.25, 0), (7, 12, 1, 1.0, 1),
+    (8, 16, 2, 2.0, 0), (9, 11, 1, 1.0, 1), (10, 20, 1, 1.5, 0), (11, 13, 1, 1.0, 1), (12, 32, 1, 1.0, 0),
+    (12, 32, 1, 1.25, 0), (13, 8, 1, 1.0, 1), (16, 8, 2, 1.25, 0), (20, 6, 1, 1.0, 1)])
+def test_forces_and_torques_match_oracle(oracle, lmax, nq, nshapes, expo, fv):
+    """Every compiled order 0..12, the run-time-order kernel (13..20), odd nq (ragged last slab)."""
+    case = make_case(220 if lmax <= 12 else 120, lmax, nshapes, seed=lmax, rmax_fn=oracle.shape_rmax)
+    K, E = coeff_tables(1, 1000.0, expo)
+    sp = make_ctx(case, nq, K, E)
+    sp.set_option("force_volume", fv)
+    sp.set_option("count", 1)
+    b = case["bed"]
+    f, tq, eng, vir = sp.compute(case["n"], b["x"], b["quat"], b["type"], b["shtype"], eflag=True, vflag=True)
+    st = sp.stats()
+    o = oracle_compute(oracle, case, nq, K, E, eflag=True, vflag=True, force_volume=bool(fv))
+    check(f, tq, o)
+    assert abs(eng - o["eng_virial"][0]) < TOL * abs(o["eng_virial"][0])
+    assert np.abs(vir - o["eng_virial"][1:]).max() < TOL * np.abs(o["eng_virial"][1:]).max()
+    assert (st["n_candidates"], st["n_contact"], st["n_touching"]) == tuple(o["counts"])
+    for s in range(nshapes):
+        assert abs(sp.rmax(s) - case["rmax"][s]) < 1e-14
+    sp.close()
+
+
+def test_mixed_types_and_exponents(oracle):
+    case = make_case(300, 6, 3, seed=40, ntypes=3, rmax_fn=oracle.shape_rmax)
+    K, E = coeff_tables(3, kn=lambda i, j: 300.0 * (i + j), expo=lambda i, j: 1.0 + 0.25 * abs(i - j))
+    sp = make_ctx(case, 12, K, E)
+    b = case["bed"]
+    f, tq, eng, vir = sp.compute(case["n"], b["x"], b["quat"], b["type"], b["shtype"], eflag=True, vflag=True)
+    o = oracle_compute(oracle, case, 12, K, E, eflag=True, vflag=True)
+    check(f, tq, o)
+    assert abs(eng - o["eng_virial"][0]) < TOL * abs(o["eng_virial"][0])
+    sp.close()
+
+
+def test_per_pair_integrals_match_oracle(oracle):
+    import torch
+    case = make_case(200, 6, 2, seed=7, amp=0.25, rmax_fn=oracle.shape_rmax)
+    K, E = coeff_tables(1, 1000.0, 1.0)
+    sp = make_ctx(case, 16, K, E)
+    sp.set_option("force_volume", 1)
+    out = torch.zeros(case["jlist"].size, 7, dtype=torch.float64, device="cuda")
+    sp.set_pair_output(out.data_ptr())
+    b = case["bed"]
+    sp.compute(case["n"], b["x"], b["quat"], b["type"], b["shtype"])
+    o = oracle_compute(oracle, case, 16, K, E, force_volume=True, want_pairs=True)
+    got = out.cpu().numpy()
+    assert np.abs(got - o["pairs"]).max() < TOL * np.abs(o["pairs"]).max()
+    assert (got[:, 0] > 0).sum() == o["counts"][2]
+    sp.set_pair_output(None)
+    sp.close()
+
+
+@pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p)[:-4] for p in GOLDEN])
+def test_golden_vectors(path):
+    """Committed vectors only: needs neither the oracle nor /root/reference."""
+    from shpair import ShPair
+    g = np.load(path)
+    lmax, nq = int(g["lmax"]), int(g["nq"])
+    sp = ShPair(0)
+    sp.settings(nq)
+    sp.set_ntypes(1, g["anm"].shape[0])
+    for s, a in enumerate(g["anm"]):
+        sp.set_shape(s, lmax, a)
+        assert abs(sp.rmax(s) - g["rmax"][s]) < 1e-14
+    sp.coeff("*", "*", float(g["kn"]), float(g["exponent"]))
+    sp.set_neighbors_csr(g["ilist"], g["offsets"], g["jlist"])
+    sp.set_option("count", 1)
+    f, tq, eng, vir = sp.compute(g["x"].shape[0], g["x"], g["quat"], g["type"], g["shtype"], eflag=True, vflag=True)
+    fs = np.abs(g["f"]).max()
+    assert np.abs(f - g["f"]).max() < TOL * fs
+    assert np.abs(tq - g["torque"]).max() < TOL * max(fs, np.abs(g["torque"]).max())
+    assert abs(eng - g["eng_virial"][0]) < TOL * g["eng_virial"][0]
+    assert np.abs(vir - g["eng_virial"][1:]).max() < TOL * np.abs(g["eng_virial"][1:]).max()
+    st = sp.stats()
+    assert (st["n_candidates"], st["n_contact"], st["n_touching"]) == tuple(g["counts"])
+    sp.close()
+
+
+def test_lammps_layout_list_equals_csr_and_neighmask(oracle):
+    case = make_case(150, 4, 1, seed=9, rmax_fn=oracle.shape_rmax)
+    K, E = coeff_tables(1)
+    sp = make_ctx(case, 8, K, E)
+    b = case["bed"]
+    f0, t0, _, _ = sp.compute(case["n"], b["x"], b["quat"], b["type"], b["shtype"])
+    # LAMMPS layout: reversed ilist order, per-atom arrays, special bits set on some j
+    of, jl = case["offsets"], case["jlist"].copy()
+    jl[::2] |= np.int32(1 << 30)
+    first = [jl[of[i]:of[i + 1]] for i in range(case["n"])]
+    numneigh = np.diff(of).astype(np.int32)
+    sp.set_neighbors(case["ilist"][::-1].copy(), numneigh, first)
+    f1, t1, _, _ = sp.compute(case["n"], b["x"], b["quat"], b["type"], b["shtype"])
+    fs = np.abs(f0).max()
+    assert np.abs(f1 - f0).max() < 1e-12 * fs and np.abs(t1 - t0).max() < 1e-12 * fs
+    sp.close()
+
+
+def test_newton_off_with_ghosts(oracle):
+    case = make_case(240, 6, 2, seed=11, rmax_fn=oracle.shape_rmax)
+    K, E = coeff_tables(1, 1000.0, 1.25)
+    n, nlocal = case["n"], 120
+    sub = dict(case)
+    sub["ilist"] = case["ilist"][:nlocal]
+    sub["offsets"] = case["offsets"][:nlocal + 1]
+    sub["jlist"] = case["jlist"][:case["offsets"][nlocal]]
+    sp = make_ctx(sub, 10, K, E)
+    b = case["bed"]
+    for newton in (True, False):
+        f = np.zeros((n, 3))
+        tq = np.zeros((n, 3))
+        _, _, eng, vir = sp.compute(nlocal, b["x"], b["quat"], b["type"], b["shtype"], newton_pair=newton,
+                                    eflag=True, vflag=True, f=f, torque=tq)
+        o = oracle_compute(oracle, sub, 10, K, E, nlocal=nlocal, newton_pair=newton, eflag=True, vflag=True)
+        check(f, tq, o)
+        assert abs(eng - o["eng_virial"][0]) < TOL * abs(o["eng_virial"][0])
+        assert np.abs(vir - o["eng_virial"][1:]).max() < TOL * np.abs(o["eng_virial"][1:]).max()
+        if not newton:
+            assert not f[nlocal:].any() and not tq[nlocal:].any()
+    sp.close()
+
+
+def test_compute_adds_into_f_and_torque(oracle):
+    case = make_case(100, 4, 1, seed=12, rmax_fn=oracle.shape_rmax)
+    K, E = coeff_tables(1)
+    sp = make_ctx(case, 8, K, E)
+    b = case["bed"]
+    f0, t0, _, _ = sp.compute(case["n"], b["x"], b["quat"], b["type"], b["shtype"])
+    f = np.full((case["n"], 3), 5.0)
+    tq = np.full((case["n"], 3), -2.0)
+    sp.compute(case["n"], b["x"], b["quat"], b["type"], b["shtype"], f=f, torque=tq)
+    assert np.allclose(f - 5.0, f0, rtol=0, atol=1e-9 * np.abs(f0).max())
+    assert np.allclose(tq + 2.0, t0, rtol=0, atol=1e-9 * np.abs(f0).max())
+    sp.close()
+
+
+def test_device_pointer_entry_point_and_stream(oracle):
+    import torch
+    case = make_case(300, 6, 1, seed=13, rmax_fn=oracle.shape_rmax)
+    K, E = coeff_tables(1, 1000.0, 1.5)
+    sp = make_ctx(case, 16, K, E)
+    b = case["bed"]
+    dev = torch.device("cuda:0")
+    x = torch.from_numpy(b["x"]).to(dev)
+    q = torch.from_numpy(b["quat"]).to(dev)
+    ty = torch.from_numpy(b["type"]).to(dev)
+    sh = torch.from_numpy(b["shtype"]).to(dev)
+    f = torch.zeros(case["n"], 3, dtype=torch.float64, device=dev)
+    tq = torch.zeros_like(f)
+    ev = torch.zeros(7, dtype=torch.float64, device=dev)
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        sp.compute_device(case["n"], 0, x.data_ptr(), q.data_ptr(), ty.data_ptr(), sh.data_ptr(), f.data_ptr(),
+                          tq.data_ptr(), eflag=True, vflag=True, ev=ev.data_ptr(), stream=st.cuda_stream)
+    st.synchronize()
+    o = oracle_compute(oracle, case, 16, K, E, eflag=True, vflag=True)
+    check(f.cpu().numpy(), tq.cpu().numpy(), o)
+    assert np.abs(ev.cpu().numpy() - o["eng_virial"]).max() < TOL * np.abs(o["eng_virial"]).max()
+    # second call on the context's own stream accumulates on top
+    sp.compute_device(case["n"], 0, x.data_ptr(), q.data_ptr(), ty.data_ptr(), sh.data_ptr(), f.data_ptr(),
+                      tq.data_ptr())
+    sp.synchronize()
+    assert rel_err(f.cpu().numpy(), 2 * o["f"]) < TOL
+    sp.close()
+
+
+def test_empty_ragged_and_separated_inputs(oracle):
+    from shpair import ShPair, shapes
+    case = make_case(60, 4, 1, seed=14, spacing=4.0, rmax_fn=oracle.shape_rmax)  # no pairs at all
+    K, E = coeff_tables(1)
+    sp = make_ctx(case, 8, K, E)
+    b = case["bed"]
+    f, tq, eng, _ = sp.compute(case["n"], b["x"], b["quat"], b["type"], b["shtype"], eflag=True, vflag=True)
+    assert not f.any() and not tq.any() and eng == 0.0
+    # listed pairs whose bounding spheres do not overlap (stale list, skin region)
+    il = np.arange(60, dtype=np.int32)
+    of = np.zeros(61, dtype=np.int32)
+    of[1:] = np.minimum(np.arange(1, 61), 3).cumsum()
+    jl = np.concatenate([np.arange(i + 1, i + 1 + min(i + 1, 3)) % 60 for i in range(60)]).astype(np.int32)
+    sp.set_neighbors_csr(il, of, jl)
+    sp.set_option("count", 1)
+    f, tq, _, _ = sp.compute(case["n"], b["x"], b["quat"], b["type"], b["shtype"])
+    assert not f.any() and sp.stats()["n_contact"] == 0 and sp.stats()["n_candidates"] == jl.size
+    # zero atoms / zero-length list
+    sp.set_neighbors_csr(np.zeros(0, np.int32), np.zeros(1, np.int32), np.zeros(0, np.int32))
+    f, tq, _, _ = sp.compute(case["n"], b["x"], b["quat"], b["type"], b["shtype"])
+    assert not f.any()
+    sp.close()
+
+
+def test_error_codes(oracle):
+    from shpair import ShPair, ShPairError, shapes
+    sp = ShPair(0)
+    with pytest.raises(ShPairError) as e:
+        sp.settings(0)
+    assert e.value.code == -1
+    with pytest.raises(ShPairError) as e:
+        sp.settings(1000)
+    assert e.value.code == -6
+    with pytest.raises(ShPairError) as e:
+        sp.set_shape(0, 4, shapes.sphere(1.0, 4))
+    assert e.value.code == -4  # set_ntypes first
+    sp.set_ntypes(1, 2)
+    with pytest.raises(ShPairError) as e:
+        sp.set_shape(5, 4, shapes.sphere(1.0, 4))
+    assert e.value.code == -1
+    with pytest.raises(ShPairError) as e:
+        sp.set_shape(0, 21, np.zeros(22 * 23))
+    assert e.value.code == -6
+    bad = shapes.sphere(1.0, 2)
+    bad[3] = np.nan
+    with pytest.raises(ShPairError) as e:
+        sp.set_shape(0, 2, bad)
+    assert e.value.code == -1
+    sp.set_shape(0, 2, shapes.sphere(1.0, 2))
+    with pytest.raises(ShPairError) as e:
+        sp.coeff(1, 3, 1.0, 1.0)
+    assert e.value.code == -1
+    with pytest.raises(ShPairError) as e:
+        sp.coeff(1, 1, 1.0, 0.5)
+    assert e.value.code == -1
+    x = np.zeros((2, 3))
+    x[1, 0] = 1.5
+    q = np.tile([1.0, 0, 0, 0], (2, 1))
+    one = np.ones(2, np.int32)
+    zero = np.zeros(2, np.int32)
+    with pytest.raises(ShPairError) as e:  # no neighbour list yet
+        sp.compute(2, x, q, one, zero)
+    assert e.value.code == -4
+    sp.set_neighbors_csr([0, 1], [0, 1, 1], [1])
+    with pytest.raises(ShPairError) as e:  # shape 1 never set
+        sp.compute(2, x, q, one, zero)
+    assert e.value.code == -4 and "shape 1" in str(e.value)
+    sp.set_shape(1, 0, shapes.sphere(1.0))
+    with pytest.raises(ShPairError) as e:  # pair_coeff never set
+        sp.compute(2, x, q, one, zero)
+    assert e.value.code == -4 and "pair_coeff" in str(e.value)
+    sp.coeff("*", "*", 100.0, 1.0)
+    f, tq, _, _ = sp.compute(2, x, q, one, zero)
+    assert f[0, 0] < 0 < f[1, 0] and abs(f[0, 0] + f[1, 0]) < 1e-12
+    with pytest.raises(ShPairError) as e:
+        ShPair(99)
+    assert e.value.code == -2
+    sp.close()
+
+
+def test_reconfiguration_between_computes(oracle):
+    """pair_coeff / shapes / nq changed after a compute are picked up (tables re-uploaded)."""
+    case = make_case(150, 4, 1, seed=15, rmax_fn=oracle.shape_rmax)
+    K, E = coeff_tables(1, 1000.0, 1.0)
+    sp = make_ctx(case, 8, K, E)
+    b = case["bed"]
+    sp.compute(case["n"], b["x"], b["quat"], b["type"], b["shtype"])
+    sp.coeff(1, 1, 250.0, 1.5)
+    sp.settings(12)
+    K2, E2 = coeff_tables(1, 250.0, 1.5)
+    f, tq, _, _ = sp.compute(case["n"], b["x"], b["quat"], b["type"], b["shtype"])
+    check(f, tq, oracle_compute(oracle, case, 12, K2, E2))
+    sp.close()
+
+
+def test_full_size_bed_conservation_and_linearity(oracle):
+    """BASELINE config 2 at full size (100k particles, L=6, nq=16): size-independent properties.
+    Newton's third law, angular-momentum balance, pair-list linearity, run-to-run agreement, and a
+    spot check of 2000 random atoms' neighbourhoods against the oracle."""
+    from shpair import ShPair
+    case = make_case(100000, 6, 1, seed=2, rmax_fn=oracle.shape_rmax)
+    K, E = coeff_tables(1, 1000.0, 1.25)
+    sp = make_ctx(case, 16, K, E)
+    b = case["bed"]
+    n = case["n"]
+    f, tq, eng, vir = sp.compute(n, b["x"], b["quat"], b["type"], b["shtype"], eflag=True, vflag=True)
+    fs = np.abs(f).max()
+    assert fs > 0 and np.all(np.isfinite(f)) and np.all(np.isfinite(tq))
+    assert np.abs(f.sum(axis=0)).max() < 1e-10 * fs * np.sqrt(n)
+    ang = (tq + np.cross(b["x"], f)).sum(axis=0)
+    assert np.abs(ang).max() < 1e-9 * fs * np.sqrt(n) * np.abs(b["x"]).max()
+    W = np.einsum("ia,ib->ab", b["x"], f)
+    assert np.abs(vir - [W[0, 0], W[1, 1], W[2, 2], W[0, 1], W[0, 2], W[1, 2]]).max() < 1e-8 * np.abs(vir).max()
+    # run-to-run: atomics reorder the sums, nothing else
+    f2, tq2, eng2, _ = sp.compute(n, b["x"], b["quat"], b["type"], b["shtype"], eflag=True)
+    assert np.abs(f2 - f).max() < 1e-12 * fs and abs(eng2 - eng) < 1e-11 * eng
+    # linearity in the pair list: two halves of the list sum to the whole
+    of, jl, il = case["offsets"], case["jlist"], case["ilist"]
+    h = n // 2
+    facc = np.zeros_like(f)
+    tacc = np.zeros_like(tq)
+    for lo, hi in ((0, h), (h, n)):
+        sp.set_neighbors_csr(il[lo:hi], of[lo:hi + 1] - of[lo], jl[of[lo]:of[hi]])
+        sp.compute(n, b["x"], b["quat"], b["type"], b["shtype"], f=facc, torque=tacc)
+    assert np.abs(facc - f).max() < 1e-12 * fs and np.abs(tacc - tq).max() < 1e-12 * fs
+    # spot check against the oracle: all pairs of 1500 random rows
+    rng = np.random.default_rng(0)
+    rows = np.sort(rng.choice(n, 1500, replace=False))
+    cnt = (of[rows + 1] - of[rows]).astype(np.int32)
+    sof = np.zeros(rows.size + 1, np.int32)
+    sof[1:] = cnt.cumsum()
+    sjl = np.concatenate([jl[of[r]:of[r + 1]] for r in rows]).astype(np.int32)
+    sub = dict(case)
+    sub["ilist"], sub["offsets"], sub["jlist"] = rows.astype(np.int32), sof, sjl
+    sp.set_neighbors_csr(sub["ilist"], sof, sjl)
+    fg, tg, eg, _ = sp.compute(n, b["x"], b["quat"], b["type"], b["shtype"], eflag=True)
+    o = oracle_compute(oracle, sub, 16, K, E, eflag=True, nthreads=0)
+    check(fg, tg, o)
+    assert abs(eg - o["eng_virial"][0]) < TOL * o["eng_virial"][0]
+    sp.close()
