@@ -1,0 +1,252 @@
+#!/usr/bin/env python3
+"""bench.py — contact-pairs/s of the `pair_style sh` hot path on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+A "step" is one pass of the hot path over one synthetic bed resident in HBM:
+[forward halo exchange, N > 1] -> clear f/torque -> shpair_compute_device()
+-> [reverse halo exchange, N > 1].  Workload at N = 1: BASELINE.json
+configs[1] — 100k particles, one L_max = 6 shape, dense packed bed, n_q = 16
+(Q = 512 cap nodes per pair), general force law (exponent 1.25, so the overlap
+volume root finder runs for every touching node).  N > 1: the same bed per
+rank (weak scaling), bricks of the processor grid, RCCL point-to-point halo.
+
+Prints ONE JSON line on rank 0 (fields: module docstring of DESIGN.md §Measurement).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "lammps-spherharm_amd"))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+BYTES_PER_PAIR = 236          # algorithmic HBM bytes per contact pair
+HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+F64_VALU_PEAK_TFLOPS = 78.6   # 256 CU x 4 SIMD x 16 lanes/clk x 2 flop x 2.4 GHz (= half the FP32 vector peak)
+
+
+def flops_per_pair(lmax, nq):
+    """SURVEY.md §8(d) algorithmic count: (60 + 6L + 9T) FLOP per cap node, Q = 2 nq^2 nodes."""
+    T = (lmax + 1) * (lmax + 2) // 2
+    return (60 + 6 * lmax + 9 * T) * 2 * nq * nq
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--particles", type=int, default=100000, help="particles per GPU")
+    ap.add_argument("--lmax", type=int, default=6)
+    ap.add_argument("--nq", type=int, default=16)
+    ap.add_argument("--nshapes", type=int, default=1)
+    ap.add_argument("--exponent", type=float, default=1.25)
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg (0 = skip)")
+    ap.add_argument("--cpu-threads", type=int, default=16, help="OpenMP threads of the cpu_baseline leg "
+                    "(16 = the host-core share of one GPU on the bench box)")
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    import torch
+    from shpair import ShPair, shapes, bed
+    from shpair.halo import Decomposition, HaloExchange, proc_grid
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run",
+                  file=sys.stderr)
+        sys.exit(2)
+    if not torch.cuda.is_available():
+        print("bench.py: no GPU visible; the HIP path has no CPU fallback", file=sys.stderr)
+        sys.exit(3)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    lmax, nq, nshapes = args.lmax, args.nq, args.nshapes
+    shp = [shapes.random_shape(lmax, bed.SEED0 + 2 + s) for s in range(nshapes)]
+    sp = ShPair(local_rank)
+    sp.settings(nq)
+    sp.set_ntypes(1, nshapes)
+    for s, a in enumerate(shp):
+        sp.set_shape(s, lmax, a)
+    sp.coeff("*", "*", 1000.0, args.exponent)
+    rmax = [sp.rmax(s) for s in range(nshapes)]
+
+    # ---- the bed: world x particles, bricks of the processor grid (weak scaling)
+    grid = proc_grid(world)
+    gbed = bed.make_bed(args.particles * world, rmax, nshapes, seed=bed.SEED0 + 2,
+                        aspect=tuple(float(g) for g in grid))
+    halo = None
+    if world == 1:
+        gid = np.arange(args.particles)
+        nlocal = args.particles
+        il, of, jl = bed.half_neighbor_list(gbed["x"], gbed["shtype"], rmax)
+    else:
+        dec = Decomposition(gbed["x"], gbed["shtype"], rmax, grid)
+        view = dec.plan(rank)
+        gid, nlocal = view["gid"], view["nlocal"]
+        il, of, jl = dec.neighbor_list(view)
+        halo = HaloExchange(view, dev, dist)
+    nall = gid.size
+    sp.set_neighbors_csr(il, of, jl)
+
+    x = torch.from_numpy(gbed["x"][gid]).to(dev)
+    q = torch.from_numpy(gbed["quat"][gid]).to(dev)
+    ty = torch.from_numpy(gbed["type"][gid]).to(dev)
+    sh = torch.from_numpy(gbed["shtype"][gid]).to(dev)
+    f = torch.zeros(nall, 3, dtype=torch.float64, device=dev)
+    tq = torch.zeros_like(f)
+    stream = torch.cuda.current_stream()
+
+    def step():
+        if halo is not None:
+            halo.forward(x, q)
+        f.zero_()
+        tq.zero_()
+        sp.compute_device(nlocal, nall - nlocal, x.data_ptr(), q.data_ptr(), ty.data_ptr(), sh.data_ptr(),
+                          f.data_ptr(), tq.data_ptr(), stream=stream.cuda_stream)
+        if halo is not None:
+            halo.reverse(f, tq)
+
+    # ---- untimed: count the contact pairs of this bed (static positions)
+    sp.set_option("count", 1)
+    step()
+    torch.cuda.synchronize()
+    st = sp.stats()
+    n_contact, n_touching = st["n_contact"], st["n_touching"]
+    sp.set_option("count", 0)
+
+    for _ in range(args.warmup):
+        step()
+
+    # ---- timed region: exactly K steps between barrier + synchronize
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        if halo is not None:
+            halo.forward(x, q)
+        f.zero_()
+        tq.zero_()
+        ev[k][0].record(stream)   # HIP events on the stream the pair kernel is launched on
+        sp.compute_device(nlocal, nall - nlocal, x.data_ptr(), q.data_ptr(), ty.data_ptr(), sh.data_ptr(),
+                          f.data_ptr(), tq.data_ptr(), stream=stream.cuda_stream)
+        ev[k][1].record(stream)
+        if halo is not None:
+            halo.reverse(f, tq)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+
+    tot = torch.tensor([elapsed, float(n_contact), float(n_touching), kernel_ms], dtype=torch.float64, device=dev)
+    if dist is not None:
+        mx = tot.clone()
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        sm = tot.clone()
+        dist.all_reduce(sm, op=dist.ReduceOp.SUM)
+        elapsed = float(mx[0])
+        contact_all, touching_all = float(sm[1]), float(sm[2])
+    else:
+        contact_all, touching_all = float(n_contact), float(n_touching)
+
+    # sanity: forces are finite and (N = 1) sum to zero
+    fh = f[:nlocal].cpu().numpy()
+    assert np.all(np.isfinite(fh)) and np.abs(fh).max() > 0
+
+    if rank == 0:
+        ms_per_step = 1e3 * elapsed / args.steps
+        value = contact_all * args.steps / elapsed
+        achieved_gbs = BYTES_PER_PAIR * n_contact / (kernel_ms * 1e-3) / 1e9
+        fpp = flops_per_pair(lmax, nq)
+        achieved_tf = fpp * n_contact / (kernel_ms * 1e-3) / 1e12
+        out = {
+            "metric": "contact_pairs_per_sec", "value": value, "unit": "contact-pairs/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{args.particles} particles/GPU, {nshapes} SH shape(s) L_max={lmax}, dense packed "
+                            f"bed (jittered HCP, spacing 1.9 mean radii), n_q={nq} (Q={2 * nq * nq} nodes/pair), "
+                            f"pair_coeff kn=1000 exponent={args.exponent} (overlap volume + force + torque), "
+                            "inputs resident in HBM",
+                "particles_per_gpu": args.particles, "lmax": lmax, "nq": nq, "nshapes": nshapes,
+                "exponent": args.exponent, "proc_grid": list(grid),
+                "half_list_pairs_rank0": int(jl.size), "contact_pairs_rank0": int(n_contact),
+                "touching_pairs_rank0": int(n_touching), "contact_pairs_all_ranks": int(contact_all),
+                "ghost_atoms_rank0": int(nall - nlocal),
+            },
+            "timesteps_per_sec": args.steps / elapsed,
+            "roofline": {
+                "bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": None,
+                "kernel": "pair_contact_kernel", "kernel_ms": kernel_ms,
+                "bytes_per_pair": BYTES_PER_PAIR, "pairs_per_launch": int(n_contact),
+                "note": "north_star asks for the HBM fraction; the kernel is FP64-VALU bound (see valu_f64)",
+            },
+            "valu_f64": {
+                "bound": "valu_f64", "achieved": achieved_tf, "peak": F64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": achieved_tf / F64_VALU_PEAK_TFLOPS, "flop_per_pair": fpp,
+                "note": "algorithmic FLOP (SURVEY §8d formula) / kernel time; no MFMA by design",
+            },
+        }
+        if world == 1 and args.cpu_seconds > 0:
+            out["cpu_baseline"] = cpu_baseline(args, shp, rmax, gbed, il, of, jl)
+        print(json.dumps(out), flush=True)
+    sp.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(args, shp, rmax, gbed, il, of, jl):
+    """The CPU oracle (a port of docs/SPEC.md — the reference's PairSH is not in the mount) on a bounded
+    sample of the same bed: the first rows of the same half list, all host cores via OpenMP."""
+    from oracle import oracle as O  # checker / baseline only
+    O.build()
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    nthreads = max(1, min(args.cpu_threads, avail))
+    K = np.full((2, 2), 1000.0)
+    E = np.full((2, 2), args.exponent)
+    sh_list = [(args.lmax, a, r) for a, r in zip(shp, rmax)]
+
+    def run(nrows):
+        t = time.perf_counter()
+        o = O.compute(sh_list, K, E, args.nq, gbed["x"].shape[0], gbed["x"], gbed["quat"], gbed["type"],
+                      gbed["shtype"], il[:nrows], of[:nrows + 1], jl[:of[nrows]], nthreads=nthreads)
+        return time.perf_counter() - t, int(o["counts"][1])
+    probe_rows = min(len(il), 2000)
+    t_probe, c_probe = run(probe_rows)
+    rate = c_probe / max(t_probe, 1e-6)
+    per_row = max(c_probe / probe_rows, 1e-9)
+    nrows = int(min(len(il), max(probe_rows, args.cpu_seconds * rate / per_row)))
+    t_main, c_main = run(nrows)
+    return {"value": c_main / t_main, "unit": "contact-pairs/s", "cores": nthreads, "kind": "port",
+            "sample": f"first {nrows} rows of the same half list ({c_main} contact pairs, {t_main:.1f} s, "
+                      f"OpenMP x{nthreads}); own CPU restatement of docs/SPEC.md, not the reference's PairSH "
+                      "(absent from the mount)"}
+
+
+if __name__ == "__main__":
+    main()

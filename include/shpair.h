@@ -115,8 +115,10 @@ int shpair_compute(shpair_ctx *ctx, int nlocal, int nghost, const double *x, con
 
 /* Device-pointer form: all arrays already resident in HBM (the measured
  * path). Same layout and ADD semantics; ev_dev (nullable) is 7 doubles on the
- * device: [0] += energy, [1..6] += virial.  stream: a hipStream_t, or NULL
- * for the context's own stream.  Asynchronous: returns after enqueueing. */
+ * device: [0] += energy, [1..6] += virial.  stream: the hipStream_t to launch
+ * on; NULL is HIP's null stream (what the arrays' producer normally used), and
+ * shpair_get_stream() returns the context's own stream if that is wanted.
+ * Asynchronous: returns after enqueueing. */
 int shpair_compute_device(shpair_ctx *ctx, int nlocal, int nghost, const double *x_dev,
                           const double *quat_dev, const int *type_dev, const int *shtype_dev,
                           int newton_pair, int eflag, int vflag, double *f_dev, double *torque_dev,
@@ -135,6 +137,10 @@ int shpair_get_stats(shpair_ctx *ctx, shpair_stats *out);
  * 7 doubles per half-list entry (V, S_n[3], T_n[3], docs/SPEC.md §2), device
  * memory owned by the caller; NULL disables. */
 int shpair_set_pair_output(shpair_ctx *ctx, double *pair_out_dev);
+
+/* The context's own non-blocking stream (a hipStream_t), used by
+ * shpair_compute() for its staging copies and kernels. */
+int shpair_get_stream(shpair_ctx *ctx, void **stream);
 
 /* Wait for everything enqueued on the context's stream. */
 int shpair_synchronize(shpair_ctx *ctx);

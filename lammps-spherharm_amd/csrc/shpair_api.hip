@@ -425,7 +425,7 @@ int shpair_compute_device(shpair_ctx* c, int nlocal, int nghost, const double* x
   c->stats.n_candidates = c->npairs;
   if (c->npairs == 0) return SHPAIR_OK;
   if (!x || !quat || !type || !shtype || !f || !torque) CTX_FAIL(c, SHPAIR_EINVAL, "null atom array");
-  hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+  hipStream_t st = (hipStream_t)stream;  // NULL = HIP null stream
 
   PairParams P;
   P.x = x; P.quat = quat; P.type = type; P.shtype = shtype; P.f = f; P.torque = torque;
@@ -565,6 +565,13 @@ int shpair_set_pair_output(shpair_ctx* c, double* pair_out_dev)
 {
   if (!c) return SHPAIR_EINVAL;
   c->pair_out = pair_out_dev;
+  return SHPAIR_OK;
+}
+
+int shpair_get_stream(shpair_ctx* c, void** stream)
+{
+  if (!c || !stream) return SHPAIR_EINVAL;
+  *stream = (void*)c->stream;
   return SHPAIR_OK;
 }
 

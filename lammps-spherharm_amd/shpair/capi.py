@@ -52,6 +52,7 @@ SYMBOLS = {
     "shpair_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
     "shpair_get_stats": (C.c_int, [C.c_void_p, C.POINTER(Stats)]),
     "shpair_set_pair_output": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "shpair_get_stream": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
     "shpair_synchronize": (C.c_int, [C.c_void_p]),
 }
 
@@ -214,7 +215,8 @@ class ShPair:
 
     def compute_device(self, nlocal, nghost, x, quat, type_, shtype, f, torque, newton_pair=True,
                        eflag=False, vflag=False, ev=None, stream=None):
-        """Device-pointer entry point: arguments are raw device addresses (ints). Asynchronous."""
+        """Device-pointer entry point: arguments are raw device addresses (ints). Asynchronous.
+        stream: a hipStream_t as int; None/0 = HIP null stream."""
         self._chk(self._lib.shpair_compute_device(self._h, int(nlocal), int(nghost), x, quat, type_, shtype,
                                                   int(newton_pair), int(eflag), int(vflag), f, torque,
                                                   ev, stream))
@@ -230,6 +232,12 @@ class ShPair:
         self._chk(self._lib.shpair_get_stats(self._h, C.byref(s)))
         return dict(n_candidates=s.n_candidates, n_contact=s.n_contact, n_touching=s.n_touching,
                     kernel_ms=s.kernel_ms, total_ms=s.total_ms)
+
+    def own_stream(self):
+        """The context's own hipStream_t as an int (None-safe for compute_device(stream=...))."""
+        st = C.c_void_p()
+        self._chk(self._lib.shpair_get_stream(self._h, C.byref(st)))
+        return st.value
 
     def synchronize(self):
         self._chk(self._lib.shpair_synchronize(self._h))

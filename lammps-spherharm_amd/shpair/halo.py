@@ -1,0 +1,177 @@
+"""Spatial domain decomposition and ghost-atom / ghost-force halo exchange.
+
+The multi-GPU shape of the path: one rank and one shpair
+context per GPU, bricks of a px x py x pz processor grid, ghost atoms within
+the neighbour cutoff of a brick, one forward exchange (x + quaternion of
+ghosts) before `compute` and one reverse exchange (force + torque on ghosts,
+summed into their owners) after it — what LAMMPS' Comm::forward_comm /
+reverse_comm do around Pair::compute (reference sources ABSENT FROM MOUNT).
+
+MI355X-first: instead of LAMMPS' three staged x/y/z swaps, every rank talks
+to each of its <= 26 (7 for a 2x2x2 grid) geometric neighbours directly with
+one batched point-to-point exchange — on an xGMI-meshed node every peer is
+one hop away, so staging through intermediates only adds latency.  Ghost
+slots are ordered by owner rank, so each peer's receive lands in one
+contiguous slice of the atom arrays (no unpack kernel on the forward path).
+Backend: torch.distributed P2P (`nccl` = RCCL on ROCm; `gloo` on CPU tests).
+"""
+import numpy as np
+
+
+def proc_grid(nranks):
+    """Most cubic px >= py >= pz factorisation (LAMMPS' default processor grid idea)."""
+    best = None
+    for px in range(1, nranks + 1):
+        if nranks % px:
+            continue
+        for py in range(1, nranks // px + 1):
+            if (nranks // px) % py:
+                continue
+            pz = nranks // px // py
+            key = (max(px, py, pz) - min(px, py, pz), -px, -py)
+            if best is None or key < best[0]:
+                best = (key, (px, py, pz))
+    return tuple(sorted(best[1], reverse=True))
+
+
+class Decomposition:
+    """Built identically on every rank from the global synthetic bed (setup only)."""
+
+    def __init__(self, x, shtype, rmax_by_shape, grid, skin=0.1):
+        self.grid = tuple(int(g) for g in grid)
+        self.nranks = int(np.prod(self.grid))
+        self.x = np.asarray(x, dtype=np.float64)
+        self.shtype = np.asarray(shtype)
+        self.rmax = np.asarray(rmax_by_shape, dtype=np.float64)
+        self.skin = skin
+        self.rcut = 2.0 * self.rmax.max() + skin
+        lo, hi = self.x.min(axis=0), self.x.max(axis=0)
+        # equal-count cuts along each axis so that weak scaling keeps ranks balanced
+        self.cuts = []
+        owner_axis = []
+        for a in range(3):
+            g = self.grid[a]
+            qs = np.quantile(self.x[:, a], np.linspace(0, 1, g + 1))
+            qs[0], qs[-1] = lo[a] - 1.0, hi[a] + 1.0
+            self.cuts.append(qs)
+            owner_axis.append(np.clip(np.searchsorted(qs, self.x[:, a], side="right") - 1, 0, g - 1))
+        px, py, pz = self.grid
+        self.owner = (owner_axis[0] * py + owner_axis[1]) * pz + owner_axis[2]
+
+    def brick(self, rank):
+        px, py, pz = self.grid
+        ix, rem = divmod(rank, py * pz)
+        iy, iz = divmod(rem, pz)
+        lo = np.array([self.cuts[0][ix], self.cuts[1][iy], self.cuts[2][iz]])
+        hi = np.array([self.cuts[0][ix + 1], self.cuts[1][iy + 1], self.cuts[2][iz + 1]])
+        return lo, hi
+
+    def local_view(self, rank):
+        """Rank-local atoms: owned first (ascending global id), then ghosts ordered by (owner, global id).
+
+        Returns dict(gid, nlocal, ghost_owner, send: {peer: local idx}, recv: {peer: (start, stop)}).
+        """
+        mine = np.flatnonzero(self.owner == rank)
+        lo, hi = self.brick(rank)
+        d = np.maximum(np.maximum(lo - self.x, self.x - hi), 0.0)
+        near = (np.einsum("ij,ij->i", d, d) < self.rcut ** 2) & (self.owner != rank)
+        ghosts = np.flatnonzero(near)
+        ghosts = ghosts[np.lexsort((ghosts, self.owner[ghosts]))]
+        gid = np.concatenate([mine, ghosts])
+        nlocal = mine.size
+        recv = {}
+        gown = self.owner[ghosts]
+        for p in np.unique(gown):
+            idx = np.flatnonzero(gown == p)
+            recv[int(p)] = (nlocal + int(idx[0]), nlocal + int(idx[-1]) + 1)
+        return dict(gid=gid, nlocal=nlocal, ghost_owner=gown, recv=recv)
+
+    def plan(self, rank):
+        """Adds the send lists: my atoms that are ghosts on peer p, in p's ghost order (ascending gid)."""
+        v = self.local_view(rank)
+        lookup = {int(g): k for k, g in enumerate(v["gid"][:v["nlocal"]])}
+        send = {}
+        for p in range(self.nranks):
+            if p == rank:
+                continue
+            lo, hi = self.brick(p)
+            cand = v["gid"][:v["nlocal"]]
+            d = np.maximum(np.maximum(lo - self.x[cand], self.x[cand] - hi), 0.0)
+            sel = cand[np.einsum("ij,ij->i", d, d) < self.rcut ** 2]
+            if sel.size:
+                send[p] = np.array([lookup[int(g)] for g in np.sort(sel)], dtype=np.int64)
+        v["send"] = send
+        return v
+
+    def neighbor_list(self, view):
+        """Half list over local+ghost atoms (newton on): every global pair is evaluated by exactly one
+        rank — the owner of the atom with the smaller global id."""
+        from .bed import half_neighbor_list
+        gid = view["gid"]
+
+        def rule(i, j):  # i local, j ghost
+            return gid[i] < gid[j]
+        return half_neighbor_list(self.x[gid], self.shtype[gid], self.rmax, skin=self.skin,
+                                  nlocal=view["nlocal"], owner_rule=rule)
+
+
+class HaloExchange:
+    """Forward (x, quat -> ghosts) and reverse (ghost f, torque -> owners) exchange for one rank."""
+
+    def __init__(self, view, device, dist_module=None):
+        import torch
+        self.torch = torch
+        self.dist = dist_module
+        self.nlocal = view["nlocal"]
+        self.recv = dict(view["recv"])
+        self.send = {p: torch.as_tensor(idx, device=device) for p, idx in view["send"].items()}
+        self.peers = sorted(set(self.recv) | set(self.send))
+        self.device = device
+        self._fwd_buf = {p: torch.empty(idx.numel(), 7, dtype=torch.float64, device=device)
+                         for p, idx in self.send.items()}
+        self._fwd_in = {p: torch.empty(b - a, 7, dtype=torch.float64, device=device)
+                        for p, (a, b) in self.recv.items()}
+        self._rev_in = {p: torch.empty(idx.numel(), 6, dtype=torch.float64, device=device)
+                        for p, idx in self.send.items()}
+        self._rev_buf = {p: torch.empty(b - a, 6, dtype=torch.float64, device=device)
+                         for p, (a, b) in self.recv.items()}
+
+    def bytes_per_step(self):
+        n_send = sum(int(i.numel()) for i in self.send.values())
+        n_recv = sum(b - a for a, b in self.recv.values())
+        return 8 * (7 * n_send + 6 * n_recv), 8 * (7 * n_recv + 6 * n_send)
+
+    def _exchange(self, sends, recvs):
+        dist = self.dist
+        ops = []
+        for p in self.peers:  # same peer order everywhere; recv first, then send
+            if p in recvs:
+                ops.append(dist.P2POp(dist.irecv, recvs[p], p))
+            if p in sends:
+                ops.append(dist.P2POp(dist.isend, sends[p], p))
+        if ops:
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+
+    def forward(self, x, quat):
+        """x[nall,3], quat[nall,4]: owners' rows -> the peers' ghost rows (Comm::forward_comm)."""
+        torch = self.torch
+        for p, idx in self.send.items():
+            buf = self._fwd_buf[p]
+            buf[:, :3] = x.index_select(0, idx)
+            buf[:, 3:] = quat.index_select(0, idx)
+        self._exchange(self._fwd_buf, self._fwd_in)
+        for p, (a, b) in self.recv.items():
+            x[a:b] = self._fwd_in[p][:, :3]
+            quat[a:b] = self._fwd_in[p][:, 3:]
+
+    def reverse(self, f, torque):
+        """Ghost rows of f/torque -> added into their owners' rows (Comm::reverse_comm)."""
+        for p, (a, b) in self.recv.items():
+            buf = self._rev_buf[p]
+            buf[:, :3] = f[a:b]
+            buf[:, 3:] = torque[a:b]
+        self._exchange(self._rev_buf, self._rev_in)
+        for p, idx in self.send.items():
+            f.index_add_(0, idx, self._rev_in[p][:, :3])
+            torque.index_add_(0, idx, self._rev_in[p][:, 3:])

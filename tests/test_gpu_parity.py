@@ -205,8 +205,13 @@ def test_device_pointer_entry_point_and_stream(oracle):
     assert np.abs(ev.cpu().numpy() - o["eng_virial"]).max() < TOL * np.abs(o["eng_virial"]).max()
     # second call on the context's own stream accumulates on top
     sp.compute_device(case["n"], 0, x.data_ptr(), q.data_ptr(), ty.data_ptr(), sh.data_ptr(), f.data_ptr(),
-                      tq.data_ptr())
+                      tq.data_ptr(), stream=sp.own_stream())
     sp.synchronize()
+    # and a third on the null stream (stream=None)
+    sp.compute_device(case["n"], 0, x.data_ptr(), q.data_ptr(), ty.data_ptr(), sh.data_ptr(), f.data_ptr(),
+                      tq.data_ptr())
+    torch.cuda.synchronize()
+    f.mul_(2.0 / 3.0)
     assert rel_err(f.cpu().numpy(), 2 * o["f"]) < TOL
     sp.close()
 
