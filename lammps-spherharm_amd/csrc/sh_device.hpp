@@ -74,13 +74,20 @@ __device__ __forceinline__ double sgpr_const_bits()
 // A chunk may run past the end of its m-block (it then holds the head of the
 // next block, unused) and the last one past the end of the shape's table,
 // which the host pads (sh_chunk_stride()).
-typedef double sh_d8 __attribute__((ext_vector_type(8)));
+#ifndef SHP_CHUNK
+#define SHP_CHUNK 4  // complex terms per scalar load: 4 = s_load_dwordx16, 2 = s_load_dwordx8
+#endif
+constexpr int kChunk = SHP_CHUNK;
+typedef double sh_d8 __attribute__((ext_vector_type(2 * SHP_CHUNK)));
 typedef sh_d8 sh_d8_u __attribute__((aligned(8)));
 typedef const sh_d8_u __attribute__((address_space(4))) * cd8ptr;
-__device__ __forceinline__ sh_d8 sload_chunk(const double* p)
+// `base` is the evaluation's laundered table pointer (launder_uniform), so the
+// chunk offset folds into the s_load immediate; a pointer laundered per chunk
+// makes the compiler precompute every chunk address outside the node loop and
+// carry them through spilled SGPR pairs.
+__device__ __forceinline__ sh_d8 sload_chunk(const cdptr base, const int off)
 {
-  asm volatile("" : "+s"(p));
-  return *(cd8ptr)p;
+  return *(cd8ptr)(base + off);
 }
 
 // One (n, m) term with its coefficient (cr, ci) already in SGPRs.
@@ -174,19 +181,21 @@ __device__ __forceinline__ void sh_block_end(const double x, const double y, ShS
 // `cur`; requests its successor, computes its terms, recurses.
 template <int L, int M, int N0, bool GRAD>
 struct ShStep {
-  static __device__ __forceinline__ void run(const double* cw_in, const sh_d8 cur, const double x, const double y,
+  static __device__ __forceinline__ void run(const cdptr cw_in, const sh_d8 cur, const double x, const double y,
                                              const double z, ShState& t)
   {
-    constexpr bool block_done = (N0 + 4 > L);
+    constexpr bool block_done = (N0 + kChunk > L);
     constexpr bool has_next = !block_done || (M + 1 <= L);
     constexpr int Mn = block_done ? M + 1 : M;
-    constexpr int Nn = block_done ? M + 1 : N0 + 4;
+    constexpr int Nn = block_done ? M + 1 : N0 + kChunk;
     sh_d8 nxt = cur;
-    if constexpr (has_next) nxt = sload_chunk(cw_in + 2 * sh_index(L, Nn, Mn));
+    if constexpr (has_next) nxt = sload_chunk(cw_in, 2 * sh_index(L, Nn, Mn));
     sh_term<L, M, N0, GRAD>(cur[0], cur[1], z, t.a);
     sh_term<L, M, N0 + 1, GRAD>(cur[2], cur[3], z, t.a);
-    sh_term<L, M, N0 + 2, GRAD>(cur[4], cur[5], z, t.a);
-    sh_term<L, M, N0 + 3, GRAD>(cur[6], cur[7], z, t.a);
+    if constexpr (kChunk == 4) {
+      sh_term<L, M, N0 + 2, GRAD>(cur[4], cur[5], z, t.a);
+      sh_term<L, M, N0 + 3, GRAD>(cur[6], cur[7], z, t.a);
+    }
     if constexpr (block_done) sh_block_end<L, M, GRAD>(x, y, t);
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (has_next) ShStep<L, Mn, Nn, GRAD>::run(cw_in, nxt, x, y, z, t);
@@ -273,9 +282,10 @@ __device__ __forceinline__ void sh_eval(const double* rc_in, const double* cw_in
     ShState t;
     t.Cm = 1.0; t.Sm = 0.0; t.Cp = 1.0; t.Sp = 0.0;
     t.r = 0.0; t.gx = 0.0; t.gy = 0.0; t.gz = 0.0;
-    const sh_d8 first = sload_chunk(cw_in);
+    const cdptr cwl = launder_uniform(cw_in);
+    const sh_d8 first = sload_chunk(cwl, 0);
     __builtin_amdgcn_sched_barrier(0);
-    ShStep<L, 0, 0, GRAD>::run(cw_in, first, x, y, z, t);
+    ShStep<L, 0, 0, GRAD>::run(cwl, first, x, y, z, t);
     r = t.r;
     if constexpr (GRAD) { gx = t.gx; gy = t.gy; gz = t.gz; }
   } else {

@@ -107,6 +107,7 @@ struct shpair_ctx {
 
   int opt_force_volume = 0, opt_timing = 0, opt_count = 0, opt_variant = 0;
   double* pair_out = nullptr;
+  unsigned long long* dbg = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr, evA = nullptr, evB = nullptr;
   bool timed_last = false, counted_last = false, total_timed_last = false;
   shpair_stats stats{};
@@ -438,6 +439,7 @@ int shpair_compute_device(shpair_ctx* c, int nlocal, int nghost, const double* x
   P.nq = nq;
   P.ev = ev; P.pair_out = c->pair_out;
   P.flags = nullptr;
+  P.dbg = c->dbg;
   P.eflag = eflag ? 1 : 0; P.vflag = vflag ? 1 : 0; P.force_volume = c->opt_force_volume;
   if (c->opt_count) {
     HIPCHK(c, c->d_flags.ensure(c->npairs));
@@ -565,6 +567,14 @@ int shpair_set_pair_output(shpair_ctx* c, double* pair_out_dev)
 {
   if (!c) return SHPAIR_EINVAL;
   c->pair_out = pair_out_dev;
+  return SHPAIR_OK;
+}
+
+// Not part of include/shpair.h: work counters of SHP_STATS diagnostic builds.
+int shpair_debug_set_counters(shpair_ctx* c, unsigned long long* dbg_dev)
+{
+  if (!c) return SHPAIR_EINVAL;
+  c->dbg = dbg_dev;
   return SHPAIR_OK;
 }
 

@@ -256,11 +256,15 @@ int sho_pair(int Li, const double *anmi, double Ri, int Lj, const double *anmj, 
           const double gl = g_ray(Lj, anmj, Rj, uj, dj, lam);
           if (diag) diag[2] += 1.0;
           if (gl >= 0.0) lo = lam; else hi = lam;
-          rin = lam;
-          if (fabs(gl) <= 1e-13 * Rj) break;
           double nxt = lam - gl * (lam - lprev) / (gl - gprev);
-          if (!(nxt > lo && nxt < hi)) nxt = 0.5 * (lo + hi);
+          const int ok = (nxt > lo && nxt < hi);
+          if (fabs(gl) <= 1e-7 * Rj) {  /* accept the extrapolated point, clamped to the bracket */
+            rin = (fabs(nxt) <= 1e300) ? fmin(fmax(nxt, lo), hi) : lam;
+            break;
+          }
+          if (!ok) nxt = 0.5 * (lo + hi);
           if (hi - lo <= 1e-14 * Rj) { rin = 0.5 * (lo + hi); break; }
+          rin = nxt;
           lprev = lam; gprev = gl; lam = nxt;
         }
       }
