@@ -1,0 +1,111 @@
+// host_main.cpp — TEST SCAFFOLD: a minimal C++ host that drives the PairSH
+// adapter the way LAMMPS would (pair_style -> pair_coeff -> init -> compute)
+// on a bed read from a plain text file, and writes forces/torques back.
+// Built against stub/ (no LAMMPS in this image); used by
+// tests/test_lammps_adapter.py on the GPU box.  Not part of the product.
+//
+// bed file:  nlocal nghost ntypes newton eflag
+//            per atom: x y z qw qx qy qz type shtype
+//            inum ; per row: i n j1 .. jn
+// usage: lammps_host <bed> <out> <nq> <kn> <exponent> <shape files...>
+#include <cstdio>
+#include <cstdlib>
+#include <string>
+#include <vector>
+
+#include "pair_sh.h"
+
+using namespace LAMMPS_NS;
+
+int main(int argc, char **argv)
+{
+  if (argc < 7) {
+    fprintf(stderr, "usage: %s bed out nq kn exponent shapes...\n", argv[0]);
+    return 2;
+  }
+  FILE *fp = fopen(argv[1], "r");
+  if (!fp) return 3;
+  int nlocal, nghost, ntypes, newton, eflag;
+  if (fscanf(fp, "%d %d %d %d %d", &nlocal, &nghost, &ntypes, &newton, &eflag) != 5) return 3;
+  const int nall = nlocal + nghost;
+  LAMMPS lmp;
+  Memory mem;
+  double **x, **quat, **f, **tq;
+  mem.create(x, nall, 3, "x");
+  mem.create(quat, nall, 4, "quat");
+  mem.create(f, nall, 3, "f");
+  mem.create(tq, nall, 3, "torque");
+  std::vector<int> type(nall), shtype(nall);
+  for (int i = 0; i < nall; i++)
+    if (fscanf(fp, "%lf %lf %lf %lf %lf %lf %lf %d %d", &x[i][0], &x[i][1], &x[i][2], &quat[i][0], &quat[i][1],
+               &quat[i][2], &quat[i][3], &type[i], &shtype[i]) != 9)
+      return 3;
+  int inum;
+  if (fscanf(fp, "%d", &inum) != 1) return 3;
+  std::vector<int> ilist(inum), numneigh(nall, 0);
+  std::vector<std::vector<int>> rows(nall);
+  std::vector<int *> firstneigh(nall, nullptr);
+  for (int ii = 0; ii < inum; ii++) {
+    int i, n;
+    if (fscanf(fp, "%d %d", &i, &n) != 2) return 3;
+    ilist[ii] = i;
+    numneigh[i] = n;
+    rows[i].resize(n);
+    for (int k = 0; k < n; k++)
+      if (fscanf(fp, "%d", &rows[i][k]) != 1) return 3;
+    firstneigh[i] = rows[i].data();
+  }
+  fclose(fp);
+
+  Atom *atom = lmp.atom;
+  atom->ntypes = ntypes;
+  atom->nlocal = nlocal;
+  atom->nghost = nghost;
+  atom->x = x;
+  atom->f = f;
+  atom->torque = tq;
+  atom->type = type.data();
+  atom->extractable["quat"] = (void *) quat;        // as atom_style spherharm would expose them
+  atom->extractable["shtype"] = (void *) shtype.data();
+  lmp.force->newton_pair = newton;
+
+  NeighList list;
+  list.inum = inum;
+  list.ilist = ilist.data();
+  list.numneigh = numneigh.data();
+  list.firstneigh = firstneigh.data();
+  lmp.neighbor->lastcall = 1;
+
+  PairSH pair(&lmp);
+  pair.list = &list;
+  std::vector<char *> sargs;
+  std::string kw = "shapes";
+  sargs.push_back(argv[3]);
+  sargs.push_back(kw.data());
+  for (int a = 6; a < argc; a++) sargs.push_back(argv[a]);
+  pair.settings((int) sargs.size(), sargs.data());
+  std::string star = "*";
+  char *cargs[4] = {star.data(), star.data(), argv[4], argv[5]};
+  pair.coeff(4, cargs);
+  pair.init_style();
+  double cut = 0.0;
+  for (int i = 1; i <= ntypes; i++)
+    for (int j = i; j <= ntypes; j++) cut = pair.init_one(i, j);
+
+  pair.compute(eflag, eflag);    // step 1
+  const double e1 = pair.eng_vdwl;
+  // step 2 reuses the uploaded neighbour list (lastcall unchanged); LAMMPS clears forces in between
+  for (int i = 0; i < nall; i++)
+    for (int a = 0; a < 3; a++) f[i][a] = tq[i][a] = 0.0;
+  pair.compute(eflag, eflag);
+
+  fp = fopen(argv[2], "w");
+  if (!fp) return 4;
+  fprintf(fp, "%.17g %.17g %.17g\n", cut, e1, pair.eng_vdwl);
+  fprintf(fp, "%.17g %.17g %.17g %.17g %.17g %.17g\n", pair.virial[0], pair.virial[1], pair.virial[2],
+          pair.virial[3], pair.virial[4], pair.virial[5]);
+  for (int i = 0; i < nall; i++)
+    fprintf(fp, "%.17g %.17g %.17g %.17g %.17g %.17g\n", f[i][0], f[i][1], f[i][2], tq[i][0], tq[i][1], tq[i][2]);
+  fclose(fp);
+  return 0;
+}

@@ -1,0 +1,284 @@
+/* ----------------------------------------------------------------------
+   pair_sh.cpp — LAMMPS Pair adapter over the shpair C ABI (include/shpair.h).
+
+   Input script (everything else of the run is unmodified LAMMPS):
+
+     pair_style sh <nq> [device <id>] [shapes <file> ...]
+     pair_coeff I J <kn> <exponent>
+
+   Per-atom data, looked up once per compute():
+     orientation  atom->extract("quat")  or custom d2_quat   (nall x 4, w x y z)
+     shape index  atom->extract("shtype") or custom i_shtype (0-based)
+   Shape tables: the files named after `shapes`, one per shape index, text:
+     line 1: lmax ; then one line per (n, m >= 0): n m Re(a_nm) Im(a_nm)
+   (the reference's own shape-file format is unknown: its reader is absent
+   from the mount).
+
+   Reference: PairSH of LAMMPS-SPHERHARM is ABSENT FROM MOUNT; written against
+   the stock LAMMPS Pair interface.
+------------------------------------------------------------------------- */
+
+#include "pair_sh.h"
+
+#include "atom.h"
+#include "comm.h"
+#include "error.h"
+#include "force.h"
+#include "memory.h"
+#include "neigh_list.h"
+#include "neighbor.h"
+#include "update.h"
+#include "utils.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#include "shpair.h"
+
+using namespace LAMMPS_NS;
+
+/* ---------------------------------------------------------------------- */
+
+PairSH::PairSH(LAMMPS *lmp) :
+    Pair(lmp), ctx(nullptr), nq(16), device(-1), nshapes(0), kn(nullptr), exponent(nullptr), maxrad(0.0),
+    last_neigh_build(-1)
+{
+  single_enable = 0;
+  restartinfo = 0;
+  no_virial_fdotr_compute = 1;    // the virial comes back from the device, tallied per pair
+  manybody_flag = 0;
+}
+
+PairSH::~PairSH()
+{
+  if (ctx) shpair_destroy(ctx);
+  if (allocated) {
+    memory->destroy(setflag);
+    memory->destroy(cutsq);
+    memory->destroy(kn);
+    memory->destroy(exponent);
+  }
+}
+
+void PairSH::check(int rc, const char *what)
+{
+  if (rc == SHPAIR_OK) return;
+  char msg[640];
+  snprintf(msg, sizeof(msg), "pair sh: %s failed: %s (%s)", what, shpair_strerror(rc),
+           ctx ? shpair_last_error(ctx) : "no context");
+  error->all(FLERR, msg);
+}
+
+/* ----------------------------------------------------------------------
+   pair_style sh <nq> [device <id>] [shapes f1 f2 ...]
+------------------------------------------------------------------------- */
+
+void PairSH::settings(int narg, char **arg)
+{
+  if (narg < 1) error->all(FLERR, "Illegal pair_style sh command: pair_style sh <nq> [device id] [shapes files...]");
+  nq = atoi(arg[0]);
+  if (nq < 1 || nq > SHPAIR_MAX_NQ) error->all(FLERR, "pair_style sh: quadrature order out of range");
+  shape_files.clear();
+  int iarg = 1;
+  while (iarg < narg) {
+    if (strcmp(arg[iarg], "device") == 0) {
+      if (iarg + 2 > narg) error->all(FLERR, "Illegal pair_style sh command: device needs an id");
+      device = atoi(arg[iarg + 1]);
+      iarg += 2;
+    } else if (strcmp(arg[iarg], "shapes") == 0) {
+      ++iarg;
+      while (iarg < narg && strcmp(arg[iarg], "device") != 0) shape_files.emplace_back(arg[iarg++]);
+      if (shape_files.empty()) error->all(FLERR, "Illegal pair_style sh command: shapes needs file names");
+    } else
+      error->all(FLERR, "Illegal pair_style sh command: unknown keyword");
+  }
+  if (!ctx) {
+    // one rank per GPU: default device = rank within the node
+    int dev = device;
+    if (dev < 0) {
+      const char *lr = getenv("OMPI_COMM_WORLD_LOCAL_RANK");
+      if (!lr) lr = getenv("MV2_COMM_WORLD_LOCAL_RANK");
+      if (!lr) lr = getenv("SLURM_LOCALID");
+      dev = lr ? atoi(lr) : 0;
+    }
+    const int rc = shpair_create(&ctx, dev);
+    if (rc != SHPAIR_OK) {
+      char msg[256];
+      snprintf(msg, sizeof(msg), "pair sh: cannot open HIP device %d: %s", dev, shpair_strerror(rc));
+      error->all(FLERR, msg);    // no CPU fallback by design
+    }
+  }
+  check(shpair_settings(ctx, nq), "shpair_settings");
+}
+
+void PairSH::allocate()
+{
+  allocated = 1;
+  const int n = atom->ntypes;
+  memory->create(setflag, n + 1, n + 1, "pair:setflag");
+  memory->create(cutsq, n + 1, n + 1, "pair:cutsq");
+  memory->create(kn, n + 1, n + 1, "pair:kn");
+  memory->create(exponent, n + 1, n + 1, "pair:exponent");
+  for (int i = 0; i <= n; i++)
+    for (int j = 0; j <= n; j++) {
+      setflag[i][j] = 0;
+      kn[i][j] = 0.0;
+      exponent[i][j] = 1.0;
+    }
+}
+
+/* ----------------------------------------------------------------------
+   shape tables -> shpair_set_shape()
+------------------------------------------------------------------------- */
+
+void PairSH::load_shapes()
+{
+  if (shape_files.empty()) error->all(FLERR, "pair sh: no shape tables: add `shapes <file> ...` to pair_style sh");
+  nshapes = (int) shape_files.size();
+  check(shpair_set_ntypes(ctx, atom->ntypes, nshapes), "shpair_set_ntypes");
+  maxrad = 0.0;
+  for (int s = 0; s < nshapes; s++) {
+    FILE *fp = fopen(shape_files[s].c_str(), "r");
+    if (!fp) error->one(FLERR, "pair sh: cannot open shape file");
+    int lmax = -1;
+    if (fscanf(fp, "%d", &lmax) != 1 || lmax < 0 || lmax > SHPAIR_MAX_LMAX) {
+      fclose(fp);
+      error->one(FLERR, "pair sh: bad lmax in shape file");
+    }
+    std::vector<double> anm((size_t) (lmax + 1) * (lmax + 2), 0.0);
+    int n, m;
+    double re, im;
+    while (fscanf(fp, "%d %d %lf %lf", &n, &m, &re, &im) == 4) {
+      if (n < 0 || n > lmax || m < 0 || m > n) {
+        fclose(fp);
+        error->one(FLERR, "pair sh: (n, m) out of range in shape file");
+      }
+      const int k = n * (n + 1) / 2 + m;
+      anm[2 * k] = re;
+      anm[2 * k + 1] = im;
+    }
+    fclose(fp);
+    check(shpair_set_shape(ctx, s, lmax, anm.data(), 0.0), "shpair_set_shape");
+    double r = 0.0;
+    check(shpair_get_rmax(ctx, s, &r), "shpair_get_rmax");
+    if (r > maxrad) maxrad = r;
+  }
+}
+
+/* ----------------------------------------------------------------------
+   pair_coeff I J kn exponent
+------------------------------------------------------------------------- */
+
+void PairSH::coeff(int narg, char **arg)
+{
+  if (narg != 4) error->all(FLERR, "Incorrect args for pair coefficients: pair_coeff I J kn exponent");
+  if (!allocated) allocate();
+  int ilo, ihi, jlo, jhi;
+#ifdef SHPAIR_LAMMPS_OLD_API    // LAMMPS before 2020: Force::bounds; later: utils::bounds
+  force->bounds(FLERR, arg[0], atom->ntypes, ilo, ihi);
+  force->bounds(FLERR, arg[1], atom->ntypes, jlo, jhi);
+#else
+  utils::bounds(FLERR, arg[0], 1, atom->ntypes, ilo, ihi, error);
+  utils::bounds(FLERR, arg[1], 1, atom->ntypes, jlo, jhi, error);
+#endif
+  const double k = atof(arg[2]);
+  const double e = atof(arg[3]);
+  if (k < 0.0) error->all(FLERR, "pair_coeff sh: kn must be >= 0");
+  if (e < 1.0) error->all(FLERR, "pair_coeff sh: exponent must be >= 1");
+  int count = 0;
+  for (int i = ilo; i <= ihi; i++)
+    for (int j = (jlo > i ? jlo : i); j <= jhi; j++) {
+      kn[i][j] = kn[j][i] = k;
+      exponent[i][j] = exponent[j][i] = e;
+      setflag[i][j] = 1;
+      count++;
+    }
+  if (count == 0) error->all(FLERR, "Incorrect args for pair coefficients");
+}
+
+/* ---------------------------------------------------------------------- */
+
+void PairSH::init_style()
+{
+  if (!ctx) error->all(FLERR, "pair sh: pair_style sh was not processed");
+  int flag = 0, cols = 0;
+  const bool have_quat = atom->extract("quat") || atom->find_custom("quat", flag, cols) >= 0;
+  const bool have_shtype = atom->extract("shtype") || atom->find_custom("shtype", flag, cols) >= 0;
+  if (!have_quat) error->all(FLERR, "pair sh requires per-atom quaternions (atom_style spherharm, or fix property/atom d2_quat 4)");
+  if (!have_shtype) error->all(FLERR, "pair sh requires a per-atom shape index (atom_style spherharm, or fix property/atom i_shtype)");
+  load_shapes();    // also sizes the coefficient tables, so pair_coeff values go in afterwards
+  for (int i = 1; i <= atom->ntypes; i++)
+    for (int j = 1; j <= atom->ntypes; j++) {
+      if (!setflag[i][j] && !setflag[j][i]) error->all(FLERR, "All pair coeffs are not set");
+      check(shpair_set_coeff(ctx, i, j, kn[i][j], exponent[i][j]), "shpair_set_coeff");
+    }
+#ifdef SHPAIR_LAMMPS_OLD_API
+  neighbor->request(this, instance_me);    // default request: half list
+#else
+  neighbor->add_request(this);    // default request: half list, newton follows the run
+#endif
+  last_neigh_build = -1;
+}
+
+/* cutoff of a type pair: the two largest bounding spheres may touch */
+
+double PairSH::init_one(int i, int j)
+{
+  if (setflag[i][j] == 0 && setflag[j][i] == 0) error->all(FLERR, "All pair coeffs are not set");
+  kn[j][i] = kn[i][j];
+  exponent[j][i] = exponent[i][j];
+  return 2.0 * maxrad;
+}
+
+/* ----------------------------------------------------------------------
+   the hot path: one call into the HIP library per timestep
+------------------------------------------------------------------------- */
+
+void PairSH::compute(int eflag, int vflag)
+{
+  ev_init(eflag, vflag);
+
+  const int nlocal = atom->nlocal;
+  const int nall = nlocal + atom->nghost;
+
+  // neighbour list: re-upload only after a rebuild
+  if (neighbor->lastcall != last_neigh_build) {
+    check(shpair_set_neighbors(ctx, list->inum, list->ilist, list->numneigh, list->firstneigh), "shpair_set_neighbors");
+    last_neigh_build = neighbor->lastcall;
+  }
+
+  // per-atom orientation and shape index
+  int flag = 0, cols = 0, idx;
+  double **quat = (double **) atom->extract("quat");
+  if (!quat && (idx = atom->find_custom("quat", flag, cols)) >= 0 && flag == 1 && cols == 4) quat = atom->darray[idx];
+  if (!quat) error->one(FLERR, "pair sh: per-atom quaternions disappeared");
+  int *shtype = (int *) atom->extract("shtype");
+  if (!shtype && (idx = atom->find_custom("shtype", flag, cols)) >= 0 && flag == 0 && cols == 0) shtype = atom->ivector[idx];
+  if (!shtype) error->one(FLERR, "pair sh: per-atom shape index disappeared");
+
+  double eng = 0.0, vir[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+  double *x0 = nall ? atom->x[0] : nullptr;
+  double *q0 = nall ? quat[0] : nullptr;
+  double *f0 = nall ? atom->f[0] : nullptr;
+  double *t0 = nall ? atom->torque[0] : nullptr;
+  check(shpair_compute(ctx, nlocal, atom->nghost, x0, q0, atom->type, shtype, force->newton_pair, eflag_global ? 1 : 0,
+                       vflag_global ? 1 : 0, f0, t0, &eng, vir),
+        "shpair_compute");
+
+  if (eflag_global) eng_vdwl += eng;
+  if (vflag_global)
+    for (int a = 0; a < 6; a++) virial[a] += vir[a];
+  if (eflag_atom || vflag_atom) error->all(FLERR, "pair sh does not tally per-atom energy/virial");
+}
+
+void *PairSH::extract(const char *str, int &dim)
+{
+  dim = 2;
+  if (strcmp(str, "kn") == 0) return (void *) kn;
+  if (strcmp(str, "exponent") == 0) return (void *) exponent;
+  dim = 0;
+  if (strcmp(str, "nq") == 0) return (void *) &nq;
+  return nullptr;
+}

@@ -1,0 +1,2 @@
+// COMPILE-CHECK SCAFFOLD (see lammps_stub.h) — stands in for LAMMPS' comm.h in this image only.
+#include "lammps_stub.h"

@@ -1,0 +1,191 @@
+// lammps_stub.h — COMPILE-CHECK AND TEST SCAFFOLD, NOT LAMMPS.
+//
+// There are no LAMMPS headers in this image, so the adapter
+// pair_sh.{h,cpp} cannot be compiled against the real thing here.  This file
+// declares, hand-written from the public LAMMPS developer documentation, only
+// the members the adapter touches, with just enough behaviour behind them for
+// tests/lammps_host to drive PairSH::settings/coeff/init_style/compute on a
+// synthetic bed.  Nothing here is shipped or used outside that test; with a
+// real LAMMPS tree the adapter includes the real headers instead.
+#pragma once
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#define FLERR __FILE__, __LINE__
+
+namespace LAMMPS_NS {
+
+typedef int64_t bigint;
+
+class Error {
+ public:
+  [[noreturn]] void all(const char *file, int line, const char *msg)
+  {
+    fprintf(stderr, "ERROR: %s (%s:%d)\n", msg, file, line);
+    exit(1);
+  }
+  [[noreturn]] void one(const char *file, int line, const char *msg) { all(file, line, msg); }
+};
+
+class Memory {
+ public:
+  template <typename T> T **create(T **&a, int n1, int n2, const char *)
+  {
+    T *data = (T *) calloc((size_t) n1 * n2, sizeof(T));
+    a = (T **) malloc(sizeof(T *) * n1);
+    for (int i = 0; i < n1; i++) a[i] = data + (size_t) i * n2;
+    return a;
+  }
+  template <typename T> void destroy(T **&a)
+  {
+    if (!a) return;
+    free(a[0]);
+    free(a);
+    a = nullptr;
+  }
+};
+
+class Atom {
+ public:
+  int ntypes = 1, nlocal = 0, nghost = 0;
+  double **x = nullptr, **f = nullptr, **torque = nullptr;
+  int *type = nullptr;
+  int **iarray = nullptr;
+  int **ivector = nullptr;      // custom per-atom int vectors
+  double ***darray = nullptr;   // custom per-atom double arrays
+  std::map<std::string, void *> extractable;
+  std::vector<std::string> custom_names;
+  std::vector<int> custom_flag, custom_cols;
+  void *extract(const char *name)
+  {
+    auto it = extractable.find(name);
+    return it == extractable.end() ? nullptr : it->second;
+  }
+  int find_custom(const char *name, int &flag, int &cols)
+  {
+    for (size_t i = 0; i < custom_names.size(); i++)
+      if (custom_names[i] == name) {
+        flag = custom_flag[i];
+        cols = custom_cols[i];
+        return (int) i;
+      }
+    return -1;
+  }
+};
+
+class Force {
+ public:
+  int newton_pair = 1;
+  void bounds(const char *, int, char *str, int nmax, int &nlo, int &nhi)
+  {
+    if (strcmp(str, "*") == 0) {
+      nlo = 1;
+      nhi = nmax;
+    } else
+      nlo = nhi = atoi(str);
+  }
+};
+
+class NeighList {
+ public:
+  int inum = 0;
+  int *ilist = nullptr, *numneigh = nullptr;
+  int **firstneigh = nullptr;
+};
+
+class Neighbor {
+ public:
+  bigint lastcall = 0;
+  int nrequest = 0;
+  void add_request(class Pair *) { nrequest++; }
+  void request(void *, int) { nrequest++; }
+};
+
+class Comm {
+ public:
+  int me = 0, nprocs = 1;
+};
+class Update {
+ public:
+  bigint ntimestep = 0;
+};
+
+class LAMMPS {
+ public:
+  Memory *memory = new Memory;
+  Error *error = new Error;
+  Atom *atom = new Atom;
+  Force *force = new Force;
+  Neighbor *neighbor = new Neighbor;
+  Comm *comm = new Comm;
+  Update *update = new Update;
+};
+
+class Pointers {
+ public:
+  explicit Pointers(LAMMPS *p) :
+      lmp(p), memory(p->memory), error(p->error), atom(p->atom), force(p->force), neighbor(p->neighbor),
+      comm(p->comm), update(p->update)
+  {
+  }
+  virtual ~Pointers() = default;
+
+ protected:
+  LAMMPS *lmp;
+  Memory *&memory;
+  Error *&error;
+  Atom *&atom;
+  Force *&force;
+  Neighbor *&neighbor;
+  Comm *&comm;
+  Update *&update;
+};
+
+namespace utils {
+inline void bounds(const char *, int, const char *str, int nmin, int nmax, int &nlo, int &nhi, Error *)
+{
+  if (strcmp(str, "*") == 0) {
+    nlo = nmin;
+    nhi = nmax;
+  } else
+    nlo = nhi = atoi(str);
+}
+}    // namespace utils
+
+class Pair : protected Pointers {
+ public:
+  double eng_vdwl = 0.0, eng_coul = 0.0;
+  double virial[6] = {0, 0, 0, 0, 0, 0};
+  int allocated = 0;
+  int **setflag = nullptr;
+  double **cutsq = nullptr;
+  int single_enable = 1, restartinfo = 1, no_virial_fdotr_compute = 0, manybody_flag = 0;
+  int instance_me = 0;
+  NeighList *list = nullptr;
+  int eflag_either = 0, eflag_global = 0, eflag_atom = 0, vflag_either = 0, vflag_global = 0, vflag_atom = 0;
+  int evflag = 0;
+
+  explicit Pair(LAMMPS *p) : Pointers(p) {}
+  virtual void compute(int, int) = 0;
+  virtual void settings(int, char **) = 0;
+  virtual void coeff(int, char **) = 0;
+  virtual void init_style() {}
+  virtual double init_one(int, int) { return 0.0; }
+  virtual void *extract(const char *, int &) { return nullptr; }
+  void ev_init(int eflag, int vflag)
+  {
+    eflag_either = eflag_global = eflag ? 1 : 0;
+    vflag_either = vflag_global = vflag ? 1 : 0;
+    eflag_atom = vflag_atom = 0;
+    evflag = eflag || vflag;
+    eng_vdwl = eng_coul = 0.0;
+    for (double &v : virial) v = 0.0;
+  }
+};
+
+}    // namespace LAMMPS_NS

@@ -1,0 +1,91 @@
+"""The C++ host path: PairSH (lammps-spherharm_amd/lammps/pair_sh.cpp) driven through
+settings -> coeff -> init_style -> init_one -> compute by a minimal C++ host built
+against the stub headers (this image has no LAMMPS tree).  CPU: the adapter compiles
+and, without a GPU, refuses to run.  GPU: forces/torques/energy/virial equal the oracle."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from common import make_case, coeff_tables, oracle_compute
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LMP = os.path.join(ROOT, "lammps-spherharm_amd", "lammps")
+HOST = os.path.join(LMP, "build", "lammps_host")
+
+
+def build_host():
+    subprocess.check_call(["make", "-C", LMP], stdout=subprocess.DEVNULL)
+    assert os.path.exists(HOST)
+
+
+def write_inputs(tmp_path, case, nlocal, newton, eflag):
+    b = case["bed"]
+    n = case["n"]
+    bedf = tmp_path / "bed.txt"
+    with open(bedf, "w") as fp:
+        fp.write(f"{nlocal} {n - nlocal} 1 {int(newton)} {int(eflag)}\n")
+        for i in range(n):
+            fp.write(" ".join(repr(float(v)) for v in (*b["x"][i], *b["quat"][i])) +
+                     f" {b['type'][i]} {b['shtype'][i]}\n")
+        of, jl = case["offsets"], case["jlist"]
+        rows = [ii for ii in range(len(case["ilist"]))]
+        fp.write(f"{len(rows)}\n")
+        for ii in rows:
+            js = jl[of[ii]:of[ii + 1]]
+            fp.write(f"{case['ilist'][ii]} {len(js)} " + " ".join(str(int(j)) for j in js) + "\n")
+    shapes = []
+    for s, a in enumerate(case["shapes"]):
+        p = tmp_path / f"shape{s}.txt"
+        a2 = np.asarray(a).reshape(-1, 2)
+        with open(p, "w") as fp:
+            fp.write(f"{case['lmax']}\n")
+            for nn in range(case["lmax"] + 1):
+                for m in range(nn + 1):
+                    k = nn * (nn + 1) // 2 + m
+                    fp.write(f"{nn} {m} {a2[k, 0]!r} {a2[k, 1]!r}\n")
+        shapes.append(str(p))
+    return str(bedf), shapes
+
+
+def test_adapter_compiles_and_has_no_cpu_fallback(tmp_path, oracle, gpu_available):
+    build_host()
+    if gpu_available:
+        pytest.skip("GPU present: the host run is covered by the -m gpu test")
+    case = make_case(20, 4, 1, seed=30, rmax_fn=oracle.shape_rmax)
+    bedf, shapes = write_inputs(tmp_path, case, 20, True, False)
+    r = subprocess.run([HOST, bedf, str(tmp_path / "out.txt"), "8", "1000.0", "1.0", *shapes],
+                       capture_output=True, text=True)
+    assert r.returncode != 0 and "cannot open HIP device" in r.stderr and "no CPU fallback" in r.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("newton,expo", [(True, 1.25), (False, 1.0)])
+def test_pairsh_adapter_matches_oracle(tmp_path, oracle, newton, expo):
+    build_host()
+    case = make_case(260, 6, 2, seed=31, rmax_fn=oracle.shape_rmax)
+    nlocal = 260 if newton else 130
+    if not newton:
+        case = dict(case)
+        case["ilist"] = case["ilist"][:nlocal]
+        case["jlist"] = case["jlist"][:case["offsets"][nlocal]]
+        case["offsets"] = case["offsets"][:nlocal + 1]
+    bedf, shapes = write_inputs(tmp_path, case, nlocal, newton, True)
+    out = tmp_path / "out.txt"
+    env = dict(os.environ)
+    r = subprocess.run([HOST, bedf, str(out), "12", "750.0", repr(expo), *shapes], capture_output=True, text=True,
+                       env=env, timeout=300)
+    assert r.returncode == 0, r.stderr
+    lines = open(out).read().split("\n")
+    cut, e1, e2 = (float(v) for v in lines[0].split())
+    vir = np.array([float(v) for v in lines[1].split()])
+    ft = np.array([[float(v) for v in ln.split()] for ln in lines[2:] if ln.strip()])
+    K, E = coeff_tables(1, 750.0, expo)
+    o = oracle_compute(oracle, case, 12, K, E, nlocal=nlocal, newton_pair=newton, eflag=True, vflag=True)
+    fs = np.abs(o["f"]).max()
+    assert abs(cut - 2 * max(case["rmax"])) < 1e-14
+    assert np.abs(ft[:, :3] - o["f"]).max() < 1e-9 * fs
+    assert np.abs(ft[:, 3:] - o["torque"]).max() < 1e-9 * max(fs, np.abs(o["torque"]).max())
+    assert abs(e1 - o["eng_virial"][0]) < 1e-9 * o["eng_virial"][0] and abs(e2 - e1) < 1e-11 * e1
+    assert np.abs(vir - o["eng_virial"][1:]).max() < 1e-9 * np.abs(o["eng_virial"][1:]).max()
