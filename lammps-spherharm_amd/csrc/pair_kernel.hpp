@@ -67,6 +67,11 @@ constexpr int kWavesPerBlock = 4;
 #define SHP_MIN_WAVES 4  // waves per SIMD the register allocator must leave room for (<= 128 VGPRs)
 #endif
 
+// docs/SPEC.md §2.6: residual below which the inverse-quadratic extrapolation is accepted
+#ifndef SHP_TAU3
+#define SHP_TAU3 1e-4
+#endif
+
 // Per-wave LDS: the pair frame (everything per pair the node loops need, kept
 // out of VGPRs) and the queue of inside nodes waiting for phase 2.
 constexpr int kQueue = 128;  // entries; a slab adds <= 64 to a queue holding < 64
@@ -94,6 +99,16 @@ __device__ __forceinline__ double rsqrt_nr(const double x)
   h = fma(-x * y, y, 1.0);
   y = fma(y * 0.5, h, y);
   return y;
+}
+
+// 1/d to the last ulp or two: v_rcp_f64 + two Newton steps (5 VALU ops instead of
+// the ~12 of an IEEE division); 0 and denormals give inf/NaN, which the callers test.
+__device__ __forceinline__ double rcp_nr(const double d)
+{
+  double r = __builtin_amdgcn_rcp(d);
+  r = fma(fma(-d, r, 1.0), r, r);
+  r = fma(fma(-d, r, 1.0), r, r);
+  return r;
 }
 
 template <int L, bool NEEDV>
@@ -182,6 +197,9 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock, SHP_MIN_WAVES) pair_conta
   const int nq = P.nq;
   const int npsi = 2 * nq;
   const int Q = nq * npsi;
+  // p / npsi for 0 <= p < Q <= 2^15 as a multiply-shift: exact because
+  // magic * npsi - 2^24 < npsi <= 256 < 2^24 / 2^15
+  const unsigned magic = ((1u << 24) + (unsigned)npsi - 1u) / (unsigned)npsi;
   const int nslabs = (Q + 63) >> 6;
   const double hw = 0.5 * (1.0 - cosa), hm = 0.5 * (1.0 + cosa);
   const double dpsi = 6.283185307179586476925286766559 / (double)npsi;
@@ -197,7 +215,7 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock, SHP_MIN_WAVES) pair_conta
       const int p = (slab << 6) + lane;
       ++slab;
       const bool valid = p < Q;
-      const int k = valid ? p / npsi : 0;
+      const int k = valid ? (int)(((unsigned)p * magic) >> 24) : 0;
       const int l = valid ? p - k * npsi : 0;
       const double mu = fma(hw, P.glt[k], hm);
       const double sig = sqrt(fmax(0.0, fma(-mu, mu, 1.0)));
@@ -264,7 +282,7 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock, SHP_MIN_WAVES) pair_conta
 #endif
     const int p = lds.qp[e];
     const double ri = lds.qri[e];
-    const int k = p / npsi;
+    const int k = (int)(((unsigned)p * magic) >> 24);
     const int l = p - k * npsi;
     const double mu = fma(hw, P.glt[k], hm);
     const double sig = sqrt(fmax(0.0, fma(-mu, mu, 1.0)));
@@ -279,7 +297,8 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock, SHP_MIN_WAVES) pair_conta
       const double uj1 = fma(a1, fr[FR_BJ1 + 1], fma(a2, fr[FR_BJ2 + 1], mu * fr[FR_BJC + 1]));
       const double uj2 = fma(a1, fr[FR_BJ1 + 2], fma(a2, fr[FR_BJ2 + 2], mu * fr[FR_BJC + 2]));
       bool act = active && !centre_inside;
-      double lo = 0.0, hi = ri, lam, lprev = ri, gprev;
+      // three most recent points: (xa,ga) oldest, (xb,gb), (lam,gl) newest
+      double lo = 0.0, hi = ri, lam, xa = ri, ga, xb = ri, gb;
       {
         const double dj0 = fr[FR_DJ], dj1 = fr[FR_DJ + 1], dj2 = fr[FR_DJ + 2];
         const double bp = uj0 * dj0 + uj1 * dj1 + uj2 * dj2;
@@ -287,9 +306,9 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock, SHP_MIN_WAVES) pair_conta
         lam = bp - sqrt(fmax(0.0, fma(bp, bp, -(rho2 - rj0 * rj0))));
         if (!(lam > lo && lam < hi)) lam = 0.5 * (lo + hi);
         const double q0 = fma(ri, uj0, -dj0), q1 = fma(ri, uj1, -dj1), q2 = fma(ri, uj2, -dj2);
-        gprev = sqrt(q0 * q0 + q1 * q1 + q2 * q2) - rj0;
+        ga = gb = sqrt(q0 * q0 + q1 * q1 + q2 * q2) - rj0;
       }
-      const double tolg = 1e-7 * Rj, tolx = 1e-14 * Rj;
+      const double tolx = 1e-14 * Rj;
       if (!act) lam = ri;
       for (int it = 0; it < 60; ++it) {
         if (!__any(act)) break;
@@ -308,18 +327,29 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock, SHP_MIN_WAVES) pair_conta
         const double gl = z0 ? -Rj : ss2 * iv - rj;
         if (act) {
           if (gl >= 0.0) lo = lam; else hi = lam;
-          double nxt = lam - gl * (lam - lprev) / (gl - gprev);
-          if (fabs(gl) <= tolg) {  // accept the extrapolated point, clamped to the bracket
-            rin = (fabs(nxt) <= 1e300) ? fmin(fmax(nxt, lo), hi) : lam;
+          const bool have3 = it >= 1;
+          const double dbl = gb - gl;
+          const double sec = fma(gl * (lam - xb), rcp_nr(dbl), lam);
+          double ext = sec;  // extrapolation to g = 0 through all known points
+          if (have3) {       // inverse quadratic interpolation over one common denominator
+            const double dab = ga - gb, dal = ga - gl;
+            const double num = fma(xa * gb, gl * dbl, fma(lam * ga, gb * dab, -(xb * ga) * (gl * dal)));
+            ext = num * rcp_nr(dab * dal * dbl);
+          }
+          if (!(fabs(ext) <= 1e300)) ext = sec;
+          if (fabs(gl) <= (have3 ? SHP_TAU3 : 1e-7) * Rj) {  // accept the extrapolated point
+            rin = (fabs(ext) <= 1e300) ? fmin(fmax(ext, lo), hi) : lam;
             act = false;
           } else {
+            double nxt = ext;
+            if (!(nxt > lo && nxt < hi)) nxt = sec;
             if (!(nxt > lo && nxt < hi)) nxt = 0.5 * (lo + hi);
             if (hi - lo <= tolx) {
               rin = 0.5 * (lo + hi);
               act = false;
             } else {
               rin = nxt;
-              lprev = lam; gprev = gl; lam = nxt;
+              xa = xb; ga = gb; xb = lam; gb = gl; lam = nxt;
             }
           }
         }

@@ -61,13 +61,19 @@ SHP_HD constexpr double scale(int n, int m)
   for (int k = n; k >= m + 2; k -= 2) s *= beta(k, m);
   return s;
 }
-// the multiplier of z Q_{n-1} in the rescaled recurrence; for n == m+1 it
-// includes Pi_m^m (Q_{m+1} = a1 z)
+// The kernels run the recurrence on Q_n = Pi_n^m / (s_nm Pi_m^m):
+//   Q_m = 1,  Q_{m+1} = a'_{m+1} z,  Q_n = a'_n z Q_{n-1} - Q_{n-2}.
+// Both subtrahends (Q_{n-2} in general, Q_m = 1.0 for n = m+2) then cost no
+// register: 1.0 is an inline constant of v_fma_f64, a general constant is not
+// (one SGPR operand per VALU instruction on gfx950) and had to be copied to a
+// VGPR pair per m-block.  Pi_m^m and s_nm are folded into the coefficients.
 SHP_HD constexpr double aprime(int n, int m)
 {
-  if (n == m + 1) return alpha(n, m) * pmm(m);
+  if (n == m + 1) return alpha(n, m);
   return alpha(n, m) * scale(n - 1, m) / scale(n, m);
 }
+// what the host multiplies (2 - delta_m0) a_nm with
+SHP_HD constexpr double coef_scale(int n, int m) { return scale(n, m) * pmm(m); }
 
 }  // namespace sh_const
 }  // namespace shp

@@ -4,7 +4,8 @@
 //   r = sum_m Re[ W_m(z) (x+iy)^m ],  W_m(z) = sum_n Q_n^m(z) cw_nm
 // with the z-polynomials Q_n^m from a two-term recurrence rescaled so that the
 // coefficient of Q_{n-2} is exactly 1 (one v_mul_f64 + one v_fma_f64 per term):
-//   Q_m^m = Pi_m^m (constant), Q_{m+1}^m = a1 z, Q_n^m = a'_nm z Q_{n-1}^m - Q_{n-2}^m.
+//   Q_m^m = 1, Q_{m+1}^m = a'_{m+1,m} z, Q_n^m = a'_nm z Q_{n-1}^m - Q_{n-2}^m
+// (Pi_n^m = s_nm Pi_m^m Q_n^m; the factor s_nm Pi_m^m is folded into cw on the host).
 //
 // Where the operands live (one wavefront per pair, so all of them are
 // wave-uniform):
@@ -17,9 +18,8 @@
 //
 // Table layout (built on the host by sh_tables.cpp), m-major so that the
 // constants of one m-block are contiguous: k = sh_index(L, n, m)
-//   rc[k]                 : n == m   -> Pi_m^m ; n == m+1 -> a1 ; n >= m+2 -> a'_nm
-//   cw[2k], cw[2k+1]      : (2-delta_m0) a_nm s_nm, for n == m additionally
-//                           multiplied by Pi_m^m so that W_m starts at cw.
+//   rc[k]                 : n == m -> 1 ; n > m -> a'_nm
+//   cw[2k], cw[2k+1]      : (2-delta_m0) a_nm s_nm Pi_m^m
 // Reference: the SH math helpers of the reference are ABSENT FROM MOUNT
 // (SURVEY.md §2.2); this is the build's own formulation.
 #pragma once
@@ -97,14 +97,14 @@ __device__ __forceinline__ void sh_term(const double cr, const double ci, const 
   if constexpr (N > L) {
     return;
   } else if constexpr (N == M) {
-    s.Wr = cr;   // cw already carries Pi_m^m
+    s.Wr = cr;   // Q_m = 1
     s.Wi = (M > 0) ? ci : 0.0;
     s.Zr = 0.0;
     s.Zi = 0.0;
     s.p1 = 0.0; s.p2 = 0.0; s.d1 = 0.0; s.d2 = 0.0;
   } else if constexpr (N == M + 1) {
     const double a1 = SHP_SGPR_CONST(sh_const::aprime(M + 1, M));
-    s.p2 = SHP_SGPR_CONST(sh_const::pmm(M));
+    s.p2 = 1.0;   // Q_m, an inline constant
     s.p1 = a1 * z;
     s.d2 = 0.0;
     s.d1 = a1;

@@ -48,14 +48,16 @@ void build_recurrence(int L, std::vector<double>& rc, std::vector<double>& scale
 {
   // n-major (k = n(n+1)/2+m); values from sh_const.hpp so that the host-folded
   // scale and the constants compiled into the kernels agree bit for bit.
+  // rc: n == m -> 1 (Q_m), n > m -> a'_nm.  scale: s_nm Pi_m^m.
   const int T = (L + 1) * (L + 2) / 2;
   rc.assign(T, 0.0);
   scale.assign(T, 1.0);
   for (int m = 0; m <= L; ++m) {
-    rc[idx(m, m)] = sh_const::pmm(m);
+    rc[idx(m, m)] = 1.0;
+    scale[idx(m, m)] = sh_const::coef_scale(m, m);
     for (int n = m + 1; n <= L; ++n) {
       rc[idx(n, m)] = sh_const::aprime(n, m);
-      scale[idx(n, m)] = sh_const::scale(n, m);
+      scale[idx(n, m)] = sh_const::coef_scale(n, m);
     }
   }
 }
@@ -63,16 +65,15 @@ void build_recurrence(int L, std::vector<double>& rc, std::vector<double>& scale
 void build_coefficients(int L, int lmax, const double* anm, const std::vector<double>& rc,
                         const std::vector<double>& scale, std::vector<double>& cw)
 {
+  (void)rc;
   const int T = (L + 1) * (L + 2) / 2;
   cw.assign(2 * T, 0.0);
   for (int n = 0; n <= lmax && n <= L; ++n)
     for (int m = 0; m <= n; ++m) {
       const int k = idx(n, m);
       const double fac = (m == 0) ? 1.0 : 2.0;
-      double sc = scale[k];
-      if (n == m) sc = rc[k];  // W_m starts at cw * Pi_m^m
-      cw[2 * k] = fac * anm[2 * k] * sc;
-      cw[2 * k + 1] = (m == 0) ? 0.0 : fac * anm[2 * k + 1] * sc;
+      cw[2 * k] = fac * anm[2 * k] * scale[k];
+      cw[2 * k + 1] = (m == 0) ? 0.0 : fac * anm[2 * k + 1] * scale[k];
     }
 }
 

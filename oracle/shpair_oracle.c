@@ -250,22 +250,30 @@ int sho_pair(int Li, const double *anmi, double Ri, int Lj, const double *anmj, 
         double hi = ri;
         double lam = bp - sqrt(fmax(0.0, bp * bp - (rho2 - rj0 * rj0)));
         if (!(lam > lo && lam < hi)) lam = 0.5 * (lo + hi);
-        double lprev = ri, gprev = s - rj0;
+        /* three most recent points: (xa,ga) oldest, (xb,gb), (lam,gl) newest */
+        double xa = ri, ga = s - rj0, xb = ri, gb = s - rj0;
         rin = lam;
         for (int it = 0; it < 60; ++it) {
           const double gl = g_ray(Lj, anmj, Rj, uj, dj, lam);
           if (diag) diag[2] += 1.0;
           if (gl >= 0.0) lo = lam; else hi = lam;
-          double nxt = lam - gl * (lam - lprev) / (gl - gprev);
-          const int ok = (nxt > lo && nxt < hi);
-          if (fabs(gl) <= 1e-7 * Rj) {  /* accept the extrapolated point, clamped to the bracket */
-            rin = (fabs(nxt) <= 1e300) ? fmin(fmax(nxt, lo), hi) : lam;
+          const int have3 = (it >= 1);
+          const double sec = lam - gl * (lam - xb) / (gl - gb);
+          double ext = sec;  /* extrapolation through all known points */
+          if (have3)
+            ext = xa * gb * gl / ((ga - gb) * (ga - gl)) + xb * ga * gl / ((gb - ga) * (gb - gl)) +
+                  lam * ga * gb / ((gl - ga) * (gl - gb));
+          if (!(fabs(ext) <= 1e300)) ext = sec;
+          if (fabs(gl) <= (have3 ? 1e-4 : 1e-7) * Rj) {  /* accept the extrapolated point */
+            rin = (fabs(ext) <= 1e300) ? fmin(fmax(ext, lo), hi) : lam;
             break;
           }
-          if (!ok) nxt = 0.5 * (lo + hi);
+          double nxt = ext;
+          if (!(nxt > lo && nxt < hi)) nxt = sec;
+          if (!(nxt > lo && nxt < hi)) nxt = 0.5 * (lo + hi);
           if (hi - lo <= 1e-14 * Rj) { rin = 0.5 * (lo + hi); break; }
           rin = nxt;
-          lprev = lam; gprev = gl; lam = nxt;
+          xa = xb; ga = gb; xb = lam; gb = gl; lam = nxt;
         }
       }
       out[0] += om * (ri * ri * ri - rin * rin * rin) / 3.0;

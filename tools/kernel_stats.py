@@ -11,7 +11,7 @@ sys.path.insert(0, os.path.join(ROOT, "lammps-spherharm_amd"))
 import torch  # noqa: E402,F401
 from shpair import capi, shapes, bed  # noqa: E402
 
-capi.library_path = lambda: os.path.join(ROOT, "lammps-spherharm_amd", "shpair", "libshpair_stats.so")
+capi.library_path = lambda: os.path.join(ROOT, "lammps-spherharm_amd", "shpair", os.environ.get("SHP_STATS_LIB", "libshpair_stats.so"))
 from shpair import ShPair  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 100000
@@ -37,7 +37,7 @@ npairs = jl.size
 Q = 2 * nq * nq
 print(f"pairs {npairs}  Q {Q}  slabs/pair {d[0] / npairs:.2f}")
 print(f"nodes in B_j: {d[1] / (npairs * Q):.3f} of all nodes; slabs with j-eval: {d[2] / d[0]:.3f}")
-print(f"inside nodes: {d[3] / (npairs * Q):.3f} of all nodes; slabs with gradient pass: {d[4] / d[0]:.3f}; "
-      f"lane fill in those slabs: {d[3] / max(1, 64 * d[4]):.3f}")
-print(f"root finder: wave iterations per gradient slab {d[5] / max(1, d[4]):.2f}; lane evals per inside node "
+print(f"inside nodes: {d[3] / (npairs * Q):.3f} of all nodes; phase-2 batches per pair: {d[4] / npairs:.2f}; "
+      f"lane fill of the batches: {d[7] / max(1, 64 * d[4]):.3f}")
+print(f"root finder: wave iterations per batch {d[5] / max(1, d[4]):.2f}; lane evals per inside node "
       f"{d[6] / max(1, d[3]):.2f}; lane fill in root loop {d[6] / max(1, 64 * d[5]):.3f}")
