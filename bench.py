@@ -48,6 +48,12 @@ def parse():
     ap.add_argument("--nshapes", type=int, default=1)
     ap.add_argument("--exponent", type=float, default=1.25)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg (0 = skip)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl = RCCL over xGMI (the product path). gloo = rehearsal only: every rank uses "
+                         "GPU 0 and the halo buffers are staged through the host")
+    ap.add_argument("--verify", action="store_true",
+                    help="N > 1: gather the owned forces and compare them with a single-domain compute of the "
+                         "whole bed on rank 0 (small beds only)")
     ap.add_argument("--cpu-threads", type=int, default=16, help="OpenMP threads of the cpu_baseline leg "
                     "(16 = the host-core share of one GPU on the bench box)")
     return ap.parse_args()
@@ -70,13 +76,19 @@ def main():
     if not torch.cuda.is_available():
         print("bench.py: no GPU visible; the HIP path has no CPU fallback", file=sys.stderr)
         sys.exit(3)
+    rehearsal = args.backend == "gloo"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     lmax, nq, nshapes = args.lmax, args.nq, args.nshapes
     shp = [shapes.random_shape(lmax, bed.SEED0 + 2 + s) for s in range(nshapes)]
@@ -102,7 +114,7 @@ def main():
         view = dec.plan(rank)
         gid, nlocal = view["gid"], view["nlocal"]
         il, of, jl = dec.neighbor_list(view)
-        halo = HaloExchange(view, dev, dist)
+        halo = HaloExchange(view, dev, dist, host_staged=rehearsal)
     nall = gid.size
     sp.set_neighbors_csr(il, of, jl)
 
@@ -160,7 +172,8 @@ def main():
     elapsed = time.perf_counter() - t0
     kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
 
-    tot = torch.tensor([elapsed, float(n_contact), float(n_touching), kernel_ms], dtype=torch.float64, device=dev)
+    tot = torch.tensor([elapsed, float(n_contact), float(n_touching), kernel_ms], dtype=torch.float64,
+                       device="cpu" if rehearsal else dev)
     if dist is not None:
         mx = tot.clone()
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
@@ -174,6 +187,32 @@ def main():
     # sanity: forces are finite and (N = 1) sum to zero
     fh = f[:nlocal].cpu().numpy()
     assert np.all(np.isfinite(fh)) and np.abs(fh).max() > 0
+
+    verify_err = None
+    if args.verify and dist is not None:
+        mine = (gid[:nlocal], f[:nlocal].cpu().numpy(), tq[:nlocal].cpu().numpy())
+        parts = [None] * world if rank == 0 else None
+        dist.gather_object(mine, parts, dst=0)
+        if rank == 0:
+            ntot = args.particles * world
+            fg = np.zeros((ntot, 3))
+            tg = np.zeros((ntot, 3))
+            for g_, f_, t_ in parts:
+                fg[g_] = f_
+                tg[g_] = t_
+            ref = ShPair(local_rank)
+            ref.settings(nq)
+            ref.set_ntypes(1, nshapes)
+            for s_, a_ in enumerate(shp):
+                ref.set_shape(s_, lmax, a_)
+            ref.coeff("*", "*", 1000.0, args.exponent)
+            ril, rof, rjl = bed.half_neighbor_list(gbed["x"], gbed["shtype"], rmax)
+            ref.set_neighbors_csr(ril, rof, rjl)
+            fr_, tr_, _, _ = ref.compute(ntot, gbed["x"], gbed["quat"], gbed["type"], gbed["shtype"])
+            ref.close()
+            sc = np.abs(fr_).max()
+            verify_err = float(max(np.abs(fg - fr_).max(), np.abs(tg - tr_).max()) / sc)
+            assert verify_err < 1e-9, f"decomposed forces differ from single-domain forces: {verify_err}"
 
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
@@ -193,11 +232,13 @@ def main():
                             "inputs resident in HBM",
                 "particles_per_gpu": args.particles, "lmax": lmax, "nq": nq, "nshapes": nshapes,
                 "exponent": args.exponent, "proc_grid": list(grid),
+                "backend": "rccl" if (world > 1 and not rehearsal) else ("gloo-rehearsal" if world > 1 else "none"),
                 "half_list_pairs_rank0": int(jl.size), "contact_pairs_rank0": int(n_contact),
                 "touching_pairs_rank0": int(n_touching), "contact_pairs_all_ranks": int(contact_all),
                 "ghost_atoms_rank0": int(nall - nlocal),
             },
             "timesteps_per_sec": args.steps / elapsed,
+            "verify_rel_err": verify_err,
             "roofline": {
                 "bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": None,

@@ -118,10 +118,13 @@ class Decomposition:
 class HaloExchange:
     """Forward (x, quat -> ghosts) and reverse (ghost f, torque -> owners) exchange for one rank."""
 
-    def __init__(self, view, device, dist_module=None):
+    def __init__(self, view, device, dist_module=None, host_staged=False):
+        """host_staged: exchange through CPU copies of the buffers (for a `gloo` rehearsal of the
+        GPU code path on a box with fewer GPUs than ranks; the product path is RCCL, unstaged)."""
         import torch
         self.torch = torch
         self.dist = dist_module
+        self.host_staged = host_staged
         self.nlocal = view["nlocal"]
         self.recv = dict(view["recv"])
         self.send = {p: torch.as_tensor(idx, device=device) for p, idx in view["send"].items()}
@@ -143,6 +146,10 @@ class HaloExchange:
 
     def _exchange(self, sends, recvs):
         dist = self.dist
+        if self.host_staged:
+            dev_recvs = recvs
+            sends = {p: b.cpu() for p, b in sends.items()}
+            recvs = {p: self.torch.empty(b.shape, dtype=b.dtype) for p, b in dev_recvs.items()}
         ops = []
         for p in self.peers:  # same peer order everywhere; recv first, then send
             if p in recvs:
@@ -152,6 +159,9 @@ class HaloExchange:
         if ops:
             for w in dist.batch_isend_irecv(ops):
                 w.wait()
+        if self.host_staged:
+            for p, b in recvs.items():
+                dev_recvs[p].copy_(b)
 
     def forward(self, x, quat):
         """x[nall,3], quat[nall,4]: owners' rows -> the peers' ghost rows (Comm::forward_comm)."""
