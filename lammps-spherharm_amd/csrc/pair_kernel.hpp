@@ -1,6 +1,15 @@
 // pair_kernel.hpp — the contact kernel: ONE WAVEFRONT PER HALF-LIST PAIR.
 //
-// docs/SPEC.md §2.  Two phases per pair, both 64 nodes wide:
+// docs/SPEC.md §2.  Per pair: a set-up step and two phases, all 64 lanes wide:
+//   set-up   particle i's expansion is rotated into the CAP frame (pole = the
+//            direction to the neighbour): real-SH coefficients through
+//            Z(alpha) X^T Z(beta) X Z(gamma) with the constant matrices
+//            X^l = T(Rx(90 deg)) (no Wigner recursion, no trigonometry beyond
+//            three sin/cos pairs), then per quadrature ring k and order m the
+//            Fourier coefficients A_km, B_km of r_i around the ring and their
+//            mu-derivatives.  After that r_i at a cap node costs 6 FP64 ops per
+//            m instead of a full (L+1)(L+2)/2-term evaluation, and so does its
+//            surface gradient.
 //   phase 1  the lanes stride the Q = 2 nq^2 cap nodes in slabs of 64: r_i at
 //            the node, the surface point in j's frame, r_j there -> inside?
 //            Inside nodes are appended to a per-wave LDS queue (ballot + mbcnt).
@@ -46,6 +55,14 @@ struct PairParams {
   const double* kn;
   const double* expo;
   int ntypes;
+  // cap-frame evaluation of particle i (sh_tables.hpp)
+  const double* creal;   // nshapes x (lmax+1)^2 real-basis coefficients
+  const double* xval;    // X = T(Rx(+90)) and X^T in ELL form: 2 x (lmax+1)^2 rows x (lmax/2+1) values
+  const int* xcol;       // ... and absolute column indices
+  const int* xinfo;      // (lmax+1)^2: l | (m + l) << 8
+  const double* gscale;  // (lmax+1)^2 ring-recurrence scale g_lm
+  int wave_lds_bytes;    // dynamic LDS per wave (wave_lds_layout)
+  int waves_per_block;
   // quadrature tables
   const double* glt;    // nq Gauss-Legendre nodes on [-1,1]
   const double* glw;    // nq weights
@@ -62,7 +79,7 @@ struct PairParams {
   unsigned long long* dbg;  // SHP_STATS builds only: work counters (tools/kernel_stats.py)
 };
 
-constexpr int kWavesPerBlock = 4;
+constexpr int kMaxWavesPerBlock = 4;
 #ifndef SHP_MIN_WAVES
 #define SHP_MIN_WAVES 4  // waves per SIMD the register allocator must leave room for (<= 128 VGPRs)
 #endif
@@ -72,21 +89,50 @@ constexpr int kWavesPerBlock = 4;
 #define SHP_TAU3 1e-4
 #endif
 
-// Per-wave LDS: the pair frame (everything per pair the node loops need, kept
-// out of VGPRs) and the queue of inside nodes waiting for phase 2.
+// ---- per-wave dynamic LDS (doubles unless noted) ---------------------------
+//   frame[kFrame]        pair frame, FR_* below
+//   trig[6 (L+1)]        cos/sin of m alpha, m beta, m gamma
+//   v0[(L+1)^2], v1[..]  ping-pong coefficient vectors of the rotation
+//   ring[nq][L+1][4]     A_km, B_km, dA/dmu, dB/dmu; the two B slots of m = 0
+//                        (identically zero) carry mu_k and sigma_k
+//   qri[kQueue], qrj[kQueue], qp[kQueue] (int)   queue of inside nodes
 constexpr int kQueue = 128;  // entries; a slab adds <= 64 to a queue holding < 64
-struct WaveLds {
-  double frame[36];      // see FR_* below
-  double qri[kQueue];    // r_i at the node
-  double qrj[kQueue];    // r_j at the node's surface point (root-finder start)
-  int qp[kQueue];        // node index p = k * npsi + l
+constexpr int kFrame = 28;
+enum { FR_BJ1 = 0, FR_BJ2 = 3, FR_BJC = 6, FR_DJ = 9, FR_E1 = 12, FR_E2 = 15, FR_C = 18, FR_D = 21 };
+
+struct WaveLdsLayout {
+  int trig, v0, v1, ring, qri, qrj, qp, bytes;  // offsets in doubles (qp: in doubles too), total bytes
 };
-enum { FR_BI1 = 0, FR_BI2 = 3, FR_BIC = 6, FR_BJ1 = 9, FR_BJ2 = 12, FR_BJC = 15, FR_DJ = 18, FR_RMI = 21, FR_D = 30 };
+__host__ __device__ inline WaveLdsLayout wave_lds_layout(const int L, const int nq)
+{
+  WaveLdsLayout w;
+  const int ns = (L + 1) * (L + 1);
+  w.trig = kFrame;
+  w.v0 = w.trig + 6 * (L + 1);
+  w.v1 = w.v0 + ns;
+  w.ring = w.v1 + ns;
+  w.ring += w.ring & 1;  // 16-byte aligned rows for ds_read_b128
+  w.qri = w.ring + 4 * nq * (L + 1);
+  w.qrj = w.qri + kQueue;
+  w.qp = w.qrj + kQueue;
+  w.bytes = 8 * (w.qp + kQueue / 2);
+  w.bytes = (w.bytes + 15) & ~15;
+  return w;
+}
 
 __device__ __forceinline__ unsigned launder_u32(unsigned v)
 {
   asm volatile("" : "+v"(v));
   return v;
+}
+
+__device__ __forceinline__ void wave_lds_sync()
+{
+  // LDS written by some lanes of the wave, read by others: DS operations of one
+  // wave execute in order, so only the compiler has to be kept from reordering.
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
 // 1/sqrt(x) to the last ulp or two: v_rsq_f64 (2^-26) + two Newton steps.
@@ -111,23 +157,187 @@ __device__ __forceinline__ double rcp_nr(const double d)
   return r;
 }
 
-template <int L, bool NEEDV>
-__global__ void __launch_bounds__(64 * kWavesPerBlock, SHP_MIN_WAVES) pair_contact_kernel(const PairParams P)
+// ---- set-up: particle i's expansion in the cap frame ------------------------
+// M = [b1 b2 bc]: the cap axes (e1, e2, c) in i's body frame, so that
+// r_cap(u') = r_body(M u').  M = Rz(alpha) Ry(beta) Rz(gamma), Ry(beta) =
+// Rx(-90) Rz(beta) Rx(90); with (O_A f)(u) = f(A u), O_{AB} = O_B O_A, hence
+//   c' = Z(gamma) X Z(beta) X^T Z(alpha) c ,  X = T(Rx(+90)) (constant).
+// alpha is read off the third column of M; gamma follows from the WELL
+// CONDITIONED sum (cos beta >= 0) or difference (cos beta < 0) of the two
+// angles, so that the 1/sin(beta) error of alpha near the poles only moves the
+// axis of a vanishing tilt.
+template <int L>
+__device__ __forceinline__ void cap_frame_tables(const PairParams& P, double* __restrict__ lw, const WaveLdsLayout& W,
+                                                 const int LL, const int si, const int lane, const double* b1,
+                                                 const double* b2, const double* bc, const double hw, const double hm)
 {
-  __shared__ WaveLds lds_all[kWavesPerBlock];
+  const int ns = (LL + 1) * (LL + 1);
+  double* trig = lw + W.trig;
+  double* v0 = lw + W.v0;
+  double* v1 = lw + W.v1;
+  // Euler angles: lanes 0,1,2 tabulate cos/sin(m angle) for alpha, beta, gamma
+  {
+    const double cb = bc[2];
+    const double sb = sqrt(fmax(0.0, fma(-cb, cb, 1.0)));
+    double ca = 1.0, sa = 0.0;
+    if (sb > 0.0) {
+      const double n = rsqrt_nr(bc[0] * bc[0] + bc[1] * bc[1]);
+      ca = bc[0] * n;
+      sa = bc[1] * n;
+    }
+    double cg, sg;
+    if (cb >= 0.0) {
+      const double iv = 1.0 / (1.0 + cb);
+      const double cs = (b1[0] + b2[1]) * iv, ss = (b1[1] - b2[0]) * iv;  // alpha + gamma
+      cg = cs * ca + ss * sa;
+      sg = ss * ca - cs * sa;
+    } else {
+      const double iv = 1.0 / (1.0 - cb);
+      const double cd = -(b1[0] - b2[1]) * iv, sd = -(b1[1] + b2[0]) * iv;  // alpha - gamma
+      cg = ca * cd + sa * sd;
+      sg = sa * cd - ca * sd;
+    }
+    if (lane < 3) {
+      const double c1 = lane == 0 ? ca : (lane == 1 ? cb : cg);
+      const double s1 = lane == 0 ? sa : (lane == 1 ? sb : sg);
+      double* t = trig + 2 * (LL + 1) * lane;
+      double cm = 1.0, sm = 0.0;
+      for (int m = 0; m <= LL; ++m) {
+        t[2 * m] = cm;
+        t[2 * m + 1] = sm;
+        const double c = fma(cm, c1, -(sm * s1)), s = fma(cm, s1, sm * c1);
+        cm = c;
+        sm = s;
+      }
+    }
+  }
+  wave_lds_sync();
+  const double* creal = P.creal + (size_t)si * ns;
+  const int XW = LL / 2 + 1;
+  // five steps; step s reads `src`, writes `dst`; element e = row (l, m) of the vector
+  for (int step = 0; step < 5; ++step) {
+    const double* src = (step == 0) ? creal : ((step & 1) ? v0 : v1);
+    double* dst = (step & 1) ? v1 : v0;
+    for (int e = lane; e < ns; e += 64) {
+      double out;
+      if ((step & 1) == 0) {  // Z(angle): 0 alpha, 2 beta, 4 gamma
+        const int inf = P.xinfo[e];
+        const int l = inf & 255, mm = (inf >> 8) - l;
+        const double* t = trig + 2 * (LL + 1) * (step >> 1);
+        const int m = mm < 0 ? -mm : mm;
+        const double self = src[e], other = src[l * l + l - mm];
+        const double cm = t[2 * m], sm = t[2 * m + 1];
+        out = (mm == 0) ? self : fma(cm, self, (mm > 0 ? sm : -sm) * other);
+        if (step == 4) out *= P.gscale[e];
+      } else {  // X^T (step 1) or X (step 3), ELL rows
+        const size_t rowoff = ((size_t)(step == 1 ? ns : 0) + e) * XW;
+        const double* val = P.xval + rowoff;
+        const int* col = P.xcol + rowoff;
+        out = 0.0;
+#pragma unroll
+        for (int t = 0; t < ((L >= 0) ? L / 2 + 1 : XW); ++t) out = fma(val[t], src[col[t]], out);
+      }
+      dst[e] = out;
+    }
+    wave_lds_sync();
+  }
+  // rotated, scaled coefficients are in v0.  Ring tables: one (k, m) per lane.
+  const double* ch = v0;
+  double* ring = lw + W.ring;
+  const int nkm = P.nq * (LL + 1);
+  for (int idx = lane; idx < nkm; idx += 64) {
+    const int k = idx / (LL + 1);
+    const int m = idx - k * (LL + 1);
+    const double mu = fma(hw, P.glt[k], hm);
+    const double sig2 = fmax(0.0, fma(-mu, mu, 1.0));
+    const double sig = sqrt(sig2);
+    const double* rcm = P.rc + sh_moff(LL, m);
+    double q2 = 0.0, q1 = 1.0, d2 = 0.0, d1 = 0.0;  // Q_{n-2}, Q_{n-1} and mu-derivatives; start at n = m
+    double wa = ch[m * m + 2 * m], wb = (m > 0) ? ch[m * m] : 0.0, wad = 0.0, wbd = 0.0;
+    double sp = 1.0;  // sigma^m
+    // fixed trip count L: step t multiplies sigma^m while t < m, then is term n = t + 1
+#pragma unroll
+    for (int t = 0; t < ((L >= 0) ? L : LL); ++t) {
+      if (t < m) {
+        sp *= sig;
+      } else {
+        const int n = t + 1;
+        const double a = rcm[n - m];
+        const double q = fma(a, mu * q1, -q2);
+        const double d = fma(a, fma(mu, d1, q1), -d2);
+        const double ca = ch[n * n + n + m], cbm = (m > 0) ? ch[n * n + n - m] : 0.0;
+        wa = fma(ca, q, wa);
+        wb = fma(cbm, q, wb);
+        wad = fma(ca, d, wad);
+        wbd = fma(cbm, d, wbd);
+        q2 = q1; q1 = q; d2 = d1; d1 = d;
+      }
+    }
+    // d/dmu [sigma^m W] = sigma^m (W' - m mu W / sigma^2)
+    const double f = (m > 0) ? (double)m * mu / sig2 : 0.0;
+    double* o = ring + 4 * idx;
+    o[0] = sp * wa;
+    o[2] = sp * fma(-f, wa, wad);
+    if (m == 0) {
+      o[1] = mu;   // B_k0 = 0: the slot carries mu_k
+      o[3] = sig;  // dB_k0/dmu = 0: carries sigma_k
+    } else {
+      o[1] = sp * wb;
+      o[3] = sp * fma(-f, wb, wbd);
+    }
+  }
+  wave_lds_sync();
+}
+
+// r_i (and its mu / psi derivatives) at ring row `row`, azimuth (c1, s1) = (cos psi, sin psi)
+template <int L, bool GRAD>
+__device__ __forceinline__ void ring_eval(const double* __restrict__ row, const int LL, const double c1, const double s1,
+                                          double& r, double& rmu, double& rpsi)
+{
+  r = row[0];
+  rmu = GRAD ? row[2] : 0.0;
+  rpsi = 0.0;
+  double cm = c1, sm = s1;
+  const int lim = (L >= 0) ? L : LL;
+#pragma unroll
+  for (int m = 1; m <= lim; ++m) {
+    const double A = row[4 * m], B = row[4 * m + 1];
+    r = fma(A, cm, r);
+    r = fma(B, sm, r);
+    if (GRAD) {
+      rmu = fma(row[4 * m + 2], cm, rmu);
+      rmu = fma(row[4 * m + 3], sm, rmu);
+      const double dm = (double)m;
+      rpsi = fma(dm * B, cm, rpsi);
+      rpsi = fma(-dm * A, sm, rpsi);
+    }
+    if (m < lim) {
+      const double c = fma(cm, c1, -(sm * s1)), s = fma(cm, s1, sm * c1);
+      cm = c;
+      sm = s;
+    }
+  }
+}
+
+template <int L, bool NEEDV>
+__global__ void __launch_bounds__(64 * kMaxWavesPerBlock, SHP_MIN_WAVES) pair_contact_kernel(const PairParams P)
+{
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int lane = threadIdx.x & 63;
   const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int w = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * kWavesPerBlock)) + wib;
+  const int w = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * P.waves_per_block)) + wib;
   if (w >= P.npairs) return;
-  WaveLds& lds = lds_all[wib];
-  // The frame is loop invariant: a plain LDS load would be hoisted out of the
-  // node loops and pinned in ~70 VGPRs, which is what it is in LDS to avoid.
-  // Each loop iteration therefore re-derives its frame pointer from a byte
-  // offset laundered through an empty asm (an integer, so that the compiler
-  // still sees an LDS address and emits ds_read, not flat loads).
-  const unsigned frame_off = (unsigned)(wib * sizeof(WaveLds));
-#define SHP_FRAME() ((const double*)((const char*)&lds_all[0] + launder_u32(frame_off)))
-  const double* fr = SHP_FRAME();
+  const int LL = (L >= 0) ? L : P.lmax;
+  const int nq = P.nq;
+  const WaveLdsLayout W = wave_lds_layout(LL, nq);
+  // The frame and ring tables are loop invariant: a plain LDS load would be
+  // hoisted out of the node loops and pinned in VGPRs, which is what they are
+  // in LDS to avoid.  Each loop iteration therefore re-derives its base pointer
+  // from a byte offset laundered through an empty asm (an integer, so that the
+  // compiler still sees an LDS address and emits ds_read, not flat loads).
+  const unsigned wave_off = (unsigned)(wib * P.wave_lds_bytes);
+#define SHP_LDS() ((double*)(smem_raw + launder_u32(wave_off)))
+  double* lw = SHP_LDS();
 
   const int i = P.pair_i[w];
   const int j = P.pair_j[w];
@@ -158,32 +368,36 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock, SHP_MIN_WAVES) pair_conta
     quat_to_mat(P.quat[4 * i], P.quat[4 * i + 1], P.quat[4 * i + 2], P.quat[4 * i + 3], Rmi);
     quat_to_mat(P.quat[4 * j], P.quat[4 * j + 1], P.quat[4 * j + 2], P.quat[4 * j + 3], Rmj);
 
-    // the cap frame in both body frames (b?1 = R^T e1, b?2 = R^T e2, b?c = R^T c), d in j's frame
+    // the cap axes in i's body frame (columns of M) and in j's body frame, d in j's frame
+    double b1[3], b2[3], bc[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      b1[a] = Rmi[a] * e10 + Rmi[3 + a] * e11 + Rmi[6 + a] * e12;
+      b2[a] = Rmi[a] * e20 + Rmi[3 + a] * e21 + Rmi[6 + a] * e22;
+      bc[a] = Rmi[a] * c0 + Rmi[3 + a] * c1 + Rmi[6 + a] * c2;
+    }
     if (lane == 0) {
 #pragma unroll
       for (int a = 0; a < 3; ++a) {
-        lds.frame[FR_BI1 + a] = Rmi[a] * e10 + Rmi[3 + a] * e11 + Rmi[6 + a] * e12;
-        lds.frame[FR_BI2 + a] = Rmi[a] * e20 + Rmi[3 + a] * e21 + Rmi[6 + a] * e22;
-        lds.frame[FR_BIC + a] = Rmi[a] * c0 + Rmi[3 + a] * c1 + Rmi[6 + a] * c2;
-        lds.frame[FR_BJ1 + a] = Rmj[a] * e10 + Rmj[3 + a] * e11 + Rmj[6 + a] * e12;
-        lds.frame[FR_BJ2 + a] = Rmj[a] * e20 + Rmj[3 + a] * e21 + Rmj[6 + a] * e22;
-        lds.frame[FR_BJC + a] = Rmj[a] * c0 + Rmj[3 + a] * c1 + Rmj[6 + a] * c2;
-        lds.frame[FR_DJ + a] = Rmj[a] * d0 + Rmj[3 + a] * d1 + Rmj[6 + a] * d2;
+        lw[FR_BJ1 + a] = Rmj[a] * e10 + Rmj[3 + a] * e11 + Rmj[6 + a] * e12;
+        lw[FR_BJ2 + a] = Rmj[a] * e20 + Rmj[3 + a] * e21 + Rmj[6 + a] * e22;
+        lw[FR_BJC + a] = Rmj[a] * c0 + Rmj[3 + a] * c1 + Rmj[6 + a] * c2;
+        lw[FR_DJ + a] = Rmj[a] * d0 + Rmj[3 + a] * d1 + Rmj[6 + a] * d2;
       }
-#pragma unroll
-      for (int a = 0; a < 9; ++a) lds.frame[FR_RMI + a] = Rmi[a];
-      lds.frame[FR_D] = d0; lds.frame[FR_D + 1] = d1; lds.frame[FR_D + 2] = d2;
+      lw[FR_E1] = e10; lw[FR_E1 + 1] = e11; lw[FR_E1 + 2] = e12;
+      lw[FR_E2] = e20; lw[FR_E2 + 1] = e21; lw[FR_E2 + 2] = e22;
+      lw[FR_C] = c0; lw[FR_C + 1] = c1; lw[FR_C + 2] = c2;
+      lw[FR_D] = d0; lw[FR_D + 1] = d1; lw[FR_D + 2] = d2;
     }
+    const double hw0 = 0.5 * (1.0 - cosa), hm0 = 0.5 * (1.0 + cosa);
+    cap_frame_tables<L>(P, lw, W, LL, si, lane, b1, b2, bc, hw0, hm0);
   }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
   const double* rc = P.rc;
-  const double* cwi = P.coef + (size_t)si * P.cstride;
   const double* cwj = P.coef + (size_t)sj * P.cstride;
   const int lrt = P.lmax;
   const double Rj2 = Rj * Rj;
+  const double* fr = SHP_LDS();
 
   // SPEC §2.6: centre of i inside j (only possible when rho < Rj)
   bool centre_inside = false;
@@ -194,15 +408,15 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock, SHP_MIN_WAVES) pair_conta
     centre_inside = (rho - rj <= 0.0);
   }
 
-  const int nq = P.nq;
   const int npsi = 2 * nq;
   const int Q = nq * npsi;
   // p / npsi for 0 <= p < Q <= 2^15 as a multiply-shift: exact because
   // magic * npsi - 2^24 < npsi <= 256 < 2^24 / 2^15
   const unsigned magic = ((1u << 24) + (unsigned)npsi - 1u) / (unsigned)npsi;
   const int nslabs = (Q + 63) >> 6;
-  const double hw = 0.5 * (1.0 - cosa), hm = 0.5 * (1.0 + cosa);
+  const double hw = 0.5 * (1.0 - cosa);
   const double dpsi = 6.283185307179586476925286766559 / (double)npsi;
+  const int rowlen = 4 * (LL + 1);
 
   double aV = 0.0, aS0 = 0.0, aS1 = 0.0, aS2 = 0.0, aT0 = 0.0, aT1 = 0.0, aT2 = 0.0;
   int qhead = 0, qcount = 0, slab = 0;  // wave-uniform
@@ -211,22 +425,19 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock, SHP_MIN_WAVES) pair_conta
     // ---------------------------------------------------------------- phase 1
     // classify slabs of 64 cap nodes until 64 inside nodes are queued
     while (qcount < 64 && slab < nslabs) {
-      fr = SHP_FRAME();
+      fr = SHP_LDS();
       const int p = (slab << 6) + lane;
       ++slab;
       const bool valid = p < Q;
       const int k = valid ? (int)(((unsigned)p * magic) >> 24) : 0;
       const int l = valid ? p - k * npsi : 0;
-      const double mu = fma(hw, P.glt[k], hm);
-      const double sig = sqrt(fmax(0.0, fma(-mu, mu, 1.0)));
-      const double a1 = sig * P.cpsi[l], a2 = sig * P.spsi[l];
-      // node direction in i's body frame and r_i there
-      const double ui0 = fma(a1, fr[FR_BI1], fma(a2, fr[FR_BI2], mu * fr[FR_BIC]));
-      const double ui1 = fma(a1, fr[FR_BI1 + 1], fma(a2, fr[FR_BI2 + 1], mu * fr[FR_BIC + 1]));
-      const double ui2 = fma(a1, fr[FR_BI1 + 2], fma(a2, fr[FR_BI2 + 2], mu * fr[FR_BIC + 2]));
+      const double* row = fr + W.ring + k * rowlen;
+      const double mu = row[1], sig = row[3];
+      const double c1 = P.cpsi[l], s1 = P.spsi[l];
       double ri, t0, t1, t2;
-      sh_eval<L, false>(rc, cwi, lrt, ui0, ui1, ui2, ri, t0, t1, t2);
+      ring_eval<L, false>(row, LL, c1, s1, ri, t0, t1);
       // the surface point seen from x_j, in j's body frame
+      const double a1 = sig * c1, a2 = sig * s1;
       const double uj0 = fma(a1, fr[FR_BJ1], fma(a2, fr[FR_BJ2], mu * fr[FR_BJC]));
       const double uj1 = fma(a1, fr[FR_BJ1 + 1], fma(a2, fr[FR_BJ2 + 1], mu * fr[FR_BJC + 1]));
       const double uj2 = fma(a1, fr[FR_BJ1 + 2], fma(a2, fr[FR_BJ2 + 2], mu * fr[FR_BJC + 2]));
@@ -247,7 +458,7 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock, SHP_MIN_WAVES) pair_conta
       sh_eval<L, false>(rc, cwj, lrt, szero ? 0.0 : q0 * inv, szero ? 0.0 : q1 * inv, szero ? 1.0 : q2 * inv, rj0,
                         t0, t1, t2);
       if (szero) rj0 = Rj;
-      // s < r_j  <=>  s2 < r_j^2 (both non-negative); SPEC: inside iff s < r_j, s == 0 is inside
+      // SPEC: inside iff s < r_j (s == 0 is inside); s = s2 / sqrt(s2)
       const bool inside = cand && (szero || s2 * inv < rj0);
       const unsigned long long m = __ballot(inside);
 #ifdef SHP_STATS
@@ -257,9 +468,10 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock, SHP_MIN_WAVES) pair_conta
       if (inside) {
         const int pos = (qhead + qcount + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32),
                                                  __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u))) & (kQueue - 1);
-        lds.qp[pos] = p;
-        lds.qri[pos] = ri;
-        lds.qrj[pos] = rj0;
+        double* lq = (double*)fr;
+        ((int*)(lq + W.qp))[pos] = p;
+        lq[W.qri + pos] = ri;
+        lq[W.qrj + pos] = rj0;
       }
       qcount += __builtin_popcountll(m);
     }
@@ -267,10 +479,8 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock, SHP_MIN_WAVES) pair_conta
 
     // ---------------------------------------------------------------- phase 2
     // up to 64 queued inside nodes, one per lane: inner radius, then gradient
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    fr = SHP_FRAME();
+    wave_lds_sync();
+    fr = SHP_LDS();
     const int cnt = qcount < 64 ? qcount : 64;
     const bool active = lane < cnt;
     const int e = (qhead + (active ? lane : 0)) & (kQueue - 1);
@@ -280,19 +490,24 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock, SHP_MIN_WAVES) pair_conta
     if (lane == 0) atomicAdd(&P.dbg[4], 1ULL);
     if (active) atomicAdd(&P.dbg[7], 1ULL);
 #endif
-    const int p = lds.qp[e];
-    const double ri = lds.qri[e];
+    const int p = ((const int*)(fr + W.qp))[e];
+    const double ri = fr[W.qri + e];
     const int k = (int)(((unsigned)p * magic) >> 24);
     const int l = p - k * npsi;
-    const double mu = fma(hw, P.glt[k], hm);
-    const double sig = sqrt(fmax(0.0, fma(-mu, mu, 1.0)));
     const double omi = active ? hw * P.glw[k] * dpsi : 0.0;
-    const double a1 = sig * P.cpsi[l], a2 = sig * P.spsi[l];
+    const double c1 = P.cpsi[l], s1 = P.spsi[l];
+    double mu, sig;
+    {
+      const double* row = fr + W.ring + k * rowlen;
+      mu = row[1];
+      sig = row[3];
+    }
 
     double rin = 0.0;
     if (NEEDV) {
-      // SPEC §2.6 inner radius by safeguarded secant, all lanes in lock step
-      const double rj0 = lds.qrj[e];
+      // SPEC §2.6 inner radius, all lanes in lock step
+      const double rj0 = fr[W.qrj + e];
+      const double a1 = sig * c1, a2 = sig * s1;
       const double uj0 = fma(a1, fr[FR_BJ1], fma(a2, fr[FR_BJ2], mu * fr[FR_BJC]));
       const double uj1 = fma(a1, fr[FR_BJ1 + 1], fma(a2, fr[FR_BJ2 + 1], mu * fr[FR_BJC + 1]));
       const double uj2 = fma(a1, fr[FR_BJ1 + 2], fma(a2, fr[FR_BJ2 + 2], mu * fr[FR_BJC + 2]));
@@ -312,7 +527,7 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock, SHP_MIN_WAVES) pair_conta
       if (!act) lam = ri;
       for (int it = 0; it < 60; ++it) {
         if (!__any(act)) break;
-        fr = SHP_FRAME();
+        fr = SHP_LDS();
 #ifdef SHP_STATS
         if (lane == 0) atomicAdd(&P.dbg[5], 1ULL);
         if (act) atomicAdd(&P.dbg[6], 1ULL);
@@ -357,44 +572,44 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock, SHP_MIN_WAVES) pair_conta
       aV = fma(omi * (1.0 / 3.0), ri * ri * ri - rin * rin * rin, aV);
     }
 
-    // surface gradient of i at the node (the value it recomputes is bit-identical to ri)
-    fr = SHP_FRAME();
-    const double ui0 = fma(a1, fr[FR_BI1], fma(a2, fr[FR_BI2], mu * fr[FR_BIC]));
-    const double ui1 = fma(a1, fr[FR_BI1 + 1], fma(a2, fr[FR_BI2 + 1], mu * fr[FR_BIC + 1]));
-    const double ui2 = fma(a1, fr[FR_BI1 + 2], fma(a2, fr[FR_BI2 + 2], mu * fr[FR_BIC + 2]));
-    double ri2, g0, g1, g2;
-    sh_eval<L, true>(rc, cwi, lrt, ui0, ui1, ui2, ri2, g0, g1, g2);
-    // vector area element A = r^2 u - r t, t = grad - (u.grad) u   (body frame of i)
-    const double ug = ui0 * g0 + ui1 * g1 + ui2 * g2;
-    const double rr = ri * (ri + ug);
-    const double A0 = fma(rr, ui0, -ri * g0), A1 = fma(rr, ui1, -ri * g1), A2 = fma(rr, ui2, -ri * g2);
+    // surface gradient of i at the node, in the cap frame:
+    //   A = r^2 u + r sigma r_mu gamma^ - (r / sigma) r_psi psi^,
+    //   u = (sigma c, sigma s, mu), gamma^ = (mu c, mu s, -sigma), psi^ = (-s, c, 0)
+    fr = SHP_LDS();
+    double r2, rmu, rpsi;
+    ring_eval<L, true>(fr + W.ring + k * rowlen, LL, c1, s1, r2, rmu, rpsi);
+    const double rad = ri * fma(ri, sig, rmu * sig * mu);   // r (r sigma + sigma mu r_mu): multiplies (c, s)
+    const double tan_ = ri * rpsi / sig;                   // (r / sigma) r_psi
+    const double A0 = fma(rad, c1, tan_ * s1);
+    const double A1 = fma(rad, s1, -tan_ * c1);
+    const double A2 = ri * fma(ri, mu, -(sig * sig) * rmu);
     aS0 = fma(omi, A0, aS0);
     aS1 = fma(omi, A1, aS1);
     aS2 = fma(omi, A2, aS2);
-    // (r u) x A, body frame
+    // (r u) x A, cap frame
     const double wr = omi * ri;
-    aT0 = fma(wr, ui1 * A2 - ui2 * A1, aT0);
-    aT1 = fma(wr, ui2 * A0 - ui0 * A2, aT1);
-    aT2 = fma(wr, ui0 * A1 - ui1 * A0, aT2);
+    const double u0 = sig * c1, u1 = sig * s1;
+    aT0 = fma(wr, u1 * A2 - mu * A1, aT0);
+    aT1 = fma(wr, mu * A0 - u0 * A2, aT1);
+    aT2 = fma(wr, u0 * A1 - u1 * A0, aT2);
     // the queue slots just read may be overwritten by the next phase 1
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
+    wave_lds_sync();
   }
 
   aS0 = wave_sum(aS0); aS1 = wave_sum(aS1); aS2 = wave_sum(aS2);
   aT0 = wave_sum(aT0); aT1 = wave_sum(aT1); aT2 = wave_sum(aT2);
   if (NEEDV) aV = wave_sum(aV);
   if (lane != 0) return;
-  fr = SHP_FRAME();
-#undef SHP_FRAME
+  fr = SHP_LDS();
+#undef SHP_LDS
 
-  // rotate the body-frame integrals of i to the space frame
-  const double S0 = fr[FR_RMI + 0] * aS0 + fr[FR_RMI + 1] * aS1 + fr[FR_RMI + 2] * aS2;
-  const double S1 = fr[FR_RMI + 3] * aS0 + fr[FR_RMI + 4] * aS1 + fr[FR_RMI + 5] * aS2;
-  const double S2 = fr[FR_RMI + 6] * aS0 + fr[FR_RMI + 7] * aS1 + fr[FR_RMI + 8] * aS2;
-  const double T0 = fr[FR_RMI + 0] * aT0 + fr[FR_RMI + 1] * aT1 + fr[FR_RMI + 2] * aT2;
-  const double T1 = fr[FR_RMI + 3] * aT0 + fr[FR_RMI + 4] * aT1 + fr[FR_RMI + 5] * aT2;
-  const double T2 = fr[FR_RMI + 6] * aT0 + fr[FR_RMI + 7] * aT1 + fr[FR_RMI + 8] * aT2;
+  // rotate the cap-frame integrals to the space frame: columns e1, e2, c
+  const double S0 = fr[FR_E1] * aS0 + fr[FR_E2] * aS1 + fr[FR_C] * aS2;
+  const double S1 = fr[FR_E1 + 1] * aS0 + fr[FR_E2 + 1] * aS1 + fr[FR_C + 1] * aS2;
+  const double S2 = fr[FR_E1 + 2] * aS0 + fr[FR_E2 + 2] * aS1 + fr[FR_C + 2] * aS2;
+  const double T0 = fr[FR_E1] * aT0 + fr[FR_E2] * aT1 + fr[FR_C] * aT2;
+  const double T1 = fr[FR_E1 + 1] * aT0 + fr[FR_E2 + 1] * aT1 + fr[FR_C + 1] * aT2;
+  const double T2 = fr[FR_E1 + 2] * aT0 + fr[FR_E2 + 2] * aT1 + fr[FR_C + 2] * aT2;
   const double d0 = fr[FR_D], d1 = fr[FR_D + 1], d2 = fr[FR_D + 2];
 
   if (P.pair_out) {
@@ -453,9 +668,18 @@ template <int L>
 void launch_pair_contact(const PairParams& P, bool needv, hipStream_t st)
 {
   if (P.npairs <= 0) return;
-  const dim3 grid((P.npairs + kWavesPerBlock - 1) / kWavesPerBlock), block(64 * kWavesPerBlock);
-  if (needv) hipLaunchKernelGGL((pair_contact_kernel<L, true>), grid, block, 0, st, P);
-  else hipLaunchKernelGGL((pair_contact_kernel<L, false>), grid, block, 0, st, P);
+  const int wpb = P.waves_per_block;
+  const dim3 grid((P.npairs + wpb - 1) / wpb), block(64 * wpb);
+  const size_t lds = (size_t)wpb * P.wave_lds_bytes;
+  if (needv) {
+    if (lds > 65536) (void)hipFuncSetAttribute((const void*)pair_contact_kernel<L, true>,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((pair_contact_kernel<L, true>), grid, block, lds, st, P);
+  } else {
+    if (lds > 65536) (void)hipFuncSetAttribute((const void*)pair_contact_kernel<L, false>,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((pair_contact_kernel<L, false>), grid, block, lds, st, P);
+  }
 }
 
 }  // namespace shp

@@ -87,6 +87,145 @@ void to_m_major(int L, int width, const std::vector<double>& src, std::vector<do
     }
 }
 
+void real_sh_all(int L, const double u[3], double* out)
+{
+  const double x = u[0], y = u[1], z = u[2];
+  const double s2 = std::sqrt(2.0);
+  double Cm = 1.0, Sm = 0.0;
+  for (int m = 0; m <= L; ++m) {
+    const double pmm = sh_const::pmm(m);
+    double p2 = 0.0, p1 = pmm;
+    const double sgn = (m % 2) ? -1.0 : 1.0;
+    for (int n = m; n <= L; ++n) {
+      double p;
+      if (n == m) p = pmm;
+      else {
+        const double b = (n - m >= 2) ? sh_const::beta(n, m) : 0.0;
+        p = sh_const::alpha(n, m) * z * p1 - b * p2;
+      }
+      if (m == 0) out[n * n + n] = p;
+      else {
+        out[n * n + n + m] = s2 * sgn * p * Cm;
+        out[n * n + n - m] = s2 * sgn * p * Sm;
+      }
+      if (n > m) { p2 = p1; p1 = p; }
+    }
+    const double c = Cm * x - Sm * y, s = Cm * y + Sm * x;
+    Cm = c;
+    Sm = s;
+  }
+}
+
+void real_coefficients(int L, int lmax, const double* anm, std::vector<double>& c)
+{
+  c.assign((size_t)(L + 1) * (L + 1), 0.0);
+  const double s2 = std::sqrt(2.0);
+  for (int l = 0; l <= lmax && l <= L; ++l)
+    for (int m = 0; m <= l; ++m) {
+      const int k = idx(l, m);
+      if (m == 0) c[l * l + l] = anm[2 * k];
+      else {
+        const double sg = s2 * ((m % 2) ? -1.0 : 1.0);
+        c[l * l + l + m] = sg * anm[2 * k];
+        c[l * l + l - m] = -sg * anm[2 * k + 1];
+      }
+    }
+}
+
+void build_xmats(int L, std::vector<double>& xp, std::vector<double>& xpt)
+{
+  const int nt = L + 2, np = 2 * nt;
+  std::vector<double> t, w;
+  gauss_legendre(nt, t, w);
+  size_t tot = 0;
+  for (int l = 0; l <= L; ++l) tot += (size_t)(2 * l + 1) * (2 * l + 1);
+  xp.assign(tot, 0.0);
+  xpt.assign(tot, 0.0);
+  const int NS = (L + 1) * (L + 1);
+  std::vector<double> su(NS), sv(NS);
+  for (int a = 0; a < nt; ++a) {
+    const double ct = t[a], st = std::sqrt(1.0 - ct * ct);
+    for (int b = 0; b < np; ++b) {
+      const double ph = 2.0 * (double)kPi * b / np;
+      const double u[3] = {st * std::cos(ph), st * std::sin(ph), ct};
+      const double v[3] = {u[0], -u[2], u[1]};  // Rx(+90) u
+      const double wq = w[a] * 2.0 * (double)kPi / np;
+      real_sh_all(L, u, su.data());
+      real_sh_all(L, v, sv.data());
+      size_t off = 0;
+      for (int l = 0; l <= L; ++l) {
+        const int n = 2 * l + 1;
+        for (int r = 0; r < n; ++r)
+          for (int c = 0; c < n; ++c) xp[off + (size_t)r * n + c] += wq * su[l * l + r] * sv[l * l + c];
+        off += (size_t)n * n;
+      }
+    }
+  }
+  size_t off = 0;
+  for (int l = 0; l <= L; ++l) {
+    const int n = 2 * l + 1;
+    for (int r = 0; r < n; ++r)
+      for (int c = 0; c < n; ++c) {
+        double& e = xp[off + (size_t)r * n + c];
+        if (std::fabs(e) < 1e-14) e = 0.0;  // structural zeros of the parity pattern
+        xpt[off + (size_t)c * n + r] = e;
+      }
+    off += (size_t)n * n;
+  }
+}
+
+void build_xmats_ell(int L, std::vector<double>& val, std::vector<int>& col, std::vector<int>& info)
+{
+  std::vector<double> xp, xpt;
+  build_xmats(L, xp, xpt);
+  const int ns = (L + 1) * (L + 1), W = L / 2 + 1;
+  val.assign((size_t)2 * ns * W, 0.0);
+  col.assign((size_t)2 * ns * W, 0);
+  info.assign(ns, 0);
+  for (int which = 0; which < 2; ++which) {
+    const std::vector<double>& x = which ? xpt : xp;
+    size_t off = 0;
+    for (int l = 0; l <= L; ++l) {
+      const int n = 2 * l + 1;
+      for (int r = 0; r < n; ++r) {
+        const int e = l * l + r;
+        info[e] = l | (r << 8);
+        int t = 0;
+        for (int c = 0; c < n; ++c) {
+          const double v = x[off + (size_t)r * n + c];
+          if (v == 0.0) continue;
+          if (t >= W) { t = -1; break; }
+          val[((size_t)which * ns + e) * W + t] = v;
+          col[((size_t)which * ns + e) * W + t] = l * l + c;
+          ++t;
+        }
+        if (t < 0) {  // cannot happen for Rx(90); keep the dense tail out of silent truncation
+          val.clear();
+          return;
+        }
+        for (; t < W; ++t) col[((size_t)which * ns + e) * W + t] = l * l;
+      }
+      off += (size_t)n * n;
+    }
+  }
+}
+
+void build_ring_scale(int L, std::vector<double>& g)
+{
+  g.assign((size_t)(L + 1) * (L + 1), 0.0);
+  const double s2 = std::sqrt(2.0);
+  for (int l = 0; l <= L; ++l)
+    for (int m = 0; m <= l; ++m) {
+      const double cs = sh_const::coef_scale(l, m);
+      if (m == 0) g[l * l + l] = cs;
+      else {
+        const double v = s2 * ((m % 2) ? -1.0 : 1.0) * cs;
+        g[l * l + l + m] = v;
+        g[l * l + l - m] = v;
+      }
+    }
+}
+
 double host_radius(int lmax, const double* anm, const double u[3])
 {
   // r = sum_m Re[W_m (x+iy)^m] with the plain normalised recurrence

@@ -20,6 +20,26 @@ void build_coefficients(int L, int lmax, const double* anm, const std::vector<do
 // the m-major device layout of sh_device.hpp.
 void to_m_major(int L, int width, const std::vector<double>& src, std::vector<double>& dst);
 
+// ---- cap-frame evaluation of particle i (pair_kernel.hpp, rotation step) ----
+// Real spherical harmonics S_lm, m = -l..l, index l*l + (m + l):
+//   S_l0 = Y_l0,  S_lm = sqrt2 (-1)^m Re Y_lm,  S_l,-m = sqrt2 (-1)^m Im Y_lm  (m > 0).
+// All (L+1)^2 values at unit vector u.
+void real_sh_all(int L, const double u[3], double* out);
+// Real-basis coefficients c_lm of a shape from its a_nm: r = sum c_lm S_lm.
+void real_coefficients(int L, int lmax, const double* anm, std::vector<double>& c);
+// X^l = representation of the fixed rotation Rx(+90 deg) on the real SH of order l:
+// X^l[m'][m] = integral S_lm'(u) S_lm(Rx(90) u) dOmega, by exact Gauss x trapezoid
+// quadrature.  xp: all l packed row-major, block l at offset l(4l^2-1)/3; xpt: the transposes.
+void build_xmats(int L, std::vector<double>& xp, std::vector<double>& xpt);
+// The same two matrices in ELL form for the kernel: a row of X^l has at most l/2+1
+// non-zeros (parity structure of Rx(90)), so each of the (L+1)^2 rows gets W = L/2+1
+// (value, absolute column index l^2 + c) slots, zero padded.  First X (rows 0..ns-1), then X^T.
+// info[e] = l | (m + l) << 8 for row e.
+void build_xmats_ell(int L, std::vector<double>& val, std::vector<int>& col, std::vector<int>& info);
+// g_lm: what a rotated real coefficient is multiplied with to enter the ring recurrence
+// (Q basis of sh_device.hpp): g_l0 = s_l0 Pi_0^0, g_l,+-m = sqrt2 (-1)^m s_lm Pi_m^m.
+void build_ring_scale(int L, std::vector<double>& g);
+
 // Host evaluation of r(u) straight from a_nm (setup only: bounding radii).
 double host_radius(int lmax, const double* anm, const double u[3]);
 

@@ -89,7 +89,8 @@ struct shpair_ctx {
   bool any_nonunit_exponent = false;
   int lmax = -1, cstride = 0;
 
-  DevBuf<double> d_rc, d_coef, d_rmax, d_kn, d_expo, d_quad;
+  DevBuf<double> d_rc, d_coef, d_rmax, d_kn, d_expo, d_quad, d_creal, d_xval, d_gscale;
+  DevBuf<int> d_xcol, d_xinfo;
   DevBuf<int> d_pair_i, d_pair_j;
   int npairs = 0;
   bool have_neighbors = false;
@@ -179,6 +180,7 @@ void shpair_destroy(shpair_ctx* c)
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   c->d_rc.release(); c->d_coef.release(); c->d_rmax.release(); c->d_kn.release(); c->d_expo.release();
   c->d_quad.release(); c->d_pair_i.release(); c->d_pair_j.release();
+  c->d_creal.release(); c->d_xval.release(); c->d_gscale.release(); c->d_xcol.release(); c->d_xinfo.release();
   c->d_x.release(); c->d_quat.release(); c->d_f.release(); c->d_torque.release(); c->d_ev.release();
   c->d_type.release(); c->d_shtype.release(); c->d_counters.release(); c->d_flags.release();
   if (c->h_ft) (void)hipHostFree(c->h_ft);
@@ -364,7 +366,27 @@ static int upload_tables(shpair_ctx* c)
     all.insert(all.end(), cw.begin(), cw.end());
     rmax.push_back(c->shapes[s].rmax);
   }
+  // cap-frame evaluation of particle i: real-basis coefficients, X matrices, ring scale
+  std::vector<double> creal_all, cr, xval, gs;
+  std::vector<int> xcol, xinfo;
+  for (int s = 0; s < c->nshapes; ++s) {
+    real_coefficients(L, c->shapes[s].lmax, c->shapes[s].anm.data(), cr);
+    creal_all.insert(creal_all.end(), cr.begin(), cr.end());
+  }
+  build_xmats_ell(L, xval, xcol, xinfo);
+  if (xval.empty()) CTX_FAIL(c, SHPAIR_EINVAL, "internal: X matrix row wider than lmax/2+1");
+  build_ring_scale(L, gs);
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, c->d_creal.ensure(creal_all.size()));
+  HIPCHK(c, c->d_xval.ensure(xval.size()));
+  HIPCHK(c, c->d_xcol.ensure(xcol.size()));
+  HIPCHK(c, c->d_xinfo.ensure(xinfo.size()));
+  HIPCHK(c, c->d_gscale.ensure(gs.size()));
+  HIPCHK(c, hipMemcpy(c->d_creal.p, creal_all.data(), creal_all.size() * sizeof(double), hipMemcpyHostToDevice));
+  HIPCHK(c, hipMemcpy(c->d_xval.p, xval.data(), xval.size() * sizeof(double), hipMemcpyHostToDevice));
+  HIPCHK(c, hipMemcpy(c->d_xcol.p, xcol.data(), xcol.size() * sizeof(int), hipMemcpyHostToDevice));
+  HIPCHK(c, hipMemcpy(c->d_xinfo.p, xinfo.data(), xinfo.size() * sizeof(int), hipMemcpyHostToDevice));
+  HIPCHK(c, hipMemcpy(c->d_gscale.p, gs.data(), gs.size() * sizeof(double), hipMemcpyHostToDevice));
   HIPCHK(c, c->d_rc.ensure(rc.size()));
   HIPCHK(c, c->d_coef.ensure(all.size()));
   HIPCHK(c, c->d_rmax.ensure(rmax.size()));
@@ -437,6 +459,17 @@ int shpair_compute_device(shpair_ctx* c, int nlocal, int nghost, const double* x
   const int nq = c->nq;
   P.glt = c->d_quad.p; P.glw = c->d_quad.p + nq; P.cpsi = c->d_quad.p + 2 * nq; P.spsi = c->d_quad.p + 4 * nq;
   P.nq = nq;
+  P.creal = c->d_creal.p; P.xval = c->d_xval.p; P.xcol = c->d_xcol.p; P.xinfo = c->d_xinfo.p; P.gscale = c->d_gscale.p;
+  {
+    const WaveLdsLayout wl = wave_lds_layout(c->lmax, nq);
+    int wpb = (160 * 1024) / wl.bytes;
+    if (wpb < 1)
+      CTX_FAIL(c, SHPAIR_ELMAX, "nq (%d) x (lmax+1) (%d) needs %d bytes of LDS per pair, more than a CU has", nq,
+               c->lmax + 1, wl.bytes);
+    if (wpb > kMaxWavesPerBlock) wpb = kMaxWavesPerBlock;
+    P.wave_lds_bytes = wl.bytes;
+    P.waves_per_block = wpb;
+  }
   P.ev = ev; P.pair_out = c->pair_out;
   P.flags = nullptr;
   P.dbg = c->dbg;
