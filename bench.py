@@ -37,6 +37,16 @@ def flops_per_pair(lmax, nq):
     return (60 + 6 * lmax + 9 * T) * 2 * nq * nq
 
 
+def pmc_traffic(args):
+    """HBM traffic per launch measured with rocprofv3 PMC passes for this exact workload, or None."""
+    try:
+        tab = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        key = f"{args.particles}:{args.lmax}:{args.nq}:{args.nshapes}:{args.exponent:g}"
+        return tab[key]["traffic_bytes"] if key in tab else None
+    except (OSError, ValueError, KeyError):
+        return None
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -241,10 +251,14 @@ def main():
             "verify_rel_err": verify_err,
             "roofline": {
                 "bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": None,
+                "frac": achieved_gbs / HBM_PEAK_GBS,
+                "traffic": pmc_traffic(args) if world == 1 else None,
                 "kernel": "pair_contact_kernel", "kernel_ms": kernel_ms,
                 "bytes_per_pair": BYTES_PER_PAIR, "pairs_per_launch": int(n_contact),
-                "note": "north_star asks for the HBM fraction; the kernel is FP64-VALU bound (see valu_f64)",
+                "algorithmic_bytes_per_launch": BYTES_PER_PAIR * int(n_contact),
+                "note": "north_star asks for the HBM fraction; the kernel is FP64-VALU bound (see valu_f64). "
+                        "traffic: bytes/launch from profiles/pmc_traffic.json (rocprofv3 FETCH_SIZE + WRITE_SIZE "
+                        "passes of this workload; uncalibrated access widths, see the file)",
             },
             "valu_f64": {
                 "bound": "valu_f64", "achieved": achieved_tf, "peak": F64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",

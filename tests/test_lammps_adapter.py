@@ -44,7 +44,7 @@ def write_inputs(tmp_path, case, nlocal, newton, eflag):
             for nn in range(case["lmax"] + 1):
                 for m in range(nn + 1):
                     k = nn * (nn + 1) // 2 + m
-                    fp.write(f"{nn} {m} {a2[k, 0]!r} {a2[k, 1]!r}\n")
+                    fp.write(f"{nn} {m} {float(a2[k, 0])!r} {float(a2[k, 1])!r}\n")
         shapes.append(str(p))
     return str(bedf), shapes
 
