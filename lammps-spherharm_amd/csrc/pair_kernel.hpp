@@ -81,7 +81,7 @@ struct PairParams {
 
 constexpr int kMaxWavesPerBlock = 4;
 #ifndef SHP_MIN_WAVES
-#define SHP_MIN_WAVES 4  // waves per SIMD the register allocator must leave room for (<= 128 VGPRs)
+#define SHP_MIN_WAVES 5  // waves per SIMD the register allocator must leave room for (<= 96 VGPRs); A/B: 5 beats 4 and 6
 #endif
 
 // docs/SPEC.md §2.6: residual below which the inverse-quadratic extrapolation is accepted

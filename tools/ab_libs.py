@@ -1,0 +1,61 @@
+"""A/B timing of several builds of libshpair on the bench bed, interleaved in one process.
+usage: python tools/ab_libs.py lib1.so lib2.so ... [--lmax 6 --nq 16 --expo 1.25 --rounds 5]"""
+import argparse
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "lammps-spherharm_amd"))
+import torch  # noqa: E402
+from shpair import capi, shapes, bed  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("libs", nargs="+")
+ap.add_argument("--lmax", type=int, default=6)
+ap.add_argument("--nq", type=int, default=16)
+ap.add_argument("--expo", type=float, default=1.25)
+ap.add_argument("--n", type=int, default=100000)
+ap.add_argument("--rounds", type=int, default=5)
+a = ap.parse_args()
+
+ctxs = []
+for lib in a.libs:
+    capi._LIB = None
+    capi.library_path = (lambda p: (lambda: p))(os.path.join(ROOT, "lammps-spherharm_amd", "shpair", lib))
+    ctxs.append(capi.ShPair(0))
+shape = shapes.random_shape(a.lmax, bed.SEED0 + 2)
+rmax = None
+b = None
+for sp in ctxs:
+    sp.settings(a.nq)
+    sp.set_ntypes(1, 1)
+    sp.set_shape(0, a.lmax, shape)
+    sp.coeff("*", "*", 1000.0, a.expo)
+    if rmax is None:
+        rmax = [sp.rmax(0)]
+        b = bed.make_bed(a.n, rmax, seed=bed.SEED0 + 2)
+        il, of, jl = bed.half_neighbor_list(b["x"], b["shtype"], rmax)
+    sp.set_neighbors_csr(il, of, jl)
+    sp.set_option("timing", 1)
+dev = torch.device("cuda:0")
+x = torch.from_numpy(b["x"]).to(dev)
+q = torch.from_numpy(b["quat"]).to(dev)
+ty = torch.from_numpy(b["type"]).to(dev)
+sh = torch.from_numpy(b["shtype"]).to(dev)
+f = torch.zeros(a.n, 3, dtype=torch.float64, device=dev)
+tq = torch.zeros_like(f)
+res = {lib: [] for lib in a.libs}
+for r in range(a.rounds + 1):
+    for lib, sp in zip(a.libs, ctxs):
+        f.zero_()
+        tq.zero_()
+        sp.compute_device(a.n, 0, x.data_ptr(), q.data_ptr(), ty.data_ptr(), sh.data_ptr(), f.data_ptr(),
+                          tq.data_ptr())
+        torch.cuda.synchronize()
+        if r > 0:
+            res[lib].append(sp.stats()["kernel_ms"])
+for lib in a.libs:
+    v = np.array(res[lib])
+    print(f"{lib}: median {np.median(v):.3f} ms  min {v.min():.3f}  pairs/s {jl.size / np.median(v) * 1e3:.3e}")
