@@ -157,6 +157,20 @@ __device__ __forceinline__ double rcp_nr(const double d)
   return r;
 }
 
+// V^e for the exponents the force law usually asks for (m - 1 or m a multiple of 1/4) by square
+// roots: ~25 VALU instructions instead of the ~150 of pow(); the whole wave issues them for lane 0.
+__device__ __forceinline__ double pow_quarter(const double v, const double e)
+{
+  if (e == 0.25) return sqrt(sqrt(v));
+  if (e == 0.5) return sqrt(v);
+  if (e == 0.75) { const double s = sqrt(v); return s * sqrt(s); }
+  if (e == 1.0) return v;
+  if (e == 1.25) return v * sqrt(sqrt(v));
+  if (e == 1.5) return v * sqrt(v);
+  if (e == 2.0) return v * v;
+  return pow(v, e);
+}
+
 // ---- set-up: particle i's expansion in the cap frame ------------------------
 // M = [b1 b2 bc]: the cap axes (e1, e2, c) in i's body frame, so that
 // r_cap(u') = r_body(M u').  M = Rz(alpha) Ry(beta) Rz(gamma), Ry(beta) =
@@ -626,7 +640,8 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, SHP_MIN_WAVES) pair_co
   const int ti = P.type[i], tj = P.type[j];
   const double knij = P.kn[ti * (P.ntypes + 1) + tj];
   const double mij = P.expo[ti * (P.ntypes + 1) + tj];
-  const double pn = (mij == 1.0) ? knij : knij * mij * pow(aV, mij - 1.0);
+  const double vm1 = (mij == 1.0) ? 1.0 : pow_quarter(aV, mij - 1.0);  // V^(m-1)
+  const double pn = knij * mij * vm1;
   const double F0 = -pn * S0, F1 = -pn * S1, F2 = -pn * S2;
   const double M0 = -pn * T0, M1 = -pn * T1, M2 = -pn * T2;
   atomicAdd(&P.f[3 * i], F0);
@@ -648,7 +663,7 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, SHP_MIN_WAVES) pair_co
   }
   if ((P.eflag || P.vflag) && P.ev) {
     const double share = P.newton_pair ? 1.0 : (0.5 + (j < P.nlocal ? 0.5 : 0.0));
-    if (P.eflag) atomicAdd(&P.ev[0], share * knij * pow(aV, mij));
+    if (P.eflag) atomicAdd(&P.ev[0], share * knij * (vm1 * aV));
     if (P.vflag) {
       // ev_tally_xyz with del = x_i - x_j = -d and the force on i
       atomicAdd(&P.ev[1], share * (-d0) * F0);

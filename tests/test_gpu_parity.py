@@ -356,3 +356,72 @@ def test_full_size_bed_conservation_and_linearity(oracle):
     check(fg, tg, o)
     assert abs(eg - o["eng_virial"][0]) < TOL * o["eng_virial"][0]
     sp.close()
+
+
+def test_degenerate_orientations_of_the_cap_frame(oracle):
+    """The cap-frame rotation reads Euler angles off M = [b1 b2 bc]; sin(beta) = 0 (neighbour exactly
+    along +-z of i's body frame) and its neighbourhood are separate code paths.  Lattice-like inputs
+    (identity quaternions, neighbours along the axes) hit them exactly."""
+    from shpair import ShPair, shapes
+    lmax, nq = 6, 12
+    a = shapes.random_shape(lmax, 77, amp=0.3)
+    rmax = oracle.shape_rmax(lmax, a)
+    dirs = [(0, 0, 1), (0, 0, -1), (1, 0, 0), (0, -1, 0), (1e-9, 0, 1), (0, 1e-7, -1), (1e-5, 1e-5, 1),
+            (3e-4, -2e-4, -1), (1e-3, 0, 1), (0.6, 0.0, 0.8), (-0.6, 0.0, -0.8)]
+    quats = [(1, 0, 0, 0), (0, 0, 0, 1), (0, 1, 0, 0), (np.sqrt(0.5), 0, 0, np.sqrt(0.5))]
+    x, q = [], []
+    il, of, jl = [], [0], []
+    for dvec in dirs:
+        for qi in quats:
+            d = np.array(dvec, float)
+            d *= 1.8 / np.linalg.norm(d)
+            base = np.array([10.0 * len(x), 0.0, 0.0])
+            il.append(len(x))
+            jl.append(len(x) + 1)
+            of.append(len(jl))
+            x += [base, base + d]
+            q += [qi, (0.5, 0.5, -0.5, 0.5)]
+            il.append(len(x) - 1)     # the second atom has an empty row
+            of.append(len(jl))
+    x = np.array(x)
+    q = np.array(q, float)
+    n = len(x)
+    ty = np.ones(n, np.int32)
+    sh = np.zeros(n, np.int32)
+    sp = ShPair(0)
+    sp.settings(nq)
+    sp.set_ntypes(1, 1)
+    sp.set_shape(0, lmax, a)
+    sp.coeff(1, 1, 1000.0, 1.5)
+    sp.set_neighbors_csr(il, of, jl)
+    f, tq, eng, _ = sp.compute(n, x, q, ty, sh, eflag=True)
+    K, E = coeff_tables(1, 1000.0, 1.5)
+    o = oracle.compute([(lmax, a, rmax)], K, E, nq, n, x, q, ty, sh, il, of, jl, eflag=True)
+    assert o["counts"][2] >= len(dirs) * len(quats) - 4
+    fs = np.abs(o["f"]).max()
+    assert np.abs(f - o["f"]).max() < TOL * fs
+    assert np.abs(tq - o["torque"]).max() < TOL * max(fs, np.abs(o["torque"]).max())
+    # per pair, not only per bed: every orientation class must be right
+    fo = o["f"][0::2]
+    hit = np.abs(fo).max(axis=1) > 0
+    per_pair = np.abs(f[0::2] - fo)[hit].max(axis=1) / np.abs(fo)[hit].max(axis=1)
+    assert per_pair.max() < 1e-8 and not f[0::2][~hit].any()
+    assert abs(eng - o["eng_virial"][0]) < TOL * o["eng_virial"][0]
+    sp.close()
+
+
+@pytest.mark.parametrize("lmax,nq", [(2, 1), (3, 2), (6, 64), (4, 128), (12, 64), (20, 24)])
+def test_extreme_quadrature_orders(oracle, lmax, nq):
+    """nq = 1 (two nodes per pair), ragged slabs, and table sizes that change the LDS budget / block shape."""
+    case = make_case(60, lmax, 1, seed=50 + lmax, rmax_fn=oracle.shape_rmax)
+    K, E = coeff_tables(1, 1000.0, 1.25)
+    sp = make_ctx(case, nq, K, E)
+    b = case["bed"]
+    f, tq, eng, vir = sp.compute(case["n"], b["x"], b["quat"], b["type"], b["shtype"], eflag=True, vflag=True)
+    o = oracle_compute(oracle, case, nq, K, E, eflag=True, vflag=True)
+    if np.abs(o["f"]).max() > 0:
+        check(f, tq, o)
+        assert abs(eng - o["eng_virial"][0]) < TOL * abs(o["eng_virial"][0])
+    else:
+        assert not f.any()
+    sp.close()
