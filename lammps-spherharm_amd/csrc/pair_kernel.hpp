@@ -62,6 +62,7 @@ struct PairParams {
   const int* xinfo;      // (lmax+1)^2: l | (m + l) << 8
   const double* gscale;  // (lmax+1)^2 ring-recurrence scale g_lm
   int wave_lds_bytes;    // dynamic LDS per wave (wave_lds_layout)
+  int ring_rows;         // quadrature rings whose tables are resident at a time (<= nq)
   int waves_per_block;
   // quadrature tables
   const double* glt;    // nq Gauss-Legendre nodes on [-1,1]
@@ -93,8 +94,9 @@ constexpr int kMaxWavesPerBlock = 4;
 //   frame[kFrame]        pair frame, FR_* below
 //   trig[6 (L+1)]        cos/sin of m alpha, m beta, m gamma
 //   v0[(L+1)^2], v1[..]  ping-pong coefficient vectors of the rotation
-//   ring[nq][L+1][4]     A_km, B_km, dA/dmu, dB/dmu; the two B slots of m = 0
-//                        (identically zero) carry mu_k and sigma_k
+//   ring[rows][L+1][4]   A_km, B_km, dA/dmu, dB/dmu of `rows` consecutive rings; the two B slots
+//                        of m = 0 (identically zero) carry mu_k and sigma_k.  rows = nq when that
+//                        leaves the CU enough waves, else the cap is processed in ring groups.
 //   qri[kQueue], qrj[kQueue], qp[kQueue] (int)   queue of inside nodes
 constexpr int kQueue = 128;  // entries; a slab adds <= 64 to a queue holding < 64
 constexpr int kFrame = 28;
@@ -103,7 +105,7 @@ enum { FR_BJ1 = 0, FR_BJ2 = 3, FR_BJC = 6, FR_DJ = 9, FR_E1 = 12, FR_E2 = 15, FR
 struct WaveLdsLayout {
   int trig, v0, v1, ring, qri, qrj, qp, bytes;  // offsets in doubles (qp: in doubles too), total bytes
 };
-__host__ __device__ inline WaveLdsLayout wave_lds_layout(const int L, const int nq)
+__host__ __device__ inline WaveLdsLayout wave_lds_layout(const int L, const int rows)
 {
   WaveLdsLayout w;
   const int ns = (L + 1) * (L + 1);
@@ -112,7 +114,7 @@ __host__ __device__ inline WaveLdsLayout wave_lds_layout(const int L, const int 
   w.v1 = w.v0 + ns;
   w.ring = w.v1 + ns;
   w.ring += w.ring & 1;  // 16-byte aligned rows for ds_read_b128
-  w.qri = w.ring + 4 * nq * (L + 1);
+  w.qri = w.ring + 4 * rows * (L + 1);
   w.qrj = w.qri + kQueue;
   w.qp = w.qrj + kQueue;
   w.bytes = 8 * (w.qp + kQueue / 2);
@@ -181,9 +183,9 @@ __device__ __forceinline__ double pow_quarter(const double v, const double e)
 // angles, so that the 1/sin(beta) error of alpha near the poles only moves the
 // axis of a vanishing tilt.
 template <int L>
-__device__ __forceinline__ void cap_frame_tables(const PairParams& P, double* __restrict__ lw, const WaveLdsLayout& W,
+__device__ __forceinline__ void cap_frame_rotate(const PairParams& P, double* __restrict__ lw, const WaveLdsLayout& W,
                                                  const int LL, const int si, const int lane, const double* b1,
-                                                 const double* b2, const double* bc, const double hw, const double hm)
+                                                 const double* b2, const double* bc)
 {
   const int ns = (LL + 1) * (LL + 1);
   double* trig = lw + W.trig;
@@ -255,13 +257,22 @@ __device__ __forceinline__ void cap_frame_tables(const PairParams& P, double* __
     }
     wave_lds_sync();
   }
-  // rotated, scaled coefficients are in v0.  Ring tables: one (k, m) per lane.
-  const double* ch = v0;
+  // the rotated, scaled coefficients are now in v0
+}
+
+// Ring tables of rings k0 .. k0 + nrows - 1 from the rotated coefficients: one (k, m) per lane.
+template <int L>
+__device__ __forceinline__ void cap_frame_rings(const PairParams& P, double* __restrict__ lw, const WaveLdsLayout& W,
+                                                const int LL, const int lane, const int k0, const int nrows,
+                                                const double hw, const double hm)
+{
+  const double* ch = lw + W.v0;
   double* ring = lw + W.ring;
-  const int nkm = P.nq * (LL + 1);
+  const int nkm = nrows * (LL + 1);
   for (int idx = lane; idx < nkm; idx += 64) {
-    const int k = idx / (LL + 1);
-    const int m = idx - k * (LL + 1);
+    const int kr = idx / (LL + 1);
+    const int m = idx - kr * (LL + 1);
+    const int k = k0 + kr;
     const double mu = fma(hw, P.glt[k], hm);
     const double sig2 = fmax(0.0, fma(-mu, mu, 1.0));
     const double sig = sqrt(sig2);
@@ -343,7 +354,7 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, SHP_MIN_WAVES) pair_co
   if (w >= P.npairs) return;
   const int LL = (L >= 0) ? L : P.lmax;
   const int nq = P.nq;
-  const WaveLdsLayout W = wave_lds_layout(LL, nq);
+  const WaveLdsLayout W = wave_lds_layout(LL, P.ring_rows);
   // The frame and ring tables are loop invariant: a plain LDS load would be
   // hoisted out of the node loops and pinned in VGPRs, which is what they are
   // in LDS to avoid.  Each loop iteration therefore re-derives its base pointer
@@ -403,8 +414,7 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, SHP_MIN_WAVES) pair_co
       lw[FR_C] = c0; lw[FR_C + 1] = c1; lw[FR_C + 2] = c2;
       lw[FR_D] = d0; lw[FR_D + 1] = d1; lw[FR_D + 2] = d2;
     }
-    const double hw0 = 0.5 * (1.0 - cosa), hm0 = 0.5 * (1.0 + cosa);
-    cap_frame_tables<L>(P, lw, W, LL, si, lane, b1, b2, bc, hw0, hm0);
+    cap_frame_rotate<L>(P, lw, W, LL, si, lane, b1, b2, bc);
   }
 
   const double* rc = P.rc;
@@ -428,24 +438,32 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, SHP_MIN_WAVES) pair_co
   // magic * npsi - 2^24 < npsi <= 256 < 2^24 / 2^15
   const unsigned magic = ((1u << 24) + (unsigned)npsi - 1u) / (unsigned)npsi;
   const int nslabs = (Q + 63) >> 6;
-  const double hw = 0.5 * (1.0 - cosa);
+  const double hw = 0.5 * (1.0 - cosa), hm = 0.5 * (1.0 + cosa);
   const double dpsi = 6.283185307179586476925286766559 / (double)npsi;
   const int rowlen = 4 * (LL + 1);
 
   double aV = 0.0, aS0 = 0.0, aS1 = 0.0, aS2 = 0.0, aT0 = 0.0, aT1 = 0.0, aT2 = 0.0;
   int qhead = 0, qcount = 0, slab = 0;  // wave-uniform
 
+  // Ring groups: the tables of P.ring_rows consecutive rings are resident at a time (all nq of
+  // them unless that would starve the CU of waves); the queue is drained at the end of a group.
+  while (slab < nslabs) {
+  const int k0 = (int)(((unsigned)(slab << 6) * magic) >> 24);
+  const int kend = (k0 + P.ring_rows < nq) ? k0 + P.ring_rows : nq;
+  const int slab_end = (kend == nq) ? nslabs : ((kend * npsi) >> 6);
+  cap_frame_rings<L>(P, SHP_LDS(), W, LL, lane, k0, kend - k0, hw, hm);
+
   for (;;) {
     // ---------------------------------------------------------------- phase 1
     // classify slabs of 64 cap nodes until 64 inside nodes are queued
-    while (qcount < 64 && slab < nslabs) {
+    while (qcount < 64 && slab < slab_end) {
       fr = SHP_LDS();
       const int p = (slab << 6) + lane;
       ++slab;
       const bool valid = p < Q;
       const int k = valid ? (int)(((unsigned)p * magic) >> 24) : 0;
       const int l = valid ? p - k * npsi : 0;
-      const double* row = fr + W.ring + k * rowlen;
+      const double* row = fr + W.ring + (k - k0) * rowlen;
       const double mu = row[1], sig = row[3];
       const double c1 = P.cpsi[l], s1 = P.spsi[l];
       double ri, t0, t1, t2;
@@ -512,7 +530,7 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, SHP_MIN_WAVES) pair_co
     const double c1 = P.cpsi[l], s1 = P.spsi[l];
     double mu, sig;
     {
-      const double* row = fr + W.ring + k * rowlen;
+      const double* row = fr + W.ring + (k - k0) * rowlen;
       mu = row[1];
       sig = row[3];
     }
@@ -591,7 +609,7 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, SHP_MIN_WAVES) pair_co
     //   u = (sigma c, sigma s, mu), gamma^ = (mu c, mu s, -sigma), psi^ = (-s, c, 0)
     fr = SHP_LDS();
     double r2, rmu, rpsi;
-    ring_eval<L, true>(fr + W.ring + k * rowlen, LL, c1, s1, r2, rmu, rpsi);
+    ring_eval<L, true>(fr + W.ring + (k - k0) * rowlen, LL, c1, s1, r2, rmu, rpsi);
     const double rad = ri * fma(ri, sig, rmu * sig * mu);   // r (r sigma + sigma mu r_mu): multiplies (c, s)
     const double tan_ = ri * rpsi / sig;                   // (r / sigma) r_psi
     const double A0 = fma(rad, c1, tan_ * s1);
@@ -609,6 +627,7 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, SHP_MIN_WAVES) pair_co
     // the queue slots just read may be overwritten by the next phase 1
     wave_lds_sync();
   }
+  }  // ring groups
 
   aS0 = wave_sum(aS0); aS1 = wave_sum(aS1); aS2 = wave_sum(aS2);
   aT0 = wave_sum(aT0); aT1 = wave_sum(aT1); aT2 = wave_sum(aT2);

@@ -106,7 +106,7 @@ struct shpair_ctx {
   DevBuf<unsigned char> d_flags;
   unsigned long long* h_counters = nullptr;  // pinned 2
 
-  int opt_force_volume = 0, opt_timing = 0, opt_count = 0, opt_variant = 0;
+  int opt_force_volume = 0, opt_timing = 0, opt_count = 0, opt_variant = 0, opt_ring_rows = 0;
   double* pair_out = nullptr;
   unsigned long long* dbg = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr, evA = nullptr, evB = nullptr;
@@ -461,14 +461,29 @@ int shpair_compute_device(shpair_ctx* c, int nlocal, int nghost, const double* x
   P.nq = nq;
   P.creal = c->d_creal.p; P.xval = c->d_xval.p; P.xcol = c->d_xcol.p; P.xinfo = c->d_xinfo.p; P.gscale = c->d_gscale.p;
   {
-    const WaveLdsLayout wl = wave_lds_layout(c->lmax, nq);
+    // Resident ring rows: all nq if a wave then needs <= 8 KB of LDS (five 4-wave workgroups per CU,
+    // the VGPR-limited 5 waves/SIMD), else as many as fit 8 KB, never fewer than one slab of 64 nodes
+    // spans.  Measured at lmax 12, nq 32 (tools/ab_libs.py --ring-rows): 32 or 18 rows 55 ms
+    // (2 workgroups per CU), 9 rows 38.7 ms, 4 rows 37.4 ms.
+    const int npsi = 2 * nq;
+    const int rows_min = 1 + (63 + npsi - 1) / npsi;
+    int rows = nq;
+    if (c->opt_ring_rows > 0) rows = c->opt_ring_rows;
+    else if (wave_lds_layout(c->lmax, nq).bytes > 8 * 1024) {
+      const int fixed = wave_lds_layout(c->lmax, 0).bytes;
+      rows = (8 * 1024 - fixed) / (32 * (c->lmax + 1));
+    }
+    if (rows < rows_min) rows = rows_min;
+    if (rows > nq) rows = nq;
+    const WaveLdsLayout wl = wave_lds_layout(c->lmax, rows);
     int wpb = (160 * 1024) / wl.bytes;
     if (wpb < 1)
-      CTX_FAIL(c, SHPAIR_ELMAX, "nq (%d) x (lmax+1) (%d) needs %d bytes of LDS per pair, more than a CU has", nq,
-               c->lmax + 1, wl.bytes);
+      CTX_FAIL(c, SHPAIR_ELMAX, "lmax %d with nq %d needs %d bytes of LDS per pair, more than a CU has", c->lmax, nq,
+               wl.bytes);
     if (wpb > kMaxWavesPerBlock) wpb = kMaxWavesPerBlock;
     P.wave_lds_bytes = wl.bytes;
     P.waves_per_block = wpb;
+    P.ring_rows = rows;
   }
   P.ev = ev; P.pair_out = c->pair_out;
   P.flags = nullptr;
@@ -565,6 +580,7 @@ int shpair_set_option(shpair_ctx* c, const char* key, int value)
   else if (!strcmp(key, "timing")) c->opt_timing = value ? 1 : 0;
   else if (!strcmp(key, "count")) c->opt_count = value ? 1 : 0;
   else if (!strcmp(key, "variant")) c->opt_variant = value;
+  else if (!strcmp(key, "ring_rows")) c->opt_ring_rows = value;
   else CTX_FAIL(c, SHPAIR_EINVAL, "unknown option '%s'", key);
   return SHPAIR_OK;
 }

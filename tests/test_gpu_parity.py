@@ -425,3 +425,21 @@ def test_extreme_quadrature_orders(oracle, lmax, nq):
     else:
         assert not f.any()
     sp.close()
+
+
+@pytest.mark.parametrize("lmax,nq,rows", [(6, 16, 3), (6, 16, 5), (4, 10, 5), (12, 32, 2), (12, 32, 9), (8, 7, 6)])
+def test_ring_groups_do_not_change_the_result(oracle, lmax, nq, rows):
+    """Large (lmax, nq) process the cap in groups of LDS-resident rings; forcing small groups on
+    small problems must reproduce the oracle (and the single-group result) exactly as well."""
+    case = make_case(120, lmax, 2, seed=60 + lmax, rmax_fn=oracle.shape_rmax)
+    K, E = coeff_tables(1, 1000.0, 1.25)
+    sp = make_ctx(case, nq, K, E)
+    b = case["bed"]
+    f0, t0, e0, _ = sp.compute(case["n"], b["x"], b["quat"], b["type"], b["shtype"], eflag=True)
+    sp.set_option("ring_rows", rows)
+    f1, t1, e1, _ = sp.compute(case["n"], b["x"], b["quat"], b["type"], b["shtype"], eflag=True)
+    o = oracle_compute(oracle, case, nq, K, E, eflag=True)
+    check(f1, t1, o)
+    fs = np.abs(f0).max()
+    assert np.abs(f1 - f0).max() < 1e-12 * fs and abs(e1 - e0) < 1e-12 * abs(e0)
+    sp.close()

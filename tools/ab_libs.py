@@ -18,6 +18,7 @@ ap.add_argument("--nq", type=int, default=16)
 ap.add_argument("--expo", type=float, default=1.25)
 ap.add_argument("--n", type=int, default=100000)
 ap.add_argument("--rounds", type=int, default=5)
+ap.add_argument("--ring-rows", type=int, nargs="*", default=[0], help="one value per lib (0 = library default)")
 a = ap.parse_args()
 
 ctxs = []
@@ -28,7 +29,9 @@ for lib in a.libs:
 shape = shapes.random_shape(a.lmax, bed.SEED0 + 2)
 rmax = None
 b = None
-for sp in ctxs:
+rr = (a.ring_rows * len(ctxs))[:len(ctxs)] if len(a.ring_rows) == 1 else a.ring_rows
+for sp, rows in zip(ctxs, rr):
+    sp.set_option("ring_rows", rows)
     sp.settings(a.nq)
     sp.set_ntypes(1, 1)
     sp.set_shape(0, a.lmax, shape)
@@ -46,6 +49,7 @@ ty = torch.from_numpy(b["type"]).to(dev)
 sh = torch.from_numpy(b["shtype"]).to(dev)
 f = torch.zeros(a.n, 3, dtype=torch.float64, device=dev)
 tq = torch.zeros_like(f)
+a.libs = [f"{lib}#{rows}" for lib, rows in zip(a.libs, rr)]
 res = {lib: [] for lib in a.libs}
 for r in range(a.rounds + 1):
     for lib, sp in zip(a.libs, ctxs):
@@ -56,6 +60,6 @@ for r in range(a.rounds + 1):
         torch.cuda.synchronize()
         if r > 0:
             res[lib].append(sp.stats()["kernel_ms"])
-for lib in a.libs:
+for lib in dict.fromkeys(a.libs):
     v = np.array(res[lib])
     print(f"{lib}: median {np.median(v):.3f} ms  min {v.min():.3f}  pairs/s {jl.size / np.median(v) * 1e3:.3e}")
