@@ -426,9 +426,8 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, SHP_MIN_WAVES) pair_co
   // SPEC §2.6: centre of i inside j (only possible when rho < Rj)
   bool centre_inside = false;
   if (NEEDV && rho < Rj) {
-    double rj, t0, t1, t2;
     const double ir = 1.0 / rho;
-    sh_eval<L, false>(rc, cwj, lrt, -fr[FR_DJ] * ir, -fr[FR_DJ + 1] * ir, -fr[FR_DJ + 2] * ir, rj, t0, t1, t2);
+    const double rj = sh_eval<L>(rc, cwj, lrt, -fr[FR_DJ] * ir, -fr[FR_DJ + 1] * ir, -fr[FR_DJ + 2] * ir);
     centre_inside = (rho - rj <= 0.0);
   }
 
@@ -466,7 +465,7 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, SHP_MIN_WAVES) pair_co
       const double* row = fr + W.ring + (k - k0) * rowlen;
       const double mu = row[1], sig = row[3];
       const double c1 = P.cpsi[l], s1 = P.spsi[l];
-      double ri, t0, t1, t2;
+      double ri, t0, t1;
       ring_eval<L, false>(row, LL, c1, s1, ri, t0, t1);
       // the surface point seen from x_j, in j's body frame
       const double a1 = sig * c1, a2 = sig * s1;
@@ -486,9 +485,7 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, SHP_MIN_WAVES) pair_co
 
       const bool szero = !(s2 > 0.0);
       const double inv = szero ? 0.0 : rsqrt_nr(s2);
-      double rj0;
-      sh_eval<L, false>(rc, cwj, lrt, szero ? 0.0 : q0 * inv, szero ? 0.0 : q1 * inv, szero ? 1.0 : q2 * inv, rj0,
-                        t0, t1, t2);
+      double rj0 = sh_eval<L>(rc, cwj, lrt, szero ? 0.0 : q0 * inv, szero ? 0.0 : q1 * inv, szero ? 1.0 : q2 * inv);
       if (szero) rj0 = Rj;
       // SPEC: inside iff s < r_j (s == 0 is inside); s = s2 / sqrt(s2)
       const bool inside = cand && (szero || s2 * inv < rj0);
@@ -569,8 +566,7 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, SHP_MIN_WAVES) pair_co
         const double ss2 = y0 * y0 + y1 * y1 + y2 * y2;
         const bool z0 = !(ss2 > 0.0);
         const double iv = z0 ? 0.0 : rsqrt_nr(ss2);
-        double rj, t0, t1, t2;
-        sh_eval<L, false>(rc, cwj, lrt, z0 ? 0.0 : y0 * iv, z0 ? 0.0 : y1 * iv, z0 ? 1.0 : y2 * iv, rj, t0, t1, t2);
+        const double rj = sh_eval<L>(rc, cwj, lrt, z0 ? 0.0 : y0 * iv, z0 ? 0.0 : y1 * iv, z0 ? 1.0 : y2 * iv);
         const double gl = z0 ? -Rj : ss2 * iv - rj;
         if (act) {
           if (gl >= 0.0) lo = lam; else hi = lam;

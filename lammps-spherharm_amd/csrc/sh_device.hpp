@@ -1,5 +1,8 @@
 // sh_device.hpp — device-side spherical-harmonic radius evaluation for gfx950.
 //
+// Used for particle j (whose evaluation points have no ring structure; particle
+// i is evaluated from the ring tables of pair_kernel.hpp).
+//
 // docs/SPEC.md §1 in the angle-free polynomial form: for a unit vector (x,y,z)
 //   r = sum_m Re[ W_m(z) (x+iy)^m ],  W_m(z) = sum_n Q_n^m(z) cw_nm
 // with the z-polynomials Q_n^m from a two-term recurrence rescaled so that the
@@ -9,10 +12,10 @@
 //
 // Where the operands live (one wavefront per pair, so all of them are
 // wave-uniform):
-//  * recurrence constants a', a1, Pi_m^m: shape independent, so for the
-//    compiled orders they are C++ constant expressions (sh_const.hpp) that the
-//    compiler materialises with s_mov_b32 on the scalar unit — no memory, no
-//    VGPR, no LDS.  The run-time-order kernel reads them from the rc table.
+//  * recurrence constants a': shape independent, so for the compiled orders
+//    they are C++ constant expressions (sh_const.hpp) that are materialised
+//    with s_mov_b32 on the scalar unit — no memory, no VGPR, no LDS.  The
+//    run-time-order kernel reads them from the rc table.
 //  * shape coefficients cw: scalar loads (s_load_dwordx16) through the scalar
 //    data cache into SGPRs, four complex terms at a time, software pipelined.
 //
@@ -32,8 +35,7 @@ namespace shp {
 // Makes a wave-uniform pointer opaque to the optimiser. The tables are loop
 // invariant, so without this LICM hoists every scalar load out of the node
 // loop and the register allocator spills ~170 SGPR pairs into VGPR lanes
-// (v_writelane/v_readlane, 256+ VGPRs, 1 wave/SIMD). Laundered per m-block,
-// the loads stay next to their use and live only for that block.
+// (v_writelane/v_readlane, 256+ VGPRs, 1 wave/SIMD).
 // The result is typed as a constant-address-space (AS4) pointer: after the asm
 // the compiler no longer knows the pointer is global, and a generic pointer
 // would be read with per-lane flat_load into VGPRs instead of s_load.
@@ -43,11 +45,6 @@ __device__ __forceinline__ cdptr launder_uniform(const double* p)
   asm volatile("" : "+s"(p));
   return (cdptr)p;
 }
-
-struct ShAcc {
-  double Wr, Wi, Zr, Zi;   // W_m and dW_m/dz
-  double p1, p2, d1, d2;   // Q_{n-1}, Q_{n-2} and their z-derivatives
-};
 
 // A compile-time double as an SGPR pair, materialised by two s_mov_b32 on the
 // scalar unit at the point of use.  `volatile` keeps LICM from hoisting the
@@ -67,31 +64,30 @@ __device__ __forceinline__ double sgpr_const_bits()
 // Shape coefficients travel in chunks of 4 complex terms = one s_load_dwordx16
 // through the scalar data cache.  The load is an ordinary AS4 load (so the
 // compiler tracks it with a counted s_waitcnt and may keep it in flight), taken
-// through a laundered pointer (so it cannot be hoisted out of the node loop).
+// through the evaluation's laundered table pointer (so it cannot be hoisted out
+// of the node loop, while the chunk offset still folds into the instruction).
 // Chunks are software pipelined: chunk k+1 is requested before the terms of
 // chunk k are computed, across m-block boundaries as well, and a
 // sched_barrier after every chunk keeps the request where it was written.
 // A chunk may run past the end of its m-block (it then holds the head of the
 // next block, unused) and the last one past the end of the shape's table,
 // which the host pads (sh_chunk_stride()).
-#ifndef SHP_CHUNK
-#define SHP_CHUNK 4  // complex terms per scalar load: 4 = s_load_dwordx16, 2 = s_load_dwordx8
-#endif
-constexpr int kChunk = SHP_CHUNK;
-typedef double sh_d8 __attribute__((ext_vector_type(2 * SHP_CHUNK)));
+constexpr int kChunk = 4;  // complex terms per scalar load
+typedef double sh_d8 __attribute__((ext_vector_type(2 * kChunk)));
 typedef sh_d8 sh_d8_u __attribute__((aligned(8)));
 typedef const sh_d8_u __attribute__((address_space(4))) * cd8ptr;
-// `base` is the evaluation's laundered table pointer (launder_uniform), so the
-// chunk offset folds into the s_load immediate; a pointer laundered per chunk
-// makes the compiler precompute every chunk address outside the node loop and
-// carry them through spilled SGPR pairs.
 __device__ __forceinline__ sh_d8 sload_chunk(const cdptr base, const int off)
 {
   return *(cd8ptr)(base + off);
 }
 
+struct ShAcc {
+  double Wr, Wi;   // W_m
+  double p1, p2;   // Q_{n-1}, Q_{n-2}
+};
+
 // One (n, m) term with its coefficient (cr, ci) already in SGPRs.
-template <int L, int M, int N, bool GRAD>
+template <int L, int M, int N>
 __device__ __forceinline__ void sh_term(const double cr, const double ci, const double z, ShAcc& s)
 {
   if constexpr (N > L) {
@@ -99,87 +95,56 @@ __device__ __forceinline__ void sh_term(const double cr, const double ci, const 
   } else if constexpr (N == M) {
     s.Wr = cr;   // Q_m = 1
     s.Wi = (M > 0) ? ci : 0.0;
-    s.Zr = 0.0;
-    s.Zi = 0.0;
-    s.p1 = 0.0; s.p2 = 0.0; s.d1 = 0.0; s.d2 = 0.0;
+    s.p1 = 0.0;
+    s.p2 = 0.0;
   } else if constexpr (N == M + 1) {
     const double a1 = SHP_SGPR_CONST(sh_const::aprime(M + 1, M));
     s.p2 = 1.0;   // Q_m, an inline constant
     s.p1 = a1 * z;
-    s.d2 = 0.0;
-    s.d1 = a1;
     s.Wr = fma(cr, s.p1, s.Wr);
     if constexpr (M > 0) s.Wi = fma(ci, s.p1, s.Wi);
-    if constexpr (GRAD) {
-      s.Zr = cr * s.d1;
-      if constexpr (M > 0) s.Zi = ci * s.d1;
-    }
   } else {
     const double a = SHP_SGPR_CONST(sh_const::aprime(N, M));
     const double p = fma(a, z * s.p1, -s.p2);
     s.Wr = fma(cr, p, s.Wr);
     if constexpr (M > 0) s.Wi = fma(ci, p, s.Wi);
-    if constexpr (GRAD) {
-      const double e = fma(z, s.d1, s.p1);
-      const double dp = (N == M + 2) ? a * e : fma(a, e, -s.d2);
-      s.Zr = fma(cr, dp, s.Zr);
-      if constexpr (M > 0) s.Zi = fma(ci, dp, s.Zi);
-      s.d2 = s.d1;
-      s.d1 = dp;
-    }
     s.p2 = s.p1;
     s.p1 = p;
   }
 }
 
 struct ShState {
-  double Cm, Sm, Cp, Sp;   // E_m and E_{m-1}
-  double r, gx, gy, gz;
+  double Cm, Sm;   // E_m = (x + i y)^m
+  double r;
   ShAcc a;
 };
 
-// Block m is complete: fold W_m, W_m' into r and the gradient, advance E_m.
-template <int L, int M, bool GRAD>
+// Block m is complete: fold W_m into r, advance E_m.
+template <int L, int M>
 __device__ __forceinline__ void sh_block_end(const double x, const double y, ShState& t)
 {
   const ShAcc& s = t.a;
   if constexpr (M == 0) {
     t.r = s.Wr;
-    if constexpr (GRAD) t.gz = s.Zr;
   } else {
     t.r = fma(s.Wr, t.Cm, t.r);
     t.r = fma(-s.Wi, t.Sm, t.r);
-    if constexpr (GRAD) {
-      t.gz = fma(s.Zr, t.Cm, t.gz);
-      t.gz = fma(-s.Zi, t.Sm, t.gz);
-      if constexpr (M == 1) {
-        t.gx += s.Wr;
-        t.gy -= s.Wi;
-      } else {
-        const double tr = (double)M * s.Wr, ti = (double)M * s.Wi;
-        t.gx = fma(tr, t.Cp, t.gx);
-        t.gx = fma(-ti, t.Sp, t.gx);
-        t.gy = fma(-tr, t.Sp, t.gy);
-        t.gy = fma(-ti, t.Cp, t.gy);
-      }
-    }
   }
   if constexpr (M < L) {  // E_{m+1} = E_m (x + i y)
     if constexpr (M == 0) {
       t.Cm = x;
       t.Sm = y;
     } else {
-      t.Cp = t.Cm;
-      t.Sp = t.Sm;
-      t.Cm = fma(t.Cp, x, -(t.Sp * y));
-      t.Sm = fma(t.Cp, y, t.Sp * x);
+      const double c = fma(t.Cm, x, -(t.Sm * y));
+      t.Sm = fma(t.Cm, y, t.Sm * x);
+      t.Cm = c;
     }
   }
 }
 
 // The chunk that starts at term (N0, M), its coefficients already requested in
 // `cur`; requests its successor, computes its terms, recurses.
-template <int L, int M, int N0, bool GRAD>
+template <int L, int M, int N0>
 struct ShStep {
   static __device__ __forceinline__ void run(const cdptr cw_in, const sh_d8 cur, const double x, const double y,
                                              const double z, ShState& t)
@@ -190,113 +155,74 @@ struct ShStep {
     constexpr int Nn = block_done ? M + 1 : N0 + kChunk;
     sh_d8 nxt = cur;
     if constexpr (has_next) nxt = sload_chunk(cw_in, 2 * sh_index(L, Nn, Mn));
-    sh_term<L, M, N0, GRAD>(cur[0], cur[1], z, t.a);
-    sh_term<L, M, N0 + 1, GRAD>(cur[2], cur[3], z, t.a);
-    if constexpr (kChunk == 4) {
-      sh_term<L, M, N0 + 2, GRAD>(cur[4], cur[5], z, t.a);
-      sh_term<L, M, N0 + 3, GRAD>(cur[6], cur[7], z, t.a);
-    }
-    if constexpr (block_done) sh_block_end<L, M, GRAD>(x, y, t);
+    sh_term<L, M, N0>(cur[0], cur[1], z, t.a);
+    sh_term<L, M, N0 + 1>(cur[2], cur[3], z, t.a);
+    sh_term<L, M, N0 + 2>(cur[4], cur[5], z, t.a);
+    sh_term<L, M, N0 + 3>(cur[6], cur[7], z, t.a);
+    if constexpr (block_done) sh_block_end<L, M>(x, y, t);
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr (has_next) ShStep<L, Mn, Nn, GRAD>::run(cw_in, nxt, x, y, z, t);
+    if constexpr (has_next) ShStep<L, Mn, Nn>::run(cw_in, nxt, x, y, z, t);
   }
 };
 
 // ---- run-time order (L < 0): plain loops over the rc / cw tables.
-template <bool GRAD>
-__device__ __forceinline__ void sh_eval_rt(const double* rc_in, const double* cw_in, const int LL, const double x,
-                                           const double y, const double z, double& r, double& gx, double& gy,
-                                           double& gz)
+__device__ __forceinline__ double sh_eval_rt(const double* rc_in, const double* cw_in, const int LL, const double x,
+                                             const double y, const double z)
 {
-  double Cm = 1.0, Sm = 0.0, Cp = 1.0, Sp = 0.0;
+  double Cm = 1.0, Sm = 0.0, r = 0.0;
   for (int m = 0; m <= LL; ++m) {
     const int o = sh_moff(LL, m);
     const cdptr rc = launder_uniform(rc_in + o);
     const cdptr cw = launder_uniform(cw_in + 2 * o);
     double Wr = cw[0], Wi = cw[1];
-    double Zr = 0.0, Zi = 0.0;
     if (m + 1 <= LL) {
-      const double a1 = rc[1];
-      double p2 = rc[0];
-      double p1 = a1 * z;
-      double d2 = 0.0, d1 = a1;
+      double p2 = 1.0;
+      double p1 = rc[1] * z;
       Wr = fma(cw[2], p1, Wr);
       Wi = fma(cw[3], p1, Wi);
-      if (GRAD) {
-        Zr = cw[2] * a1;
-        Zi = cw[3] * a1;
-      }
       for (int n = m + 2; n <= LL; ++n) {
         const int k = n - m;
-        const double a = rc[k];
-        const double p = fma(a, z * p1, -p2);
+        const double p = fma(rc[k], z * p1, -p2);
         Wr = fma(cw[2 * k], p, Wr);
         Wi = fma(cw[2 * k + 1], p, Wi);
-        if (GRAD) {
-          const double e = fma(z, d1, p1);
-          const double dp = fma(a, e, -d2);
-          Zr = fma(cw[2 * k], dp, Zr);
-          Zi = fma(cw[2 * k + 1], dp, Zi);
-          d2 = d1;
-          d1 = dp;
-        }
         p2 = p1;
         p1 = p;
       }
     }
     r = fma(Wr, Cm, r);
     r = fma(-Wi, Sm, r);
-    if (GRAD) {
-      gz = fma(Zr, Cm, gz);
-      gz = fma(-Zi, Sm, gz);
-      if (m > 0) {
-        const double tr = (double)m * Wr, ti = (double)m * Wi;
-        gx = fma(tr, Cp, gx);
-        gx = fma(-ti, Sp, gx);
-        gy = fma(-tr, Sp, gy);
-        gy = fma(-ti, Cp, gy);
-      }
-    }
-    if (m > 0) {
-      Cp = Cm;
-      Sp = Sm;
-    }
     const double c = fma(Cm, x, -(Sm * y)), sn = fma(Cm, y, Sm * x);
     Cm = c;
     Sm = sn;
   }
+  return r;
 }
 
-// r (and, if GRAD, the Cartesian gradient of the polynomial F) at unit (x,y,z).
-// L >= 0: compile-time order, fully unrolled. L < 0: run-time order lrt.
-template <int L, bool GRAD>
-__device__ __forceinline__ void sh_eval(const double* rc_in, const double* cw_in, const int lrt, const double x,
-                                        const double y, const double z, double& r, double& gx, double& gy,
-                                        double& gz)
+// r at unit (x,y,z).  L >= 0: compile-time order, fully unrolled.  L < 0: run-time order lrt.
+template <int L>
+__device__ __forceinline__ double sh_eval(const double* rc_in, const double* cw_in, const int lrt, const double x,
+                                          const double y, const double z)
 {
-  r = 0.0;
-  gx = 0.0;
-  gy = 0.0;
-  gz = 0.0;
+  double r;
   if constexpr (L >= 0) {
     ShState t;
-    t.Cm = 1.0; t.Sm = 0.0; t.Cp = 1.0; t.Sp = 0.0;
-    t.r = 0.0; t.gx = 0.0; t.gy = 0.0; t.gz = 0.0;
+    t.Cm = 1.0;
+    t.Sm = 0.0;
+    t.r = 0.0;
     const cdptr cwl = launder_uniform(cw_in);
     const sh_d8 first = sload_chunk(cwl, 0);
     __builtin_amdgcn_sched_barrier(0);
-    ShStep<L, 0, 0, GRAD>::run(cwl, first, x, y, z, t);
+    ShStep<L, 0, 0>::run(cwl, first, x, y, z, t);
     r = t.r;
-    if constexpr (GRAD) { gx = t.gx; gy = t.gy; gz = t.gz; }
   } else {
-    sh_eval_rt<GRAD>(rc_in, cw_in, lrt, x, y, z, r, gx, gy, gz);
+    r = sh_eval_rt(rc_in, cw_in, lrt, x, y, z);
   }
-  // Pin the results here. Without a fixed use the optimiser sinks the whole
+  // Pin the result here. Without a fixed use the optimiser sinks the whole
   // VALU body of the evaluation into whichever later conditional first reads
   // the result, away from its (immovable) s_load / s_mov statements, and has to
   // carry every SGPR operand there through VGPR lanes.
   asm volatile("" : "+v"(r));
-  if constexpr (GRAD) asm volatile("" : "+v"(gx), "+v"(gy), "+v"(gz));
+  return r;
 }
 
 __device__ __forceinline__ double wave_sum(double v)
