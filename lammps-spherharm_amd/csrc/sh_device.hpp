@@ -4,24 +4,22 @@
 // i is evaluated from the ring tables of pair_kernel.hpp).
 //
 // docs/SPEC.md §1 in the angle-free polynomial form: for a unit vector (x,y,z)
-//   r = sum_m Re[ W_m(z) (x+iy)^m ],  W_m(z) = sum_n Q_n^m(z) cw_nm
-// with the z-polynomials Q_n^m from a two-term recurrence rescaled so that the
-// coefficient of Q_{n-2} is exactly 1 (one v_mul_f64 + one v_fma_f64 per term):
-//   Q_m^m = 1, Q_{m+1}^m = a'_{m+1,m} z, Q_n^m = a'_nm z Q_{n-1}^m - Q_{n-2}^m
-// (Pi_n^m = s_nm Pi_m^m Q_n^m; the factor s_nm Pi_m^m is folded into cw on the host).
+//   r = sum_m Re[ W_m(z) (x+iy)^m ],  W_m(z) = sum_n (2-delta_m0) a_nm Pi_n^m(z),
+// W_m a complex polynomial of degree L-m in z.
+//  * compiled orders (L <= 12): W_m in monomial form, Horner (see sh_term below);
+//  * run-time orders (13..20): W_m = sum_n Q_n^m(z) cw_nm with the two-term recurrence
+//      Q_m^m = 1, Q_{m+1}^m = a'_{m+1,m} z, Q_n^m = a'_nm z Q_{n-1}^m - Q_{n-2}^m
+//    (Pi_n^m = s_nm Pi_m^m Q_n^m; s_nm Pi_m^m folded into cw on the host; a' in the rc table).
 //
-// Where the operands live (one wavefront per pair, so all of them are
-// wave-uniform):
-//  * recurrence constants a': shape independent, so for the compiled orders
-//    they are C++ constant expressions (sh_const.hpp) that are materialised
-//    with s_mov_b32 on the scalar unit — no memory, no VGPR, no LDS.  The
-//    run-time-order kernel reads them from the rc table.
-//  * shape coefficients cw: scalar loads (s_load_dwordx16) through the scalar
-//    data cache into SGPRs, four complex terms at a time, software pipelined.
+// Where the operands live: one wavefront per pair, so the coefficients are
+// wave-uniform and arrive as scalar loads (s_load_dwordx16) through the scalar
+// data cache into SGPRs, four complex terms at a time, software pipelined —
+// no VGPR, no LDS.
 //
 // Table layout (built on the host by sh_tables.cpp), m-major so that the
-// constants of one m-block are contiguous: k = sh_index(L, n, m)
-//   rc[k]                 : n == m -> 1 ; n > m -> a'_nm
+// entries of one m-block are contiguous: k = sh_index(L, n, m)
+//   monomial table: entry k = coefficient of z^(L-n) of W_m      (compiled orders)
+//   rc[k]                 : n == m -> 1 ; n > m -> a'_nm            (run-time orders)
 //   cw[2k], cw[2k+1]      : (2-delta_m0) a_nm s_nm Pi_m^m
 // Reference: the SH math helpers of the reference are ABSENT FROM MOUNT
 // (SURVEY.md §2.2); this is the build's own formulation.
@@ -82,34 +80,48 @@ __device__ __forceinline__ sh_d8 sload_chunk(const cdptr base, const int off)
 }
 
 struct ShAcc {
-  double Wr, Wi;   // W_m
-  double p1, p2;   // Q_{n-1}, Q_{n-2}
+  double Wr, Wi;   // W_m (Horner accumulators)
 };
 
-// One (n, m) term with its coefficient (cr, ci) already in SGPRs.
-template <int L, int M, int N>
+// w * z + c with the wave-uniform coefficient c as the SGPR addend of ONE v_fma_f64.
+// Written as asm because the compiler prefers the VOP2 form v_fmac_f64 (addend = destination
+// = VGPR) and then copies every coefficient into a fresh VGPR pair first: three VALU
+// instructions per Horner step instead of one.
+__device__ __forceinline__ double horner_step(const double w, const double z, const double c)
+{
+  double o;
+  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(o) : "v"(w), "v"(z), "s"(c));
+  return o;
+}
+
+// Compiled orders evaluate W_m(z) in MONOMIAL form by Horner (coefficients in descending powers,
+// built on the host in long double, sh_tables.cpp: build_monomial): one v_fma_f64 per coefficient
+// and accumulator instead of the recurrence's mul + fma + fmac, and no recurrence constants at
+// all.  Conditioning is fine for L <= 12 (|Horner - exact| <= 2e-15 at L = 12, 7e-13 at L = 20,
+// tools/proto/horner_proto.py), so the run-time-order kernel (L = 13..20) keeps the recurrence.
+//
+// Position K of block M holds the coefficient of z^(L-M-K), (cr, ci) already in SGPRs.  Only one
+// SGPR operand fits a VALU instruction, so the first two steps are a mul and an add.
+template <int L, int M, int K>
 __device__ __forceinline__ void sh_term(const double cr, const double ci, const double z, ShAcc& s)
 {
-  if constexpr (N > L) {
+  constexpr int D = L - M;
+  if constexpr (K > D) {
     return;
-  } else if constexpr (N == M) {
-    s.Wr = cr;   // Q_m = 1
-    s.Wi = (M > 0) ? ci : 0.0;
-    s.p1 = 0.0;
-    s.p2 = 0.0;
-  } else if constexpr (N == M + 1) {
-    const double a1 = SHP_SGPR_CONST(sh_const::aprime(M + 1, M));
-    s.p2 = 1.0;   // Q_m, an inline constant
-    s.p1 = a1 * z;
-    s.Wr = fma(cr, s.p1, s.Wr);
-    if constexpr (M > 0) s.Wi = fma(ci, s.p1, s.Wi);
+  } else if constexpr (K == 0) {
+    if constexpr (D > 0) {
+      s.Wr = cr * z;
+      if constexpr (M > 0) s.Wi = ci * z;
+    } else {
+      s.Wr = cr;   // degree 0: stays wave-uniform
+      s.Wi = ci;
+    }
+  } else if constexpr (K == 1) {
+    s.Wr = s.Wr + cr;                       // c0 z + c1
+    if constexpr (M > 0) s.Wi = s.Wi + ci;
   } else {
-    const double a = SHP_SGPR_CONST(sh_const::aprime(N, M));
-    const double p = fma(a, z * s.p1, -s.p2);
-    s.Wr = fma(cr, p, s.Wr);
-    if constexpr (M > 0) s.Wi = fma(ci, p, s.Wi);
-    s.p2 = s.p1;
-    s.p1 = p;
+    s.Wr = horner_step(s.Wr, z, cr);
+    if constexpr (M > 0) s.Wi = horner_step(s.Wi, z, ci);
   }
 }
 
@@ -142,7 +154,7 @@ __device__ __forceinline__ void sh_block_end(const double x, const double y, ShS
   }
 }
 
-// The chunk that starts at term (N0, M), its coefficients already requested in
+// The chunk that starts at position N0 - M of block M, its coefficients already requested in
 // `cur`; requests its successor, computes its terms, recurses.
 template <int L, int M, int N0>
 struct ShStep {
@@ -155,10 +167,10 @@ struct ShStep {
     constexpr int Nn = block_done ? M + 1 : N0 + kChunk;
     sh_d8 nxt = cur;
     if constexpr (has_next) nxt = sload_chunk(cw_in, 2 * sh_index(L, Nn, Mn));
-    sh_term<L, M, N0>(cur[0], cur[1], z, t.a);
-    sh_term<L, M, N0 + 1>(cur[2], cur[3], z, t.a);
-    sh_term<L, M, N0 + 2>(cur[4], cur[5], z, t.a);
-    sh_term<L, M, N0 + 3>(cur[6], cur[7], z, t.a);
+    sh_term<L, M, N0 - M>(cur[0], cur[1], z, t.a);
+    sh_term<L, M, N0 - M + 1>(cur[2], cur[3], z, t.a);
+    sh_term<L, M, N0 - M + 2>(cur[4], cur[5], z, t.a);
+    sh_term<L, M, N0 - M + 3>(cur[6], cur[7], z, t.a);
     if constexpr (block_done) sh_block_end<L, M>(x, y, t);
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (has_next) ShStep<L, Mn, Nn>::run(cw_in, nxt, x, y, z, t);

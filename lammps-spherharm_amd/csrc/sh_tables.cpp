@@ -77,6 +77,44 @@ void build_coefficients(int L, int lmax, const double* anm, const std::vector<do
     }
 }
 
+void build_monomial(int L, int lmax, const double* anm, std::vector<double>& wm)
+{
+  const int T = (L + 1) * (L + 2) / 2;
+  wm.assign(2 * T, 0.0);
+  for (int m = 0; m <= L; ++m) {
+    const int d = L - m;
+    // Pi_n^m(z), n = m..L, ascending monomial coefficients
+    std::vector<long double> p2(d + 1, 0.0L), p1(d + 1, 0.0L), p(d + 1, 0.0L), wr(d + 1, 0.0L), wi(d + 1, 0.0L);
+    const long double fac = (m == 0) ? 1.0L : 2.0L;
+    for (int n = m; n <= L; ++n) {
+      if (n == m) {
+        p.assign(d + 1, 0.0L);
+        p[0] = (long double)sh_const::pmm(m);
+      } else {
+        const long double a = sqrtl((4.0L * n * n - 1.0L) / ((long double)n * n - (long double)m * m));
+        const long double b = (n - m >= 2) ? sqrtl(((2.0L * n + 1.0L) * (n + m - 1.0L) * (n - m - 1.0L)) /
+                                                   ((long double)(n - m) * (n + m) * (2.0L * n - 3.0L)))
+                                           : 0.0L;
+        for (int k = 0; k <= d; ++k) p[k] = ((k > 0) ? a * p1[k - 1] : 0.0L) - b * p2[k];
+      }
+      if (n <= lmax) {
+        const int kk = idx(n, m);
+        for (int k = 0; k <= d; ++k) {
+          wr[k] += fac * (long double)anm[2 * kk] * p[k];
+          if (m > 0) wi[k] += fac * (long double)anm[2 * kk + 1] * p[k];
+        }
+      }
+      p2 = p1;
+      p1 = p;
+    }
+    const int base = m * (L + 1) - m * (m - 1) / 2;  // sh_moff
+    for (int k = 0; k <= d; ++k) {                   // position k holds the coefficient of z^(d-k)
+      wm[2 * (base + k)] = (double)wr[d - k];
+      wm[2 * (base + k) + 1] = (double)wi[d - k];
+    }
+  }
+}
+
 void to_m_major(int L, int width, const std::vector<double>& src, std::vector<double>& dst)
 {
   dst.assign(src.size(), 0.0);

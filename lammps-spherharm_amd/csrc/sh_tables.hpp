@@ -16,6 +16,12 @@ void build_recurrence(int L, std::vector<double>& rc, std::vector<double>& scale
 void build_coefficients(int L, int lmax, const double* anm, const std::vector<double>& rc,
                         const std::vector<double>& scale, std::vector<double>& cw);
 
+// Monomial form for the compiled-order kernels (L <= 12): W_m(z) = sum_n (2-delta_m0) a_nm Pi_n^m(z)
+// as a polynomial of degree L-m in z, coefficients in DESCENDING powers (Horner order), complex,
+// m-major in the same layout and stride as the recurrence table: wm[2 sh_index(L, m+k, m)] is the
+// real part of the coefficient of z^(L-m-k).  Polynomial arithmetic in long double.
+void build_monomial(int L, int lmax, const double* anm, std::vector<double>& wm);
+
 // Permutes an n-major table (k = n(n+1)/2+m, `width` doubles per term) into
 // the m-major device layout of sh_device.hpp.
 void to_m_major(int L, int width, const std::vector<double>& src, std::vector<double>& dst);

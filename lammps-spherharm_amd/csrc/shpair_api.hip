@@ -89,7 +89,7 @@ struct shpair_ctx {
   bool any_nonunit_exponent = false;
   int lmax = -1, cstride = 0;
 
-  DevBuf<double> d_rc, d_coef, d_rmax, d_kn, d_expo, d_quad, d_creal, d_xval, d_gscale;
+  DevBuf<double> d_rc, d_coef, d_coefm, d_rmax, d_kn, d_expo, d_quad, d_creal, d_xval, d_gscale;
   DevBuf<int> d_xcol, d_xinfo;
   DevBuf<int> d_pair_i, d_pair_j;
   int npairs = 0;
@@ -178,7 +178,7 @@ void shpair_destroy(shpair_ctx* c)
   if (!c) return;
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
-  c->d_rc.release(); c->d_coef.release(); c->d_rmax.release(); c->d_kn.release(); c->d_expo.release();
+  c->d_rc.release(); c->d_coef.release(); c->d_coefm.release(); c->d_rmax.release(); c->d_kn.release(); c->d_expo.release();
   c->d_quad.release(); c->d_pair_i.release(); c->d_pair_j.release();
   c->d_creal.release(); c->d_xval.release(); c->d_gscale.release(); c->d_xcol.release(); c->d_xinfo.release();
   c->d_x.release(); c->d_quat.release(); c->d_f.release(); c->d_torque.release(); c->d_ev.release();
@@ -354,7 +354,7 @@ static int upload_tables(shpair_ctx* c)
       if (std::isnan(k) || std::isnan(m)) CTX_FAIL(c, SHPAIR_ESTATE, "pair_coeff for types %d %d was never set", a, b);
       if (m != 1.0) c->any_nonunit_exponent = true;
     }
-  std::vector<double> rc_n, rc, scale, cw_n, cw, all, rmax;
+  std::vector<double> rc_n, rc, scale, cw_n, cw, all, allm, wm, rmax;
   build_recurrence(L, rc_n, scale);
   to_m_major(L, 1, rc_n, rc);
   const int T = (L + 1) * (L + 2) / 2;
@@ -364,6 +364,9 @@ static int upload_tables(shpair_ctx* c)
     to_m_major(L, 2, cw_n, cw);
     cw.resize(sh_chunk_stride(L), 0.0);
     all.insert(all.end(), cw.begin(), cw.end());
+    build_monomial(L, c->shapes[s].lmax, c->shapes[s].anm.data(), wm);
+    wm.resize(sh_chunk_stride(L), 0.0);
+    allm.insert(allm.end(), wm.begin(), wm.end());
     rmax.push_back(c->shapes[s].rmax);
   }
   // cap-frame evaluation of particle i: real-basis coefficients, X matrices, ring scale
@@ -389,6 +392,8 @@ static int upload_tables(shpair_ctx* c)
   HIPCHK(c, hipMemcpy(c->d_gscale.p, gs.data(), gs.size() * sizeof(double), hipMemcpyHostToDevice));
   HIPCHK(c, c->d_rc.ensure(rc.size()));
   HIPCHK(c, c->d_coef.ensure(all.size()));
+  HIPCHK(c, c->d_coefm.ensure(allm.size()));
+  HIPCHK(c, hipMemcpy(c->d_coefm.p, allm.data(), allm.size() * sizeof(double), hipMemcpyHostToDevice));
   HIPCHK(c, c->d_rmax.ensure(rmax.size()));
   HIPCHK(c, c->d_kn.ensure(c->kn.size()));
   HIPCHK(c, c->d_expo.ensure(c->expo.size()));
@@ -497,8 +502,12 @@ int shpair_compute_device(shpair_ctx* c, int nlocal, int nghost, const double* x
   }
   const bool needv = c->opt_force_volume || eflag || c->any_nonunit_exponent;
   if (c->opt_timing) HIPCHK(c, hipEventRecord(c->ev0, st));
-  if (c->lmax <= kMaxUnrolledL && c->opt_variant != 1) kLaunch[c->lmax](P, needv, st);
-  else shp_launch_Lrt(P, needv, st);
+  if (c->lmax <= kMaxUnrolledL && c->opt_variant != 1) {
+    P.coef = c->d_coefm.p;  // compiled orders read the monomial (Horner) table
+    kLaunch[c->lmax](P, needv, st);
+  } else {
+    shp_launch_Lrt(P, needv, st);
+  }
   HIPCHK(c, hipGetLastError());
   if (c->opt_timing) {
     HIPCHK(c, hipEventRecord(c->ev1, st));
