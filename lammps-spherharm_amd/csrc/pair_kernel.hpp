@@ -99,8 +99,11 @@ constexpr int kMaxWavesPerBlock = 4;
 //                        leaves the CU enough waves, else the cap is processed in ring groups.
 //   qri[kQueue], qrj[kQueue], qp[kQueue] (int)   queue of inside nodes
 constexpr int kQueue = 128;  // entries; a slab adds <= 64 to a queue holding < 64
-constexpr int kFrame = 28;
-enum { FR_BJ1 = 0, FR_BJ2 = 3, FR_BJC = 6, FR_DJ = 9, FR_E1 = 12, FR_E2 = 15, FR_C = 18, FR_D = 21 };
+constexpr int kFrame = 32;
+// per-pair scalars live in the frame too: as VALU results they would sit in VGPR pairs for
+// the whole kernel (wave-uniform FP64 values cannot be SGPRs without readfirstlane)
+enum { FR_BJ1 = 0, FR_BJ2 = 3, FR_BJC = 6, FR_DJ = 9, FR_E1 = 12, FR_E2 = 15, FR_C = 18, FR_D = 21,
+       FR_RJ = 24, FR_RJ2 = 25, FR_RHO2 = 26, FR_HW = 27, FR_HM = 28, FR_WSC = 29 };
 
 struct WaveLdsLayout {
   int trig, v0, v1, ring, qri, qrj, qp, bytes;  // offsets in doubles (qp: in doubles too), total bytes
@@ -149,6 +152,10 @@ __device__ __forceinline__ double rsqrt_nr(const double x)
   return y;
 }
 
+// sqrt(x) for x >= 0 as x * rsqrt(x): a third of the VALU work of the IEEE sqrt() expansion
+// (which rescales, iterates and fixes up special cases), accurate to the last ulp or two.
+__device__ __forceinline__ double sqrt_nr(const double x) { return (x > 0.0) ? x * rsqrt_nr(x) : 0.0; }
+
 // 1/d to the last ulp or two: v_rcp_f64 + two Newton steps (5 VALU ops instead of
 // the ~12 of an IEEE division); 0 and denormals give inf/NaN, which the callers test.
 __device__ __forceinline__ double rcp_nr(const double d)
@@ -163,12 +170,12 @@ __device__ __forceinline__ double rcp_nr(const double d)
 // roots: ~25 VALU instructions instead of the ~150 of pow(); the whole wave issues them for lane 0.
 __device__ __forceinline__ double pow_quarter(const double v, const double e)
 {
-  if (e == 0.25) return sqrt(sqrt(v));
-  if (e == 0.5) return sqrt(v);
-  if (e == 0.75) { const double s = sqrt(v); return s * sqrt(s); }
+  if (e == 0.25) return sqrt_nr(sqrt_nr(v));
+  if (e == 0.5) return sqrt_nr(v);
+  if (e == 0.75) { const double s = sqrt_nr(v); return s * sqrt_nr(s); }
   if (e == 1.0) return v;
-  if (e == 1.25) return v * sqrt(sqrt(v));
-  if (e == 1.5) return v * sqrt(v);
+  if (e == 1.25) return v * sqrt_nr(sqrt_nr(v));
+  if (e == 1.5) return v * sqrt_nr(v);
   if (e == 2.0) return v * v;
   return pow(v, e);
 }
@@ -194,7 +201,7 @@ __device__ __forceinline__ void cap_frame_rotate(const PairParams& P, double* __
   // Euler angles: lanes 0,1,2 tabulate cos/sin(m angle) for alpha, beta, gamma
   {
     const double cb = bc[2];
-    const double sb = sqrt(fmax(0.0, fma(-cb, cb, 1.0)));
+    const double sb = sqrt_nr(fma(-cb, cb, 1.0));
     double ca = 1.0, sa = 0.0;
     if (sb > 0.0) {
       const double n = rsqrt_nr(bc[0] * bc[0] + bc[1] * bc[1]);
@@ -203,12 +210,12 @@ __device__ __forceinline__ void cap_frame_rotate(const PairParams& P, double* __
     }
     double cg, sg;
     if (cb >= 0.0) {
-      const double iv = 1.0 / (1.0 + cb);
+      const double iv = rcp_nr(1.0 + cb);
       const double cs = (b1[0] + b2[1]) * iv, ss = (b1[1] - b2[0]) * iv;  // alpha + gamma
       cg = cs * ca + ss * sa;
       sg = ss * ca - cs * sa;
     } else {
-      const double iv = 1.0 / (1.0 - cb);
+      const double iv = rcp_nr(1.0 - cb);
       const double cd = -(b1[0] - b2[1]) * iv, sd = -(b1[1] + b2[0]) * iv;  // alpha - gamma
       cg = ca * cd + sa * sd;
       sg = sa * cd - ca * sd;
@@ -275,7 +282,7 @@ __device__ __forceinline__ void cap_frame_rings(const PairParams& P, double* __r
     const int k = k0 + kr;
     const double mu = fma(hw, P.glt[k], hm);
     const double sig2 = fmax(0.0, fma(-mu, mu, 1.0));
-    const double sig = sqrt(sig2);
+    const double sig = sqrt_nr(sig2);
     const double* rcm = P.rc + sh_moff(LL, m);
     double q2 = 0.0, q1 = 1.0, d2 = 0.0, d1 = 0.0;  // Q_{n-2}, Q_{n-1} and mu-derivatives; start at n = m
     double wa = ch[m * m + 2 * m], wb = (m > 0) ? ch[m * m] : 0.0, wad = 0.0, wbd = 0.0;
@@ -299,7 +306,7 @@ __device__ __forceinline__ void cap_frame_rings(const PairParams& P, double* __r
       }
     }
     // d/dmu [sigma^m W] = sigma^m (W' - m mu W / sigma^2)
-    const double f = (m > 0) ? (double)m * mu / sig2 : 0.0;
+    const double f = (m > 0) ? (double)m * mu * rcp_nr(sig2) : 0.0;
     double* o = ring + 4 * idx;
     o[0] = sp * wa;
     o[2] = sp * fma(-f, wa, wad);
@@ -369,12 +376,14 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, SHP_MIN_WAVES) pair_co
   const int si = P.shtype[i], sj = P.shtype[j];
   const double Ri = P.rmax[si], Rj = P.rmax[sj];
   double rho2, rho, cosa;
+  bool centre_in_bj;  // rho < Rj
   {
     const double d0 = P.x[3 * j] - P.x[3 * i], d1 = P.x[3 * j + 1] - P.x[3 * i + 1],
                  d2 = P.x[3 * j + 2] - P.x[3 * i + 2];
     rho2 = d0 * d0 + d1 * d1 + d2 * d2;
-    rho = sqrt(rho2);
+    rho = sqrt(rho2);  // IEEE: decides the pair (SPEC §2.1) exactly as the oracle does
     if (rho >= Ri + Rj) return;  // SPEC §2.1, wave-uniform
+    centre_in_bj = rho < Rj;
 
     // SPEC §2.2 cap
     if (rho <= Rj) cosa = -1.0;
@@ -382,9 +391,10 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, SHP_MIN_WAVES) pair_co
     else cosa = (rho2 + Ri * Ri - Rj * Rj) / (2.0 * rho * Ri);
 
     // SPEC §2.3 frame (space)
-    const double c0 = d0 / rho, c1 = d1 / rho, c2 = d2 / rho;
+    const double irho = rcp_nr(rho);
+    const double c0 = d0 * irho, c1 = d1 * irho, c2 = d2 * irho;
     const double sg = copysign(1.0, c2);
-    const double aa = -1.0 / (sg + c2);
+    const double aa = -rcp_nr(sg + c2);
     const double bb = c0 * c1 * aa;
     const double e10 = 1.0 + sg * c0 * c0 * aa, e11 = sg * bb, e12 = -sg * c0;
     const double e20 = bb, e21 = sg + c1 * c1 * aa, e22 = -c1;
@@ -413,6 +423,10 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, SHP_MIN_WAVES) pair_co
       lw[FR_E2] = e20; lw[FR_E2 + 1] = e21; lw[FR_E2 + 2] = e22;
       lw[FR_C] = c0; lw[FR_C + 1] = c1; lw[FR_C + 2] = c2;
       lw[FR_D] = d0; lw[FR_D + 1] = d1; lw[FR_D + 2] = d2;
+      lw[FR_RJ] = Rj; lw[FR_RJ2] = Rj * Rj; lw[FR_RHO2] = rho2;
+      const double hw0 = 0.5 * (1.0 - cosa);
+      lw[FR_HW] = hw0; lw[FR_HM] = 0.5 * (1.0 + cosa);
+      lw[FR_WSC] = hw0 * (6.283185307179586476925286766559 / (double)(2 * nq));  // hw dpsi
     }
     cap_frame_rotate<L>(P, lw, W, LL, si, lane, b1, b2, bc);
   }
@@ -420,13 +434,12 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, SHP_MIN_WAVES) pair_co
   const double* rc = P.rc;
   const double* cwj = P.coef + (size_t)sj * P.cstride;
   const int lrt = P.lmax;
-  const double Rj2 = Rj * Rj;
   const double* fr = SHP_LDS();
 
   // SPEC §2.6: centre of i inside j (only possible when rho < Rj)
   bool centre_inside = false;
-  if (NEEDV && rho < Rj) {
-    const double ir = 1.0 / rho;
+  if (NEEDV && centre_in_bj) {
+    const double ir = rcp_nr(rho);
     const double rj = sh_eval<L>(rc, cwj, lrt, -fr[FR_DJ] * ir, -fr[FR_DJ + 1] * ir, -fr[FR_DJ + 2] * ir);
     centre_inside = (rho - rj <= 0.0);
   }
@@ -437,8 +450,6 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, SHP_MIN_WAVES) pair_co
   // magic * npsi - 2^24 < npsi <= 256 < 2^24 / 2^15
   const unsigned magic = ((1u << 24) + (unsigned)npsi - 1u) / (unsigned)npsi;
   const int nslabs = (Q + 63) >> 6;
-  const double hw = 0.5 * (1.0 - cosa), hm = 0.5 * (1.0 + cosa);
-  const double dpsi = 6.283185307179586476925286766559 / (double)npsi;
   const int rowlen = 4 * (LL + 1);
 
   double aV = 0.0, aS0 = 0.0, aS1 = 0.0, aS2 = 0.0, aT0 = 0.0, aT1 = 0.0, aT2 = 0.0;
@@ -450,7 +461,10 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, SHP_MIN_WAVES) pair_co
   const int k0 = (int)(((unsigned)(slab << 6) * magic) >> 24);
   const int kend = (k0 + P.ring_rows < nq) ? k0 + P.ring_rows : nq;
   const int slab_end = (kend == nq) ? nslabs : ((kend * npsi) >> 6);
-  cap_frame_rings<L>(P, SHP_LDS(), W, LL, lane, k0, kend - k0, hw, hm);
+  {
+    double* lr = SHP_LDS();
+    cap_frame_rings<L>(P, lr, W, LL, lane, k0, kend - k0, lr[FR_HW], lr[FR_HM]);
+  }
 
   for (;;) {
     // ---------------------------------------------------------------- phase 1
@@ -475,7 +489,7 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, SHP_MIN_WAVES) pair_co
       const double q0 = fma(ri, uj0, -fr[FR_DJ]), q1 = fma(ri, uj1, -fr[FR_DJ + 1]),
                    q2 = fma(ri, uj2, -fr[FR_DJ + 2]);
       const double s2 = q0 * q0 + q1 * q1 + q2 * q2;
-      const bool cand = valid && (s2 < Rj2);
+      const bool cand = valid && (s2 < fr[FR_RJ2]);
 #ifdef SHP_STATS
       if (lane == 0) atomicAdd(&P.dbg[0], 1ULL);
       if (cand) atomicAdd(&P.dbg[1], 1ULL);
@@ -486,7 +500,7 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, SHP_MIN_WAVES) pair_co
       const bool szero = !(s2 > 0.0);
       const double inv = szero ? 0.0 : rsqrt_nr(s2);
       double rj0 = sh_eval<L>(rc, cwj, lrt, szero ? 0.0 : q0 * inv, szero ? 0.0 : q1 * inv, szero ? 1.0 : q2 * inv);
-      if (szero) rj0 = Rj;
+      if (szero) rj0 = fr[FR_RJ];
       // SPEC: inside iff s < r_j (s == 0 is inside); s = s2 / sqrt(s2)
       const bool inside = cand && (szero || s2 * inv < rj0);
       const unsigned long long m = __ballot(inside);
@@ -523,7 +537,7 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, SHP_MIN_WAVES) pair_co
     const double ri = fr[W.qri + e];
     const int k = (int)(((unsigned)p * magic) >> 24);
     const int l = p - k * npsi;
-    const double omi = active ? hw * P.glw[k] * dpsi : 0.0;
+    const double omi = active ? fr[FR_WSC] * P.glw[k] : 0.0;
     const double c1 = P.cpsi[l], s1 = P.spsi[l];
     double mu, sig;
     {
@@ -546,13 +560,13 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, SHP_MIN_WAVES) pair_co
       {
         const double dj0 = fr[FR_DJ], dj1 = fr[FR_DJ + 1], dj2 = fr[FR_DJ + 2];
         const double bp = uj0 * dj0 + uj1 * dj1 + uj2 * dj2;
-        if (!(rho < Rj)) lo = bp - sqrt(fmax(0.0, fma(bp, bp, -(rho2 - Rj2))));
-        lam = bp - sqrt(fmax(0.0, fma(bp, bp, -(rho2 - rj0 * rj0))));
+        const double rho2l = fr[FR_RHO2];
+        if (!centre_in_bj) lo = bp - sqrt_nr(fma(bp, bp, -(rho2l - fr[FR_RJ2])));
+        lam = bp - sqrt_nr(fma(bp, bp, -(rho2l - rj0 * rj0)));
         if (!(lam > lo && lam < hi)) lam = 0.5 * (lo + hi);
         const double q0 = fma(ri, uj0, -dj0), q1 = fma(ri, uj1, -dj1), q2 = fma(ri, uj2, -dj2);
-        ga = gb = sqrt(q0 * q0 + q1 * q1 + q2 * q2) - rj0;
+        ga = gb = sqrt_nr(q0 * q0 + q1 * q1 + q2 * q2) - rj0;
       }
-      const double tolx = 1e-14 * Rj;
       if (!act) lam = ri;
       for (int it = 0; it < 60; ++it) {
         if (!__any(act)) break;
@@ -567,7 +581,8 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, SHP_MIN_WAVES) pair_co
         const bool z0 = !(ss2 > 0.0);
         const double iv = z0 ? 0.0 : rsqrt_nr(ss2);
         const double rj = sh_eval<L>(rc, cwj, lrt, z0 ? 0.0 : y0 * iv, z0 ? 0.0 : y1 * iv, z0 ? 1.0 : y2 * iv);
-        const double gl = z0 ? -Rj : ss2 * iv - rj;
+        const double Rjl = fr[FR_RJ];
+        const double gl = z0 ? -Rjl : ss2 * iv - rj;
         if (act) {
           if (gl >= 0.0) lo = lam; else hi = lam;
           const bool have3 = it >= 1;
@@ -580,14 +595,14 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, SHP_MIN_WAVES) pair_co
             ext = num * rcp_nr(dab * dal * dbl);
           }
           if (!(fabs(ext) <= 1e300)) ext = sec;
-          if (fabs(gl) <= (have3 ? SHP_TAU3 : 1e-7) * Rj) {  // accept the extrapolated point
+          if (fabs(gl) <= (have3 ? SHP_TAU3 : 1e-7) * Rjl) {  // accept the extrapolated point
             rin = (fabs(ext) <= 1e300) ? fmin(fmax(ext, lo), hi) : lam;
             act = false;
           } else {
             double nxt = ext;
             if (!(nxt > lo && nxt < hi)) nxt = sec;
             if (!(nxt > lo && nxt < hi)) nxt = 0.5 * (lo + hi);
-            if (hi - lo <= tolx) {
+            if (hi - lo <= 1e-14 * Rjl) {
               rin = 0.5 * (lo + hi);
               act = false;
             } else {
