@@ -497,10 +497,12 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, SHP_MIN_WAVES) pair_co
 #endif
       if (!__any(cand)) continue;  // wave-uniform: the whole 64-node slab misses B_j
 
+      // s == 0 (the node sits on x_j) is inside by definition; clamping s2 keeps that lane
+      // finite without a select per component (its direction is then the zero vector)
       const bool szero = !(s2 > 0.0);
-      const double inv = szero ? 0.0 : rsqrt_nr(s2);
-      double rj0 = sh_eval<L>(rc, cwj, lrt, szero ? 0.0 : q0 * inv, szero ? 0.0 : q1 * inv, szero ? 1.0 : q2 * inv);
-      if (szero) rj0 = fr[FR_RJ];
+      const double inv = rsqrt_nr(fmax(s2, 1e-300));
+      const double rj0e = sh_eval<L>(rc, cwj, lrt, q0 * inv, q1 * inv, q2 * inv);
+      const double rj0 = szero ? fr[FR_RJ] : rj0e;
       // SPEC: inside iff s < r_j (s == 0 is inside); s = s2 / sqrt(s2)
       const bool inside = cand && (szero || s2 * inv < rj0);
       const unsigned long long m = __ballot(inside);
@@ -579,22 +581,31 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, SHP_MIN_WAVES) pair_co
                      y2 = fma(lam, uj2, -fr[FR_DJ + 2]);
         const double ss2 = y0 * y0 + y1 * y1 + y2 * y2;
         const bool z0 = !(ss2 > 0.0);
-        const double iv = z0 ? 0.0 : rsqrt_nr(ss2);
-        const double rj = sh_eval<L>(rc, cwj, lrt, z0 ? 0.0 : y0 * iv, z0 ? 0.0 : y1 * iv, z0 ? 1.0 : y2 * iv);
+        const double iv = rsqrt_nr(fmax(ss2, 1e-300));
+        const double rj = sh_eval<L>(rc, cwj, lrt, y0 * iv, y1 * iv, y2 * iv);
         const double Rjl = fr[FR_RJ];
         const double gl = z0 ? -Rjl : ss2 * iv - rj;
         if (act) {
           if (gl >= 0.0) lo = lam; else hi = lam;
-          const bool have3 = it >= 1;
+          const bool have3 = it >= 1;  // wave-uniform
           const double dbl = gb - gl;
-          const double sec = fma(gl * (lam - xb), rcp_nr(dbl), lam);
-          double ext = sec;  // extrapolation to g = 0 through all known points
-          if (have3) {       // inverse quadratic interpolation over one common denominator
+          // extrapolation to g = 0: secant through two points on the first iterate, inverse
+          // quadratic interpolation (one common denominator) through three afterwards; the
+          // secant is then only a fallback and computed on demand
+          double ext, sec;
+          if (!have3) {
+            sec = fma(gl * (lam - xb), rcp_nr(dbl), lam);
+            ext = sec;
+          } else {
             const double dab = ga - gb, dal = ga - gl;
             const double num = fma(xa * gb, gl * dbl, fma(lam * ga, gb * dab, -(xb * ga) * (gl * dal)));
             ext = num * rcp_nr(dab * dal * dbl);
+            sec = ext;
+            if (!(fabs(ext) <= 1e300) || !(ext > lo && ext < hi)) {
+              sec = fma(gl * (lam - xb), rcp_nr(dbl), lam);
+              if (!(fabs(ext) <= 1e300)) ext = sec;
+            }
           }
-          if (!(fabs(ext) <= 1e300)) ext = sec;
           if (fabs(gl) <= (have3 ? SHP_TAU3 : 1e-7) * Rjl) {  // accept the extrapolated point
             rin = (fabs(ext) <= 1e300) ? fmin(fmax(ext, lo), hi) : lam;
             act = false;
