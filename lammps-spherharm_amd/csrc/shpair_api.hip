@@ -93,6 +93,7 @@ struct shpair_ctx {
   DevBuf<int> d_xcol, d_xinfo;
   DevBuf<int> d_pair_i, d_pair_j;
   int npairs = 0;
+  int max_atom_index = -1;  // largest i or j in the uploaded list
   bool have_neighbors = false;
 
   // staging for the host-pointer entry point
@@ -276,6 +277,13 @@ int shpair_shape_default_rmax(int lmax, const double* anm, double* rmax)
 static int upload_pairs(shpair_ctx* c, const std::vector<int>& pi, const std::vector<int>& pj)
 {
   const size_t n = pi.size();
+  int mx = -1;
+  for (size_t k = 0; k < n; ++k) {
+    if (pi[k] < 0 || pj[k] < 0) CTX_FAIL(c, SHPAIR_EINVAL, "negative atom index in the neighbour list (slot %zu)", k);
+    if (pi[k] > mx) mx = pi[k];
+    if (pj[k] > mx) mx = pj[k];
+  }
+  c->max_atom_index = mx;
   HIPCHK(c, hipSetDevice(c->device));
   HIPCHK(c, c->d_pair_i.ensure(n ? n : 1));
   HIPCHK(c, c->d_pair_j.ensure(n ? n : 1));
@@ -453,6 +461,9 @@ int shpair_compute_device(shpair_ctx* c, int nlocal, int nghost, const double* x
   c->stats.n_candidates = c->npairs;
   if (c->npairs == 0) return SHPAIR_OK;
   if (!x || !quat || !type || !shtype || !f || !torque) CTX_FAIL(c, SHPAIR_EINVAL, "null atom array");
+  if ((long long)c->max_atom_index >= (long long)nlocal + nghost)
+    CTX_FAIL(c, SHPAIR_EINVAL, "the neighbour list refers to atom %d but nlocal + nghost = %lld (stale list?)",
+             c->max_atom_index, (long long)nlocal + nghost);
   hipStream_t st = (hipStream_t)stream;  // NULL = HIP null stream
 
   PairParams P;
@@ -540,6 +551,14 @@ int shpair_compute(shpair_ctx* c, int nlocal, int nghost, const double* x, const
   if (!x || !quat || !type || !shtype || !f || !torque) CTX_FAIL(c, SHPAIR_EINVAL, "null atom array");
   if (eflag && !eng_vdwl) CTX_FAIL(c, SHPAIR_EINVAL, "eflag set but eng_vdwl is null");
   if (vflag && !virial) CTX_FAIL(c, SHPAIR_EINVAL, "vflag set but virial is null");
+  // the kernel indexes its tables with these: an out-of-range value would be an out-of-bounds
+  // read on the GPU, so the host entry point checks them (the device entry point cannot)
+  for (size_t a = 0; a < nall; ++a) {
+    if (type[a] < 1 || type[a] > c->ntypes)
+      CTX_FAIL(c, SHPAIR_EINVAL, "atom %zu has type %d outside [1,%d]", a, type[a], c->ntypes);
+    if (shtype[a] < 0 || shtype[a] >= c->nshapes)
+      CTX_FAIL(c, SHPAIR_EINVAL, "atom %zu has shape index %d outside [0,%d)", a, shtype[a], c->nshapes);
+  }
   HIPCHK(c, hipSetDevice(c->device));
   HIPCHK(c, c->d_x.ensure(3 * nall));
   HIPCHK(c, c->d_quat.ensure(4 * nall));

@@ -290,6 +290,21 @@ def test_error_codes(oracle):
     sp.coeff("*", "*", 100.0, 1.0)
     f, tq, _, _ = sp.compute(2, x, q, one, zero)
     assert f[0, 0] < 0 < f[1, 0] and abs(f[0, 0] + f[1, 0]) < 1e-12
+    # out-of-range indices must be refused on the host, never reach the kernel
+    with pytest.raises(ShPairError) as e:
+        sp.compute(2, x, q, np.array([1, 2], np.int32), zero)
+    assert e.value.code == -1 and "type" in str(e.value)
+    with pytest.raises(ShPairError) as e:
+        sp.compute(2, x, q, one, np.array([0, 2], np.int32))
+    assert e.value.code == -1 and "shape index" in str(e.value)
+    sp.set_neighbors_csr([0, 1], [0, 1, 1], [5])
+    with pytest.raises(ShPairError) as e:
+        sp.compute(2, x, q, one, zero)
+    assert e.value.code == -1 and "stale list" in str(e.value)
+    with pytest.raises(ShPairError) as e:
+        sp.set_neighbors_csr([0, 1], [0, 1, 1], [-3 & 0x1FFFFFFF | 0])  # masked: a huge positive index
+        sp.compute(2, x, q, one, zero)
+    assert e.value.code == -1
     with pytest.raises(ShPairError) as e:
         ShPair(99)
     assert e.value.code == -2
