@@ -326,6 +326,37 @@ def test_reconfiguration_between_computes(oracle):
     sp.close()
 
 
+@pytest.mark.parametrize("cfg,lmax,nq,nshapes,nrows", [("config3", 6, 16, 4, 1200), ("config5", 12, 32, 1, 250)])
+def test_full_size_other_baseline_configs(oracle, cfg, lmax, nq, nshapes, nrows):
+    """BASELINE configs 3 (100k particles, 4 mixed L=6 shapes) and 5 (100k, L=12, nq=32) at full size:
+    conservation laws on the whole bed, and a random subset of rows against the oracle."""
+    case = make_case(100000, lmax, nshapes, seed=3 if nshapes > 1 else 5, rmax_fn=oracle.shape_rmax)
+    K, E = coeff_tables(1, 1000.0, 1.25)
+    sp = make_ctx(case, nq, K, E)
+    b = case["bed"]
+    n = case["n"]
+    f, tq, eng, vir = sp.compute(n, b["x"], b["quat"], b["type"], b["shtype"], eflag=True, vflag=True)
+    fs = np.abs(f).max()
+    assert fs > 0 and np.all(np.isfinite(f)) and np.all(np.isfinite(tq)) and eng > 0
+    assert np.abs(f.sum(axis=0)).max() < 1e-10 * fs * np.sqrt(n)
+    ang = (tq + np.cross(b["x"], f)).sum(axis=0)
+    assert np.abs(ang).max() < 1e-9 * fs * np.sqrt(n) * np.abs(b["x"]).max()
+    of, jl = case["offsets"], case["jlist"]
+    rng = np.random.default_rng(1)
+    rows = np.sort(rng.choice(n, nrows, replace=False))
+    sof = np.zeros(rows.size + 1, np.int32)
+    sof[1:] = (of[rows + 1] - of[rows]).cumsum()
+    sjl = np.concatenate([jl[of[r]:of[r + 1]] for r in rows]).astype(np.int32)
+    sub = dict(case)
+    sub["ilist"], sub["offsets"], sub["jlist"] = rows.astype(np.int32), sof, sjl
+    sp.set_neighbors_csr(sub["ilist"], sof, sjl)
+    fg, tg, eg, _ = sp.compute(n, b["x"], b["quat"], b["type"], b["shtype"], eflag=True)
+    o = oracle_compute(oracle, sub, nq, K, E, eflag=True, nthreads=0)
+    check(fg, tg, o)
+    assert abs(eg - o["eng_virial"][0]) < TOL * o["eng_virial"][0]
+    sp.close()
+
+
 def test_full_size_bed_conservation_and_linearity(oracle):
     """BASELINE config 2 at full size (100k particles, L=6, nq=16): size-independent properties.
     Newton's third law, angular-momentum balance, pair-list linearity, run-to-run agreement, and a
