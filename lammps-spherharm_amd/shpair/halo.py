@@ -116,7 +116,15 @@ class Decomposition:
 
 
 class HaloExchange:
-    """Forward (x, quat -> ghosts) and reverse (ghost f, torque -> owners) exchange for one rank."""
+    """Forward (x, quat -> ghosts) and reverse (ghost f, torque -> owners) exchange for one rank.
+
+    Per step and direction: ONE batched point-to-point group and two gather/scatter kernels,
+    whatever the number of peers.  Forward: the rows to send to all peers are gathered with one
+    index_select per array into a buffer whose per-peer slices are the messages; the receives
+    land directly in the (contiguous, owner-ordered) ghost rows of x and quat.  Reverse: the
+    ghost rows of f and torque are the messages as they stand; the receives land in one buffer
+    that a single index_add_ per array folds into the owners' rows.
+    """
 
     def __init__(self, view, device, dist_module=None, host_staged=False):
         """host_staged: exchange through CPU copies of the buffers (for a `gloo` rehearsal of the
@@ -126,62 +134,77 @@ class HaloExchange:
         self.dist = dist_module
         self.host_staged = host_staged
         self.nlocal = view["nlocal"]
-        self.recv = dict(view["recv"])
-        self.send = {p: torch.as_tensor(idx, device=device) for p, idx in view["send"].items()}
-        self.peers = sorted(set(self.recv) | set(self.send))
+        self.recv = {int(p): (int(a), int(b)) for p, (a, b) in view["recv"].items()}
         self.device = device
-        self._fwd_buf = {p: torch.empty(idx.numel(), 7, dtype=torch.float64, device=device)
-                         for p, idx in self.send.items()}
-        self._fwd_in = {p: torch.empty(b - a, 7, dtype=torch.float64, device=device)
-                        for p, (a, b) in self.recv.items()}
-        self._rev_in = {p: torch.empty(idx.numel(), 6, dtype=torch.float64, device=device)
-                        for p, idx in self.send.items()}
-        self._rev_buf = {p: torch.empty(b - a, 6, dtype=torch.float64, device=device)
-                         for p, (a, b) in self.recv.items()}
+        self.peers = sorted(set(self.recv) | set(int(p) for p in view["send"]))
+        # concatenated send list, peer by peer, and each peer's slice of it
+        self.send_slice = {}
+        idx = []
+        off = 0
+        for p in self.peers:
+            if p in view["send"]:
+                n = len(view["send"][p])
+                self.send_slice[p] = (off, off + n)
+                idx.append(np.asarray(view["send"][p], dtype=np.int64))
+                off += n
+        self.nsend = off
+        self.send_idx = torch.as_tensor(np.concatenate(idx) if idx else np.zeros(0, np.int64), device=device)
+        f64 = torch.float64
+        self._sx = torch.empty(self.nsend, 3, dtype=f64, device=device)   # forward out / reverse in
+        self._sq = torch.empty(self.nsend, 4, dtype=f64, device=device)
+        self._rf = torch.empty(self.nsend, 3, dtype=f64, device=device)
+        self._rt = torch.empty(self.nsend, 3, dtype=f64, device=device)
 
     def bytes_per_step(self):
-        n_send = sum(int(i.numel()) for i in self.send.values())
         n_recv = sum(b - a for a, b in self.recv.values())
-        return 8 * (7 * n_send + 6 * n_recv), 8 * (7 * n_recv + 6 * n_send)
+        return 8 * (7 * self.nsend + 6 * n_recv), 8 * (7 * n_recv + 6 * self.nsend)
 
-    def _exchange(self, sends, recvs):
+    def _exchange(self, msgs):
+        """msgs: list of (peer, send tensor or None, recv tensor or None), any number per peer."""
         dist = self.dist
-        if self.host_staged:
-            dev_recvs = recvs
-            sends = {p: b.cpu() for p, b in sends.items()}
-            recvs = {p: self.torch.empty(b.shape, dtype=b.dtype) for p, b in dev_recvs.items()}
+        staged = []
         ops = []
-        for p in self.peers:  # same peer order everywhere; recv first, then send
-            if p in recvs:
-                ops.append(dist.P2POp(dist.irecv, recvs[p], p))
-            if p in sends:
-                ops.append(dist.P2POp(dist.isend, sends[p], p))
+        for p, snd, rcv in msgs:  # same peer order on every rank; per peer: receives, then sends
+            if rcv is not None:
+                if self.host_staged:
+                    h = self.torch.empty(rcv.shape, dtype=rcv.dtype)
+                    staged.append((rcv, h))
+                    rcv = h
+                ops.append(dist.P2POp(dist.irecv, rcv, p))
+        # NCCL/RCCL matches point-to-point operations between two ranks in issue order, so both sides
+        # list the messages of a peer pair in the same order (x before quat, f before torque)
+        for p, snd, rcv in msgs:
+            if snd is not None:
+                ops.append(dist.P2POp(dist.isend, snd.cpu() if self.host_staged else snd, p))
         if ops:
             for w in dist.batch_isend_irecv(ops):
                 w.wait()
-        if self.host_staged:
-            for p, b in recvs.items():
-                dev_recvs[p].copy_(b)
+        for dev, h in staged:
+            dev.copy_(h)
 
     def forward(self, x, quat):
         """x[nall,3], quat[nall,4]: owners' rows -> the peers' ghost rows (Comm::forward_comm)."""
         torch = self.torch
-        for p, idx in self.send.items():
-            buf = self._fwd_buf[p]
-            buf[:, :3] = x.index_select(0, idx)
-            buf[:, 3:] = quat.index_select(0, idx)
-        self._exchange(self._fwd_buf, self._fwd_in)
-        for p, (a, b) in self.recv.items():
-            x[a:b] = self._fwd_in[p][:, :3]
-            quat[a:b] = self._fwd_in[p][:, 3:]
+        if self.nsend:
+            torch.index_select(x, 0, self.send_idx, out=self._sx)
+            torch.index_select(quat, 0, self.send_idx, out=self._sq)
+        msgs = []
+        for p in self.peers:
+            sl = self.send_slice.get(p)
+            rc = self.recv.get(p)
+            msgs.append((p, self._sx[sl[0]:sl[1]] if sl else None, x[rc[0]:rc[1]] if rc else None))
+            msgs.append((p, self._sq[sl[0]:sl[1]] if sl else None, quat[rc[0]:rc[1]] if rc else None))
+        self._exchange(msgs)
 
     def reverse(self, f, torque):
         """Ghost rows of f/torque -> added into their owners' rows (Comm::reverse_comm)."""
-        for p, (a, b) in self.recv.items():
-            buf = self._rev_buf[p]
-            buf[:, :3] = f[a:b]
-            buf[:, 3:] = torque[a:b]
-        self._exchange(self._rev_buf, self._rev_in)
-        for p, idx in self.send.items():
-            f.index_add_(0, idx, self._rev_in[p][:, :3])
-            torque.index_add_(0, idx, self._rev_in[p][:, 3:])
+        msgs = []
+        for p in self.peers:
+            sl = self.send_slice.get(p)
+            rc = self.recv.get(p)
+            msgs.append((p, f[rc[0]:rc[1]] if rc else None, self._rf[sl[0]:sl[1]] if sl else None))
+            msgs.append((p, torque[rc[0]:rc[1]] if rc else None, self._rt[sl[0]:sl[1]] if sl else None))
+        self._exchange(msgs)
+        if self.nsend:
+            f.index_add_(0, self.send_idx, self._rf)
+            torque.index_add_(0, self.send_idx, self._rt)
