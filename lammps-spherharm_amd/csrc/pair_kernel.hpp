@@ -107,6 +107,7 @@ enum { FR_BJ1 = 0, FR_BJ2 = 3, FR_BJC = 6, FR_DJ = 9, FR_E1 = 12, FR_E2 = 15, FR
 
 struct WaveLdsLayout {
   int trig, v0, v1, ring, qri, qrj, qp, bytes;  // offsets in doubles (qp: in doubles too), total bytes
+  int coef;                                      // SHP_COEF_LDS ablation build only
 };
 __host__ __device__ inline WaveLdsLayout wave_lds_layout(const int L, const int rows)
 {
@@ -120,7 +121,13 @@ __host__ __device__ inline WaveLdsLayout wave_lds_layout(const int L, const int 
   w.qri = w.ring + 4 * rows * (L + 1);
   w.qrj = w.qri + kQueue;
   w.qp = w.qrj + kQueue;
-  w.bytes = 8 * (w.qp + kQueue / 2);
+  w.coef = w.qp + kQueue / 2;
+  w.coef += w.coef & 1;
+#ifdef SHP_COEF_LDS
+  w.bytes = 8 * (w.coef + sh_chunk_stride(L));
+#else
+  w.bytes = 8 * w.coef;
+#endif
   w.bytes = (w.bytes + 15) & ~15;
   return w;
 }
@@ -432,7 +439,18 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, SHP_MIN_WAVES) pair_co
   }
 
   const double* rc = P.rc;
+#ifndef SHP_COEF_LDS
   const double* cwj = P.coef + (size_t)sj * P.cstride;
+#else
+  // ablation: coalesced copy of shape j's table into this wave's LDS, read back per term
+  {
+    const double* src = P.coef + (size_t)sj * P.cstride;
+    double* dst = SHP_LDS() + W.coef;
+    for (int t = lane; t < P.cstride; t += 64) dst[t] = src[t];
+    wave_lds_sync();
+  }
+#define cwj (SHP_LDS() + W.coef)
+#endif
   const int lrt = P.lmax;
   const double* fr = SHP_LDS();
 
@@ -657,6 +675,9 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, SHP_MIN_WAVES) pair_co
   if (lane != 0) return;
   fr = SHP_LDS();
 #undef SHP_LDS
+#ifdef SHP_COEF_LDS
+#undef cwj
+#endif
 
   // rotate the cap-frame integrals to the space frame: columns e1, e2, c
   const double S0 = fr[FR_E1] * aS0 + fr[FR_E2] * aS1 + fr[FR_C] * aS2;

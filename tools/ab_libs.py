@@ -51,6 +51,7 @@ f = torch.zeros(a.n, 3, dtype=torch.float64, device=dev)
 tq = torch.zeros_like(f)
 a.libs = [f"{lib}#{rows}" for lib, rows in zip(a.libs, rr)]
 res = {lib: [] for lib in a.libs}
+fref = None
 for r in range(a.rounds + 1):
     for lib, sp in zip(a.libs, ctxs):
         f.zero_()
@@ -60,6 +61,12 @@ for r in range(a.rounds + 1):
         torch.cuda.synchronize()
         if r > 0:
             res[lib].append(sp.stats()["kernel_ms"])
+        else:  # first round: all builds must agree on the forces
+            fh = f.cpu().numpy()
+            if fref is None:
+                fref = fh
+            else:
+                print(f"{lib}: max |f - f[{a.libs[0]}]| / max|f| = {np.abs(fh - fref).max() / np.abs(fref).max():.2e}")
 for lib in dict.fromkeys(a.libs):
     v = np.array(res[lib])
     print(f"{lib}: median {np.median(v):.3f} ms  min {v.min():.3f}  pairs/s {jl.size / np.median(v) * 1e3:.3e}")
