@@ -207,11 +207,15 @@ __device__ __forceinline__ void cap_frame_rotate(const PairParams& P, double* __
   double* v1 = lw + W.v1;
   // Euler angles: lanes 0,1,2 tabulate cos/sin(m angle) for alpha, beta, gamma
   {
+    // sin(beta) from the x,y components of the pole, NOT sqrt(1 - cos^2): near the poles the
+    // latter is quantised at 1e-8 and rotates by a wrong tilt (4.8e-9 in r at L = 6, caught by
+    // tests/test_host_tables.py)
     const double cb = bc[2];
-    const double sb = sqrt_nr(fma(-cb, cb, 1.0));
-    double ca = 1.0, sa = 0.0;
-    if (sb > 0.0) {
-      const double n = rsqrt_nr(bc[0] * bc[0] + bc[1] * bc[1]);
+    const double sb2 = bc[0] * bc[0] + bc[1] * bc[1];
+    double sb = 0.0, ca = 1.0, sa = 0.0;
+    if (sb2 > 1e-280) {  // below: exactly polar (and v_rsq_f64 would meet a denormal)
+      const double n = rsqrt_nr(sb2);
+      sb = sb2 * n;
       ca = bc[0] * n;
       sa = bc[1] * n;
     }

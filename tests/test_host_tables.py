@@ -1,0 +1,28 @@
+"""CPU checks of the host-built kernel tables (csrc/sh_tables.cpp): the constant X = T(Rx(90 deg))
+matrices and their ELL form, the whole cap-frame pipeline emulated on the host with the tables the
+kernel reads (incl. pole-degenerate rotations), and the monomial (Horner) table."""
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "lammps-spherharm_amd", "csrc")
+
+
+@pytest.fixture(scope="module")
+def binary(tmp_path_factory):
+    out = tmp_path_factory.mktemp("host") / "test_tables"
+    subprocess.check_call(["g++", "-O2", "-std=c++17", f"-I{CSRC}", os.path.join(ROOT, "tests", "host", "test_tables.cpp"),
+                           os.path.join(CSRC, "sh_tables.cpp"), "-o", str(out)])
+    return str(out)
+
+
+@pytest.mark.parametrize("lmax,tol", [(0, 1e-14), (1, 1e-14), (4, 2e-14), (6, 3e-14), (12, 2e-13), (20, 5e-11)])
+def test_host_tables(binary, lmax, tol):
+    out = subprocess.check_output([binary, str(lmax)], text=True)
+    v = {ln.split()[0]: float(ln.split()[1]) for ln in out.strip().split("\n")}
+    assert v["x_orthogonality"] < 1e-13
+    assert v["x_ell_mismatch"] == 0.0 and v["x_row_excess"] <= 0
+    assert v["cap_frame_error"] < tol
+    assert v["horner_error"] < tol
