@@ -107,7 +107,7 @@ struct shpair_ctx {
   DevBuf<unsigned char> d_flags;
   unsigned long long* h_counters = nullptr;  // pinned 2
 
-  int opt_force_volume = 0, opt_timing = 0, opt_count = 0, opt_variant = 0, opt_ring_rows = 0;
+  int opt_force_volume = 0, opt_timing = 0, opt_count = 0, opt_variant = 0, opt_ring_rows = 0, opt_wpb = 0;
   double* pair_out = nullptr;
   unsigned long long* dbg = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr, evA = nullptr, evB = nullptr;
@@ -492,11 +492,17 @@ int shpair_compute_device(shpair_ctx* c, int nlocal, int nghost, const double* x
     if (rows < rows_min) rows = rows_min;
     if (rows > nq) rows = nq;
     const WaveLdsLayout wl = wave_lds_layout(c->lmax, rows);
-    int wpb = (160 * 1024) / wl.bytes;
-    if (wpb < 1)
+    if (wl.bytes > 160 * 1024)
       CTX_FAIL(c, SHPAIR_ELMAX, "lmax %d with nq %d needs %d bytes of LDS per pair, more than a CU has", c->lmax, nq,
                wl.bytes);
-    if (wpb > kMaxWavesPerBlock) wpb = kMaxWavesPerBlock;
+    // One wave (= one pair) per workgroup: pairs differ in cost (a grazing pair leaves after phase 1),
+    // and a multi-wave workgroup holds its LDS and wave slots until its slowest pair is done.
+    // A/B (tools/ab_libs.py --wpb): 1 wave 4.13 ms, 2 waves 4.22, 4 waves 4.34 at L = 6.
+    int wpb = 1;
+    if (c->opt_wpb > 1) {
+      wpb = c->opt_wpb < kMaxWavesPerBlock ? c->opt_wpb : kMaxWavesPerBlock;
+      if (wpb * wl.bytes > 160 * 1024) wpb = (160 * 1024) / wl.bytes;
+    }
     P.wave_lds_bytes = wl.bytes;
     P.waves_per_block = wpb;
     P.ring_rows = rows;
@@ -609,6 +615,7 @@ int shpair_set_option(shpair_ctx* c, const char* key, int value)
   else if (!strcmp(key, "count")) c->opt_count = value ? 1 : 0;
   else if (!strcmp(key, "variant")) c->opt_variant = value;
   else if (!strcmp(key, "ring_rows")) c->opt_ring_rows = value;
+  else if (!strcmp(key, "waves_per_block")) c->opt_wpb = value;
   else CTX_FAIL(c, SHPAIR_EINVAL, "unknown option '%s'", key);
   return SHPAIR_OK;
 }

@@ -18,6 +18,7 @@ ap.add_argument("--nq", type=int, default=16)
 ap.add_argument("--expo", type=float, default=1.25)
 ap.add_argument("--n", type=int, default=100000)
 ap.add_argument("--rounds", type=int, default=5)
+ap.add_argument("--wpb", type=int, nargs="*", default=[0], help="waves per workgroup per lib (0 = default)")
 ap.add_argument("--ring-rows", type=int, nargs="*", default=[0], help="one value per lib (0 = library default)")
 a = ap.parse_args()
 
@@ -30,8 +31,10 @@ shape = shapes.random_shape(a.lmax, bed.SEED0 + 2)
 rmax = None
 b = None
 rr = (a.ring_rows * len(ctxs))[:len(ctxs)] if len(a.ring_rows) == 1 else a.ring_rows
-for sp, rows in zip(ctxs, rr):
+wp = (a.wpb * len(ctxs))[:len(ctxs)] if len(a.wpb) == 1 else a.wpb
+for sp, rows, w in zip(ctxs, rr, wp):
     sp.set_option("ring_rows", rows)
+    sp.set_option("waves_per_block", w)
     sp.settings(a.nq)
     sp.set_ntypes(1, 1)
     sp.set_shape(0, a.lmax, shape)
@@ -49,7 +52,7 @@ ty = torch.from_numpy(b["type"]).to(dev)
 sh = torch.from_numpy(b["shtype"]).to(dev)
 f = torch.zeros(a.n, 3, dtype=torch.float64, device=dev)
 tq = torch.zeros_like(f)
-a.libs = [f"{lib}#{rows}" for lib, rows in zip(a.libs, rr)]
+a.libs = [f"{lib}#{rows}w{w}" for lib, rows, w in zip(a.libs, rr, wp)]
 res = {lib: [] for lib in a.libs}
 fref = None
 for r in range(a.rounds + 1):
