@@ -18,11 +18,12 @@
 //            volume) and the surface gradient of i (vector area, torque arm).
 // Only ~30 % of the cap nodes of a packed bed are inside the neighbour, so
 // queueing them keeps the two expensive passes at full lane occupancy.
-// Per-pair data is wave-uniform: shape coefficients arrive as scalar loads,
-// recurrence constants as s_mov immediates, the pair frame sits in LDS.  The
-// seven integrals (V, S_n, T_n) are reduced with cross-lane shuffles and lane
-// 0 applies the force law and issues the FP64 atomics.
-// No MFMA: the work is a polynomial recurrence per node, FP64 VALU bound.
+// Per-pair data is wave-uniform: particle j's coefficients (monomial form, Horner,
+// sh_device.hpp) arrive as scalar loads, the pair frame, the rotation's work vectors,
+// the ring tables and the queue sit in per-wave LDS.  The seven integrals (V, S_n,
+// T_n) are reduced with cross-lane shuffles and lane 0 applies the force law and
+// issues the FP64 atomics.  One wave per workgroup.
+// No MFMA: the work is polynomial evaluation per node, FP64 VALU bound.
 //
 // Reference: PairSH::compute() of the reference is ABSENT FROM MOUNT
 // (/root/reference/README.md:1 is the whole mount).
@@ -46,8 +47,8 @@ struct PairParams {
   int nlocal;
   int newton_pair;
   // shape tables
-  const double* rc;     // recurrence constants for lmax (sh_device.hpp)
-  const double* coef;   // nshapes x cstride doubles (cw)
+  const double* rc;     // recurrence constants a'_nm for lmax, m-major (ring tables; run-time-order kernel)
+  const double* coef;   // nshapes x cstride doubles: monomial table (compiled orders) or cw (run-time order)
   const double* rmax;   // nshapes
   int cstride;
   int lmax;
@@ -76,7 +77,6 @@ struct PairParams {
   unsigned char* flags;  // per slot: 1 = contact pair, 2 = touching pair; or null (stats only)
   int eflag;
   int vflag;
-  int force_volume;
   unsigned long long* dbg;  // SHP_STATS builds only: work counters (tools/kernel_stats.py)
 };
 

@@ -52,21 +52,6 @@ typedef const double* cdptr;
 __device__ __forceinline__ cdptr launder_uniform(const double* p) { return p; }
 #endif
 
-// A compile-time double as an SGPR pair, materialised by two s_mov_b32 on the
-// scalar unit at the point of use.  `volatile` keeps LICM from hoisting the
-// (loop-invariant) constant out of the node loop into a long-lived VGPR pair —
-// with 21 (L=6) to 78 (L=12) constants that alone would cost 42..156 VGPRs.
-template <unsigned LO, unsigned HI>
-__device__ __forceinline__ double sgpr_const_bits()
-{
-  unsigned lo, hi;
-  asm volatile("s_mov_b32 %0, %2\n\ts_mov_b32 %1, %3" : "=s"(lo), "=s"(hi) : "i"(LO), "i"(HI));
-  return __hiloint2double((int)hi, (int)lo);
-}
-#define SHP_SGPR_CONST(cexpr)                                                              \
-  ::shp::sgpr_const_bits<(unsigned)(__builtin_bit_cast(unsigned long long, (cexpr)) & 0xffffffffull), \
-                         (unsigned)(__builtin_bit_cast(unsigned long long, (cexpr)) >> 32)>()
-
 // Shape coefficients travel in chunks of 4 complex terms = one s_load_dwordx16
 // through the scalar data cache.  The load is an ordinary AS4 load (so the
 // compiler tracks it with a counted s_waitcnt and may keep it in flight), taken

@@ -510,7 +510,7 @@ int shpair_compute_device(shpair_ctx* c, int nlocal, int nghost, const double* x
   P.ev = ev; P.pair_out = c->pair_out;
   P.flags = nullptr;
   P.dbg = c->dbg;
-  P.eflag = eflag ? 1 : 0; P.vflag = vflag ? 1 : 0; P.force_volume = c->opt_force_volume;
+  P.eflag = eflag ? 1 : 0; P.vflag = vflag ? 1 : 0;
   if (c->opt_count) {
     HIPCHK(c, c->d_flags.ensure(c->npairs));
     HIPCHK(c, hipMemsetAsync(c->d_counters.p, 0, 2 * sizeof(unsigned long long), st));
