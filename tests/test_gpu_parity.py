@@ -490,3 +490,30 @@ def test_ring_groups_do_not_change_the_result(oracle, lmax, nq, rows):
     fs = np.abs(f0).max()
     assert np.abs(f1 - f0).max() < 1e-12 * fs and abs(e1 - e0) < 1e-12 * abs(e0)
     sp.close()
+
+
+def test_non_finite_inputs_terminate(oracle):
+    """NaN / inf coordinates and zero quaternions must not hang the kernel (every loop is bounded) and
+    must not disturb pairs they are not part of (a NaN separation fails every comparison, so such a
+    pair simply contributes nothing)."""
+    case = make_case(200, 6, 1, seed=70, rmax_fn=oracle.shape_rmax)
+    K, E = coeff_tables(1, 1000.0, 1.25)
+    sp = make_ctx(case, 16, K, E)
+    b = case["bed"]
+    f0, t0, _, _ = sp.compute(case["n"], b["x"], b["quat"], b["type"], b["shtype"])
+    x = b["x"].copy()
+    q = b["quat"].copy()
+    x[3] = np.nan
+    x[50, 1] = np.inf
+    q[100] = 0.0
+    f, tq, _, _ = sp.compute(case["n"], x, q, b["type"], b["shtype"])
+    of, jl, il = case["offsets"], case["jlist"], case["ilist"]
+    bad = {3, 50, 100}
+    touched = set(bad)
+    for ii, i in enumerate(il):
+        for j in jl[of[ii]:of[ii + 1]]:
+            if i in bad or int(j) in bad:
+                touched.update((int(i), int(j)))
+    clean = np.array([a for a in range(case["n"]) if a not in touched])
+    assert np.array_equal(f[clean], f0[clean]) or np.abs(f[clean] - f0[clean]).max() < 1e-12 * np.abs(f0).max()
+    sp.close()
