@@ -517,3 +517,59 @@ def test_non_finite_inputs_terminate(oracle):
     clean = np.array([a for a in range(case["n"]) if a not in touched])
     assert np.array_equal(f[clean], f0[clean]) or np.abs(f[clean] - f0[clean]).max() < 1e-12 * np.abs(f0).max()
     sp.close()
+
+
+@pytest.mark.parametrize("lmax,nq", [(3, 8), (6, 16), (9, 12)])
+def test_random_pair_soup_all_cap_branches(oracle, lmax, nq):
+    """Isolated random pairs from deep overlap (centre of i inside j, full-sphere cap, tangent-cone
+    cap) to grazing: per-pair V, S_n, T_n and forces against the oracle."""
+    import torch
+    from shpair import ShPair, shapes
+    rng = np.random.default_rng(1000 + lmax)
+    shp = [shapes.random_shape(lmax, 300 + s, amp=0.35) for s in range(3)]
+    rmax = [oracle.shape_rmax(lmax, a) for a in shp]
+    npair = 240
+    x = np.zeros((2 * npair, 3))
+    q = rng.normal(size=(2 * npair, 4))
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    sh = rng.integers(0, 3, size=2 * npair).astype(np.int32)
+    sep = np.concatenate([rng.uniform(0.15, 0.9, 60), rng.uniform(0.9, 1.6, 60), rng.uniform(1.6, 2.6, 120)])
+    for p in range(npair):
+        d = rng.normal(size=3)
+        d *= sep[p] / np.linalg.norm(d)
+        x[2 * p] = (20.0 * p, 0.0, 0.0)
+        x[2 * p + 1] = x[2 * p] + d
+    il = np.arange(2 * npair, dtype=np.int32)
+    of = np.zeros(2 * npair + 1, np.int32)
+    of[1:] = np.repeat(np.arange(1, npair + 1), 2)
+    of[1::2] = np.arange(1, npair + 1)
+    of[2::2] = np.arange(1, npair + 1)
+    jl = (2 * np.arange(npair) + 1).astype(np.int32)
+    ty = np.ones(2 * npair, np.int32)
+    sp = ShPair(0)
+    sp.settings(nq)
+    sp.set_ntypes(1, 3)
+    for s, a in enumerate(shp):
+        sp.set_shape(s, lmax, a)
+    sp.coeff(1, 1, 1000.0, 1.5)
+    sp.set_neighbors_csr(il, of, jl)
+    out = torch.zeros(npair, 7, dtype=torch.float64, device="cuda")
+    sp.set_pair_output(out.data_ptr())
+    f, tq, eng, _ = sp.compute(2 * npair, x, q, ty, sh, eflag=True)
+    K, E = coeff_tables(1, 1000.0, 1.5)
+    o = oracle.compute([(lmax, a, r) for a, r in zip(shp, rmax)], K, E, nq, 2 * npair, x, q, ty, sh, il, of, jl,
+                       eflag=True, want_pairs=True)
+    got = out.cpu().numpy()
+    ref = o["pairs"]
+    rho = sep
+    rj = np.array(rmax)[sh[1::2]]
+    assert (rho < rj).sum() > 40 and (got[:, 0] > 0).sum() > 150          # the deep branches are exercised
+    scale = np.maximum(np.abs(ref).max(axis=1), 1e-30)
+    err = np.abs(got - ref).max(axis=1) / scale
+    assert err[ref[:, 0] > 0].max() < 1e-9, (np.argmax(err), err.max())
+    assert not got[ref[:, 0] == 0, 0].any()
+    fs = np.abs(o["f"]).max()
+    assert np.abs(f - o["f"]).max() < TOL * fs
+    assert abs(eng - o["eng_virial"][0]) < TOL * o["eng_virial"][0]
+    sp.set_pair_output(None)
+    sp.close()
