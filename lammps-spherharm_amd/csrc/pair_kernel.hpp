@@ -439,6 +439,10 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, SHP_MIN_WAVES) pair_co
       lw[FR_HW] = hw0; lw[FR_HM] = 0.5 * (1.0 + cosa);
       lw[FR_WSC] = hw0 * (6.283185307179586476925286766559 / (double)(2 * nq));  // hw dpsi
     }
+#if defined(SHP_ABL) && SHP_ABL == 1   // timing-only build: stop after the pair prologue
+    asm volatile("" ::"v"(b1[0] + b2[1] + bc[2]));
+    return;
+#endif
     cap_frame_rotate<L>(P, lw, W, LL, si, lane, b1, b2, bc);
   }
 
@@ -486,6 +490,10 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, SHP_MIN_WAVES) pair_co
   {
     double* lr = SHP_LDS();
     cap_frame_rings<L>(P, lr, W, LL, lane, k0, kend - k0, lr[FR_HW], lr[FR_HM]);
+#if defined(SHP_ABL) && SHP_ABL == 2   // timing-only build: stop after rotation + ring tables
+    asm volatile("" ::"v"(lr[W.ring + lane]));
+    return;
+#endif
   }
 
   for (;;) {
@@ -543,6 +551,11 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, SHP_MIN_WAVES) pair_co
       qcount += __builtin_popcountll(m);
     }
     if (qcount == 0) break;
+#if defined(SHP_ABL) && SHP_ABL == 3   // timing-only build: phase 1 only, the queue is discarded
+    qhead = (qhead + qcount) & (kQueue - 1);
+    qcount = 0;
+    continue;
+#endif
 
     // ---------------------------------------------------------------- phase 2
     // up to 64 queued inside nodes, one per lane: inner radius, then gradient
