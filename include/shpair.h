@@ -102,6 +102,13 @@ int shpair_set_neighbors(shpair_ctx *ctx, int inum, const int *ilist, const int 
 int shpair_set_neighbors_csr(shpair_ctx *ctx, int inum, const int *ilist, const int *offsets,
                              const int *jlist);
 
+/* The CSR list already resident in HBM (a device-resident host such as a KOKKOS build): device
+ * pointers, expanded on the device, asynchronous on `stream` (NULL = HIP null stream).  npairs =
+ * offsets[inum] must be passed by the caller (it is not read back); max_atom_index = the largest
+ * atom index the list can contain (normally nlocal + nghost - 1), used for the stale-list check. */
+int shpair_set_neighbors_device(shpair_ctx *ctx, int inum, const int *ilist_dev, const int *offsets_dev,
+                                const int *jlist_dev, int npairs, int max_atom_index, void *stream);
+
 /* ---- PairSH::compute(eflag, vflag) --------------------------------------- */
 
 /* Host-pointer form, LAMMPS layout: x[nall][3], quat[nall][4] (w,x,y,z),

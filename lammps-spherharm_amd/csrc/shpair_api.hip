@@ -43,6 +43,22 @@ __global__ void count_flags_kernel(const unsigned char* __restrict__ flags, int 
   }
 }
 
+// Expands a device-resident CSR half list into one (i, j) per slot; one thread per row segment entry.
+__global__ void expand_csr_kernel(const int* __restrict__ ilist, const int* __restrict__ offsets,
+                                  const int* __restrict__ jlist, int inum, int* __restrict__ pair_i,
+                                  int* __restrict__ pair_j)
+{
+  // one wave per row: rows are short (~6 entries), lanes stride the row
+  const int row = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  if (row >= inum) return;
+  const int b = offsets[row], e = offsets[row + 1], i = ilist[row];
+  for (int p = b + lane; p < e; p += 64) {
+    pair_i[p] = i;
+    pair_j[p] = jlist[p] & SHPAIR_NEIGHMASK;
+  }
+}
+
 template <typename T>
 struct DevBuf {
   T* p = nullptr;
@@ -345,6 +361,28 @@ int shpair_set_neighbors_csr(shpair_ctx* c, int inum, const int* ilist, const in
     }
   }
   return upload_pairs(c, pi, pj);
+}
+
+int shpair_set_neighbors_device(shpair_ctx* c, int inum, const int* ilist, const int* offsets, const int* jlist,
+                                int npairs, int max_atom_index, void* stream)
+{
+  if (!c) return SHPAIR_EINVAL;
+  if (inum < 0 || npairs < 0 || (inum > 0 && (!ilist || !offsets)) || (npairs > 0 && !jlist))
+    CTX_FAIL(c, SHPAIR_EINVAL, "bad device neighbour list arguments");
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, c->d_pair_i.ensure(npairs ? npairs : 1));
+  HIPCHK(c, c->d_pair_j.ensure(npairs ? npairs : 1));
+  hipStream_t st = (hipStream_t)stream;
+  if (inum > 0 && npairs > 0) {
+    const int threads = 256, rows_per_block = threads / 64;
+    hipLaunchKernelGGL(expand_csr_kernel, dim3((inum + rows_per_block - 1) / rows_per_block), dim3(threads), 0, st, ilist,
+                       offsets, jlist, inum, c->d_pair_i.p, c->d_pair_j.p);
+    HIPCHK(c, hipGetLastError());
+  }
+  c->npairs = npairs;
+  c->max_atom_index = max_atom_index;
+  c->have_neighbors = true;
+  return SHPAIR_OK;
 }
 
 static int upload_tables(shpair_ctx* c)

@@ -44,6 +44,8 @@ SYMBOLS = {
     "shpair_shape_default_rmax": (C.c_int, [C.c_int, _dp, _dp]),
     "shpair_set_neighbors": (C.c_int, [C.c_void_p, C.c_int, _ip, _ip, C.POINTER(_ip)]),
     "shpair_set_neighbors_csr": (C.c_int, [C.c_void_p, C.c_int, _ip, _ip, _ip]),
+    "shpair_set_neighbors_device": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                              C.c_int, C.c_void_p]),
     "shpair_compute": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _dp, _dp, _ip, _ip, C.c_int, C.c_int, C.c_int,
                                  _dp, _dp, _dp, _dp]),
     "shpair_compute_device": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
@@ -188,6 +190,11 @@ class ShPair:
         keep = [np.ascontiguousarray(a, dtype=np.int32) for a in firstneigh]
         arr = (_ip * len(keep))(*[a.ctypes.data_as(_ip) for a in keep])
         self._chk(self._lib.shpair_set_neighbors(self._h, ilist.size, pi, pn, arr))
+
+    def set_neighbors_device(self, inum, ilist_ptr, offsets_ptr, jlist_ptr, npairs, max_atom_index, stream=None):
+        """CSR half list already on the device (raw device addresses). Asynchronous on `stream`."""
+        self._chk(self._lib.shpair_set_neighbors_device(self._h, int(inum), ilist_ptr, offsets_ptr, jlist_ptr,
+                                                        int(npairs), int(max_atom_index), stream))
 
     # --- PairSH::compute ------------------------------------------------------------
     def compute(self, nlocal, x, quat, type_, shtype, newton_pair=True, eflag=False, vflag=False,

@@ -216,6 +216,29 @@ def test_device_pointer_entry_point_and_stream(oracle):
     sp.close()
 
 
+def test_device_resident_neighbor_list(oracle):
+    """CSR list handed over as device pointers and expanded on the device == host upload."""
+    import torch
+    case = make_case(400, 6, 2, seed=16, rmax_fn=oracle.shape_rmax)
+    K, E = coeff_tables(1, 1000.0, 1.25)
+    sp = make_ctx(case, 12, K, E)
+    b = case["bed"]
+    f0, t0, _, _ = sp.compute(case["n"], b["x"], b["quat"], b["type"], b["shtype"])
+    dev = torch.device("cuda:0")
+    jl = case["jlist"].copy()
+    jl[::4] |= np.int32(1 << 30)
+    il_d = torch.from_numpy(case["ilist"]).to(dev)
+    of_d = torch.from_numpy(case["offsets"]).to(dev)
+    jl_d = torch.from_numpy(jl).to(dev)
+    sp.set_neighbors_csr([0], [0, 0], [])          # forget the host-uploaded list
+    sp.set_neighbors_device(case["n"], il_d.data_ptr(), of_d.data_ptr(), jl_d.data_ptr(), jl.size, case["n"] - 1)
+    torch.cuda.synchronize()
+    f1, t1, _, _ = sp.compute(case["n"], b["x"], b["quat"], b["type"], b["shtype"])
+    fs = np.abs(f0).max()
+    assert fs > 0 and np.abs(f1 - f0).max() < 1e-12 * fs and np.abs(t1 - t0).max() < 1e-12 * fs
+    sp.close()
+
+
 def test_empty_ragged_and_separated_inputs(oracle):
     from shpair import ShPair, shapes
     case = make_case(60, 4, 1, seed=14, spacing=4.0, rmax_fn=oracle.shape_rmax)  # no pairs at all
