@@ -596,3 +596,38 @@ def test_random_pair_soup_all_cap_branches(oracle, lmax, nq):
     assert abs(eng - o["eng_virial"][0]) < TOL * o["eng_virial"][0]
     sp.set_pair_output(None)
     sp.close()
+
+
+@pytest.mark.parametrize("lmax", [8, 12])
+def test_flat_spectrum_shapes(oracle, lmax):
+    """Shapes whose high orders are as strong as the low ones: the worst case for the monomial
+    (Horner) form of particle j and for the rounding of the cap-frame rotation of particle i."""
+    from shpair import shapes
+    rng = np.random.default_rng(90 + lmax)
+    shp = []
+    for s in range(2):
+        a = np.zeros((shapes.nterms(lmax), 2))
+        a[0, 0] = np.sqrt(4 * np.pi)
+        amp = 0.25 / np.sqrt(shapes.nterms(lmax))
+        for n in range(1, lmax + 1):
+            for m in range(n + 1):
+                a[n * (n + 1) // 2 + m, 0] = rng.normal(0, amp) * np.sqrt(4 * np.pi)
+                if m:
+                    a[n * (n + 1) // 2 + m, 1] = rng.normal(0, amp) * np.sqrt(4 * np.pi)
+        shp.append(a.ravel())
+    case = make_case(150, lmax, 2, seed=91, rmax_fn=oracle.shape_rmax)
+    case["shapes"] = shp
+    case["rmax"] = [oracle.shape_rmax(lmax, a) for a in shp]
+    from shpair import bed
+    case["ilist"], case["offsets"], case["jlist"] = bed.half_neighbor_list(case["bed"]["x"], case["bed"]["shtype"],
+                                                                            case["rmax"])
+    K, E = coeff_tables(1, 1000.0, 1.25)
+    sp = make_ctx(case, 16, K, E)
+    b = case["bed"]
+    f, tq, eng, _ = sp.compute(case["n"], b["x"], b["quat"], b["type"], b["shtype"], eflag=True)
+    o = oracle_compute(oracle, case, 16, K, E, eflag=True)
+    assert o["counts"][2] > 100
+    check(f, tq, o)
+    assert rel_err(f, o["f"]) < 1e-11      # far inside TOL even in this worst case
+    assert abs(eng - o["eng_virial"][0]) < TOL * o["eng_virial"][0]
+    sp.close()
