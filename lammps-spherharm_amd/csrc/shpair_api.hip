@@ -15,6 +15,7 @@
 
 #include "../../include/shpair.h"
 #include "pair_kernel.hpp"
+#include "shpair_ctx.hpp"
 #include "sh_const.hpp"
 #include "sh_tables.hpp"
 
@@ -59,92 +60,9 @@ __global__ void expand_csr_kernel(const int* __restrict__ ilist, const int* __re
   }
 }
 
-template <typename T>
-struct DevBuf {
-  T* p = nullptr;
-  size_t cap = 0;
-  hipError_t ensure(size_t n)
-  {
-    if (n <= cap) return hipSuccess;
-    if (p) (void)hipFree(p);
-    p = nullptr;
-    cap = 0;
-    size_t want = n + n / 8 + 16;
-    hipError_t e = hipMalloc((void**)&p, want * sizeof(T));
-    if (e == hipSuccess) cap = want;
-    return e;
-  }
-  void release()
-  {
-    if (p) (void)hipFree(p);
-    p = nullptr;
-    cap = 0;
-  }
-};
-
-struct Shape {
-  int lmax = -1;
-  std::vector<double> anm;
-  double rmax = 0.0;
-};
-
 }  // namespace shp
 
 using namespace shp;
-
-struct shpair_ctx {
-  int device = 0;
-  hipStream_t stream = nullptr;
-  std::string err;
-
-  int nq = 16;
-  int ntypes = 0, nshapes = 0;
-  std::vector<Shape> shapes;
-  std::vector<double> kn, expo;
-  bool tables_dirty = true, quad_dirty = true;
-  bool any_nonunit_exponent = false;
-  int lmax = -1, cstride = 0;
-
-  DevBuf<double> d_rc, d_coef, d_coefm, d_rmax, d_kn, d_expo, d_quad, d_creal, d_xval, d_gscale;
-  DevBuf<int> d_xcol, d_xinfo;
-  DevBuf<int> d_pair_i, d_pair_j;
-  int npairs = 0;
-  int max_atom_index = -1;  // largest i or j in the uploaded list
-  bool have_neighbors = false;
-
-  // staging for the host-pointer entry point
-  DevBuf<double> d_x, d_quat, d_f, d_torque, d_ev;
-  DevBuf<int> d_type, d_shtype;
-  double *h_ft = nullptr;  // pinned: f then torque
-  size_t h_ft_cap = 0;
-  double *h_ev = nullptr;  // pinned 7
-
-  DevBuf<unsigned long long> d_counters;
-  DevBuf<unsigned char> d_flags;
-  unsigned long long* h_counters = nullptr;  // pinned 2
-
-  int opt_force_volume = 0, opt_timing = 0, opt_count = 0, opt_variant = 0, opt_ring_rows = 0, opt_wpb = 0;
-  double* pair_out = nullptr;
-  unsigned long long* dbg = nullptr;
-  hipEvent_t ev0 = nullptr, ev1 = nullptr, evA = nullptr, evB = nullptr;
-  bool timed_last = false, counted_last = false, total_timed_last = false;
-  shpair_stats stats{};
-};
-
-#define CTX_FAIL(ctx, code, ...)                         \
-  do {                                                   \
-    char _b[512];                                        \
-    snprintf(_b, sizeof(_b), __VA_ARGS__);               \
-    (ctx)->err = _b;                                     \
-    return (code);                                       \
-  } while (0)
-
-#define HIPCHK(ctx, call)                                                                          \
-  do {                                                                                             \
-    hipError_t _e = (call);                                                                        \
-    if (_e != hipSuccess)                                                                          \
-      CTX_FAIL(ctx, SHPAIR_EHIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(_e), __FILE__, __LINE__); \
-  } while (0)
 
 extern "C" {
 

@@ -1,0 +1,102 @@
+// shpair_ctx.hpp — the context behind the C ABI (include/shpair.h, include/shstep.h), shared by the
+// translation units that implement it.  Internal: nothing here is part of the boundary.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "../../include/shpair.h"
+
+namespace shp {
+template <typename T>
+struct DevBuf {
+  T* p = nullptr;
+  size_t cap = 0;
+  hipError_t ensure(size_t n)
+  {
+    if (n <= cap) return hipSuccess;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+    size_t want = n + n / 8 + 16;
+    hipError_t e = hipMalloc((void**)&p, want * sizeof(T));
+    if (e == hipSuccess) cap = want;
+    return e;
+  }
+  void release()
+  {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+};
+
+struct Shape {
+  int lmax = -1;
+  std::vector<double> anm;
+  double rmax = 0.0;
+  double density = 1.0;  // shstep_set_density
+};
+
+}  // namespace shp
+
+struct shstep_state;  // shstep_api.hip
+
+struct shpair_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::string err;
+
+  int nq = 16;
+  int ntypes = 0, nshapes = 0;
+  std::vector<shp::Shape> shapes;
+  std::vector<double> kn, expo;
+  bool tables_dirty = true, quad_dirty = true;
+  bool any_nonunit_exponent = false;
+  int lmax = -1, cstride = 0;
+
+  shp::DevBuf<double> d_rc, d_coef, d_coefm, d_rmax, d_kn, d_expo, d_quad, d_creal, d_xval, d_gscale;
+  shp::DevBuf<int> d_xcol, d_xinfo;
+  shp::DevBuf<int> d_pair_i, d_pair_j;
+  int npairs = 0;
+  int max_atom_index = -1;  // largest i or j in the uploaded list
+  bool have_neighbors = false;
+
+  // staging for the host-pointer entry point
+  shp::DevBuf<double> d_x, d_quat, d_f, d_torque, d_ev;
+  shp::DevBuf<int> d_type, d_shtype;
+  double *h_ft = nullptr;  // pinned: f then torque
+  size_t h_ft_cap = 0;
+  double *h_ev = nullptr;  // pinned 7
+
+  shp::DevBuf<unsigned long long> d_counters;
+  shp::DevBuf<unsigned char> d_flags;
+  unsigned long long* h_counters = nullptr;  // pinned 2
+
+  int opt_force_volume = 0, opt_timing = 0, opt_count = 0, opt_variant = 0, opt_ring_rows = 0, opt_wpb = 0;
+  double* pair_out = nullptr;
+  unsigned long long* dbg = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr, evA = nullptr, evB = nullptr;
+  bool timed_last = false, counted_last = false, total_timed_last = false;
+  shpair_stats stats{};
+
+  shstep_state* step = nullptr;  // integrator / borders / neighbour-build state, created on first use
+};
+
+#define CTX_FAIL(ctx, code, ...)                         \
+  do {                                                   \
+    char _b[512];                                        \
+    snprintf(_b, sizeof(_b), __VA_ARGS__);               \
+    (ctx)->err = _b;                                     \
+    return (code);                                       \
+  } while (0)
+
+#define HIPCHK(ctx, call)                                                                          \
+  do {                                                                                             \
+    hipError_t _e = (call);                                                                        \
+    if (_e != hipSuccess)                                                                          \
+      CTX_FAIL(ctx, SHPAIR_EHIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(_e), __FILE__, __LINE__); \
+  } while (0)
+

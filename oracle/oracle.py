@@ -18,8 +18,8 @@ _ip = C.POINTER(C.c_int)
 
 def build(force=False):
     so = os.path.join(_HERE, "libshpair_oracle.so")
-    src = os.path.join(_HERE, "shpair_oracle.c")
-    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+    srcs = [os.path.join(_HERE, n) for n in ("shpair_oracle.c", "shstep_oracle.c", "Makefile")]
+    if force or not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(p) for p in srcs):
         subprocess.check_call(["make", "-C", _HERE, "libshpair_oracle.so"], stdout=subprocess.DEVNULL)
     return so
 
@@ -28,8 +28,7 @@ def lib():
     global _LIB
     if _LIB is None:
         so = os.path.join(_HERE, "libshpair_oracle.so")
-        if not os.path.exists(so):
-            build()
+        build()
         L = C.CDLL(so)
         L.sho_sh_eval.restype = C.c_double
         L.sho_sh_eval.argtypes = [C.c_int, _dp, _dp, _dp]
@@ -47,6 +46,19 @@ def lib():
                                   C.c_int, C.c_int, C.c_int, _dp, _dp, _dp,
                                   C.POINTER(C.c_longlong), _dp, C.c_int]
         L.sho_max_threads.restype = C.c_int
+        L.sho_mass_props.restype = None
+        L.sho_mass_props.argtypes = [C.c_int, _dp, _dp]
+        L.sho_nve.restype = None
+        L.sho_nve.argtypes = [C.c_int, C.c_int, C.c_double, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _ip, _ip, C.c_int]
+        L.sho_post_force.restype = None
+        L.sho_post_force.argtypes = [C.c_int, _dp, _dp, _dp, C.c_double, C.c_double, _dp, _dp, _dp, _ip, _ip,
+                                     C.c_int, _dp, _dp]
+        L.sho_energies.restype = None
+        L.sho_energies.argtypes = [C.c_int, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _ip, _ip, C.c_int, _dp]
+        L.sho_borders.restype = C.c_int
+        L.sho_borders.argtypes = [C.c_int, _dp, _dp, _dp, _ip, C.c_double, _ip, _ip]
+        L.sho_half_list.restype = C.c_int
+        L.sho_half_list.argtypes = [C.c_int, C.c_int, _dp, _ip, _ip, _dp, C.c_double, _ip, _ip]
         _LIB = L
     return _LIB
 
@@ -139,3 +151,85 @@ def compute(shapes, kn, expo, nq, nlocal, x, quat, type_, shtype, ilist, offs, j
 
 def max_threads():
     return lib().sho_max_threads()
+
+
+# ---- docs/SPEC.md Part II (shstep_oracle.c) ---------------------------------------------------
+
+def mass_props(lmax, anm):
+    """(V, c[3], J_c xx,yy,zz,xy,xz,yz) of a shape at unit density."""
+    anm, pa = _d(anm)
+    out = np.zeros(10)
+    lib().sho_mass_props(lmax, pa, out.ctypes.data_as(_dp))
+    return out
+
+
+def nve(phase, dt, massprops, density, x, v, quat, angmom, f, torque, shtype, mask, groupbit=1):
+    """In place on x, v, quat, angmom (float64 C-contiguous arrays). phase 0 = initial, 1 = final."""
+    mp, pmp = _d(massprops)
+    rho, prho = _d(density)
+    for a in (x, v, quat, angmom):
+        assert a.dtype == np.float64 and a.flags.c_contiguous
+    f, pf = _d(f)
+    torque, pt = _d(torque)
+    shtype, ps = _i(shtype)
+    mask, pm = _i(mask)
+    lib().sho_nve(phase, x.shape[0], dt, pmp, prho, x.ctypes.data_as(_dp), v.ctypes.data_as(_dp),
+                  quat.ctypes.data_as(_dp), angmom.ctypes.data_as(_dp), pf, pt, ps, pm, groupbit)
+
+
+def post_force(massprops, density, g, gamma_t, gamma_r, v, quat, angmom, shtype, mask, f, torque, groupbit=1):
+    mp, pmp = _d(massprops)
+    rho, prho = _d(density)
+    g, pg = _d(g)
+    v, pv = _d(v)
+    quat, pq = _d(quat)
+    angmom, pl = _d(angmom)
+    shtype, ps = _i(shtype)
+    mask, pm = _i(mask)
+    for a in (f, torque):
+        assert a.dtype == np.float64 and a.flags.c_contiguous
+    lib().sho_post_force(v.shape[0], pmp, prho, pg, gamma_t, gamma_r, pv, pq, pl, ps, pm, groupbit,
+                         f.ctypes.data_as(_dp), torque.ctypes.data_as(_dp))
+
+
+def energies(massprops, density, g, x, v, quat, angmom, shtype, mask, groupbit=1):
+    """(translational KE, rotational KE, gravitational PE)."""
+    mp, pmp = _d(massprops)
+    rho, prho = _d(density)
+    g, pg = _d(g)
+    x, px = _d(x)
+    v, pv = _d(v)
+    quat, pq = _d(quat)
+    angmom, pl = _d(angmom)
+    shtype, ps = _i(shtype)
+    mask, pm = _i(mask)
+    out = np.zeros(3)
+    lib().sho_energies(x.shape[0], pmp, prho, pg, px, pv, pq, pl, ps, pm, groupbit, out.ctypes.data_as(_dp))
+    return out
+
+
+def borders(x, lo, hi, periodic, cmax):
+    """Wraps x in place; returns (ghost_owner[ng], ghost_shift[ng,3])."""
+    assert x.dtype == np.float64 and x.flags.c_contiguous
+    n = x.shape[0]
+    lo, plo = _d(lo)
+    hi, phi = _d(hi)
+    per, pper = _i(periodic)
+    own = np.zeros(26 * max(n, 1), dtype=np.int32)
+    sh = np.zeros((26 * max(n, 1), 3), dtype=np.int32)
+    ng = lib().sho_borders(n, x.ctypes.data_as(_dp), plo, phi, pper, cmax, own.ctypes.data_as(_ip),
+                           sh.ctypes.data_as(_ip))
+    return own[:ng].copy(), sh[:ng].copy()
+
+
+def half_list(nlocal, x, shtype, tag, rmax, skin):
+    """Brute-force SPEC §7 half list: (offsets[nlocal+1], jlist)."""
+    x, px = _d(x)
+    shtype, ps = _i(shtype)
+    tag, pt = _i(tag)
+    rmax, pr = _d(rmax)
+    offs = np.zeros(nlocal + 1, dtype=np.int32)
+    n = lib().sho_half_list(nlocal, x.shape[0], px, ps, pt, pr, skin, offs.ctypes.data_as(_ip), None)
+    jl = np.zeros(max(n, 1), dtype=np.int32)
+    lib().sho_half_list(nlocal, x.shape[0], px, ps, pt, pr, skin, offs.ctypes.data_as(_ip), jl.ctypes.data_as(_ip))
+    return offs, jl[:n]
