@@ -312,4 +312,54 @@ double default_rmax(int lmax, const double* anm)
   return 1.01 * best;
 }
 
+// docs/SPEC.md §5. Azimuth nodes start at phi = 0 (any offset is exact for these integrands).
+void mass_props(int lmax, const double* anm, double out[10])
+{
+  const int nt = (5 * lmax) / 2 + 3, np = 5 * lmax + 4;
+  std::vector<double> t, w;
+  gauss_legendre(nt, t, w);
+  long double V = 0, c[3] = {0, 0, 0}, J[6] = {0, 0, 0, 0, 0, 0};
+  for (int a = 0; a < nt; ++a) {
+    const double ct = t[a], st = std::sqrt(1.0 - ct * ct);
+    for (int b = 0; b < np; ++b) {
+      const double ph = 2.0 * (double)kPi * b / np;
+      const double u[3] = {st * std::cos(ph), st * std::sin(ph), ct};
+      const long double r = host_radius(lmax, anm, u);
+      const long double dw = (long double)w[a] * 2.0L * kPi / np;
+      const long double r3 = r * r * r, r4 = r3 * r, r5 = r4 * r / 5.0L;
+      V += dw * r3 / 3.0L;
+      for (int k = 0; k < 3; ++k) c[k] += dw * r4 / 4.0L * u[k];
+      J[0] += dw * r5 * (1.0L - u[0] * u[0]);
+      J[1] += dw * r5 * (1.0L - u[1] * u[1]);
+      J[2] += dw * r5 * (1.0L - u[2] * u[2]);
+      J[3] -= dw * r5 * u[0] * u[1];
+      J[4] -= dw * r5 * u[0] * u[2];
+      J[5] -= dw * r5 * u[1] * u[2];
+    }
+  }
+  for (int k = 0; k < 3; ++k) c[k] /= V;
+  const long double c2 = c[0] * c[0] + c[1] * c[1] + c[2] * c[2];
+  out[0] = (double)V;
+  for (int k = 0; k < 3; ++k) out[1 + k] = (double)c[k];
+  for (int k = 0; k < 3; ++k) out[4 + k] = (double)(J[k] - V * (c2 - c[k] * c[k]));
+  out[7] = (double)(J[3] + V * c[0] * c[1]);
+  out[8] = (double)(J[4] + V * c[0] * c[2]);
+  out[9] = (double)(J[5] + V * c[1] * c[2]);
+}
+
+// Inverse of rho * J (symmetric, xx,yy,zz,xy,xz,yz); false if not positive definite.
+bool inertia_inverse(const double mp[10], double rho, double inv[6])
+{
+  const double a = rho * mp[4], b = rho * mp[5], c = rho * mp[6], d = rho * mp[7], e = rho * mp[8], f = rho * mp[9];
+  const double det = a * (b * c - f * f) - d * (d * c - f * e) + e * (d * f - b * e);
+  if (!(a > 0.0) || !(a * b - d * d > 0.0) || !(det > 0.0)) return false;
+  inv[0] = (b * c - f * f) / det;
+  inv[1] = (a * c - e * e) / det;
+  inv[2] = (a * b - d * d) / det;
+  inv[3] = (e * f - d * c) / det;
+  inv[4] = (d * f - b * e) / det;
+  inv[5] = (d * e - a * f) / det;
+  return true;
+}
+
 }  // namespace shp

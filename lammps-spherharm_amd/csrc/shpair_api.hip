@@ -113,6 +113,7 @@ void shpair_destroy(shpair_ctx* c)
   if (!c) return;
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
+  shstep_release_state(c);
   c->d_rc.release(); c->d_coef.release(); c->d_coefm.release(); c->d_rmax.release(); c->d_kn.release(); c->d_expo.release();
   c->d_quad.release(); c->d_pair_i.release(); c->d_pair_j.release();
   c->d_creal.release(); c->d_xval.release(); c->d_gscale.release(); c->d_xcol.release(); c->d_xinfo.release();
@@ -146,6 +147,7 @@ int shpair_set_ntypes(shpair_ctx* c, int ntypes, int nshapes)
   c->ntypes = ntypes;
   c->nshapes = nshapes;
   c->shapes.assign(nshapes, Shape());
+  c->mass_dirty = true;
   c->kn.assign((size_t)(ntypes + 1) * (ntypes + 1), std::nan(""));
   c->expo.assign((size_t)(ntypes + 1) * (ntypes + 1), std::nan(""));
   c->tables_dirty = true;
@@ -169,6 +171,7 @@ int shpair_set_shape(shpair_ctx* c, int ishape, int lmax, const double* anm, dou
   s.rmax = (rmax > 0.0) ? rmax : default_rmax(lmax, anm);
   if (!(s.rmax > 0.0) || !std::isfinite(s.rmax)) CTX_FAIL(c, SHPAIR_EINVAL, "shape %d: bounding radius %g is not positive", ishape, s.rmax);
   c->tables_dirty = true;
+  c->mass_dirty = true;
   return SHPAIR_OK;
 }
 
@@ -229,6 +232,7 @@ static int upload_pairs(shpair_ctx* c, const std::vector<int>& pi, const std::ve
   }
   c->npairs = (int)n;
   c->have_neighbors = true;
+  shstep_invalidate_list(c);
   return SHPAIR_OK;
 }
 
@@ -300,6 +304,7 @@ int shpair_set_neighbors_device(shpair_ctx* c, int inum, const int* ilist, const
   c->npairs = npairs;
   c->max_atom_index = max_atom_index;
   c->have_neighbors = true;
+  shstep_invalidate_list(c);
   return SHPAIR_OK;
 }
 

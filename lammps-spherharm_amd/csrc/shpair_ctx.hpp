@@ -54,6 +54,7 @@ struct shpair_ctx {
   std::vector<shp::Shape> shapes;
   std::vector<double> kn, expo;
   bool tables_dirty = true, quad_dirty = true;
+  bool mass_dirty = true;  // rigid-body table of shstep_api.hip
   bool any_nonunit_exponent = false;
   int lmax = -1, cstride = 0;
 
@@ -84,6 +85,9 @@ struct shpair_ctx {
 
   shstep_state* step = nullptr;  // integrator / borders / neighbour-build state, created on first use
 };
+
+void shstep_release_state(shpair_ctx* c);   // shstep_api.hip
+void shstep_invalidate_list(shpair_ctx* c);
 
 #define CTX_FAIL(ctx, code, ...)                         \
   do {                                                   \

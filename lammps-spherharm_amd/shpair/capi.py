@@ -56,6 +56,23 @@ SYMBOLS = {
     "shpair_set_pair_output": (C.c_int, [C.c_void_p, C.c_void_p]),
     "shpair_get_stream": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
     "shpair_synchronize": (C.c_int, [C.c_void_p]),
+    # include/shstep.h
+    "shstep_shape_mass_props": (C.c_int, [C.c_int, _dp, _dp]),
+    "shstep_set_density": (C.c_int, [C.c_void_p, C.c_int, C.c_double]),
+    "shstep_get_body": (C.c_int, [C.c_void_p, C.c_int, _dp, _dp, _dp]),
+    "shstep_nve_device": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_double] + [C.c_void_p] * 8 + [C.c_int, C.c_void_p]),
+    "shstep_nve": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_double, _dp, _dp, _dp, _dp, _dp, _dp, _ip, _ip, C.c_int]),
+    "shstep_post_force_device": (C.c_int, [C.c_void_p, C.c_int, _dp, C.c_double, C.c_double] + [C.c_void_p] * 5 +
+                                 [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "shstep_energies_device": (C.c_int, [C.c_void_p, C.c_int, _dp] + [C.c_void_p] * 6 + [C.c_int, C.c_void_p, C.c_void_p]),
+    "shstep_set_box": (C.c_int, [C.c_void_p, _dp, _dp, _ip, C.c_double]),
+    "shstep_borders_device": (C.c_int, [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 5 + [_ip, C.c_void_p]),
+    "shstep_forward_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "shstep_reverse_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "shstep_neighbor_build_device": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, _ip,
+                                               C.c_void_p]),
+    "shstep_neighbor_check_device": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, _ip, C.c_void_p]),
+    "shstep_copy_neighbors": (C.c_int, [C.c_void_p, _ip, _ip]),
 }
 
 
@@ -116,6 +133,16 @@ def shape_default_rmax(lmax, anm):
     if rc:
         raise ShPairError(rc)
     return r.value
+
+
+def shape_mass_props(lmax, anm):
+    """(V, c[3], J_c xx,yy,zz,xy,xz,yz) at unit density (docs/SPEC.md §5)."""
+    anm, pa = _d(anm)
+    out = np.zeros(10)
+    rc = load_library().shstep_shape_mass_props(lmax, pa, out.ctypes.data_as(_dp))
+    if rc:
+        raise ShPairError(rc)
+    return out
 
 
 class ShPair:
@@ -248,3 +275,79 @@ class ShPair:
 
     def synchronize(self):
         self._chk(self._lib.shpair_synchronize(self._h))
+
+    # --- include/shstep.h: integrator, body forces, ghosts, neighbour build (device pointers as ints) ----
+    def set_density(self, ishape, rho):
+        self._chk(self._lib.shstep_set_density(self._h, int(ishape), float(rho)))
+
+    def body(self, ishape):
+        """(mass, com[3], inertia[6]) of a shape."""
+        m = C.c_double()
+        com, inertia = np.zeros(3), np.zeros(6)
+        self._chk(self._lib.shstep_get_body(self._h, int(ishape), C.byref(m), com.ctypes.data_as(_dp),
+                                            inertia.ctypes.data_as(_dp)))
+        return m.value, com, inertia
+
+    def nve_device(self, phase, nlocal, dt, x, v, quat, angmom, f, torque, shtype, mask, groupbit=1, stream=None):
+        self._chk(self._lib.shstep_nve_device(self._h, int(phase), int(nlocal), float(dt), x, v, quat, angmom, f, torque,
+                                              shtype, mask, int(groupbit), stream))
+
+    def nve(self, phase, dt, x, v, quat, angmom, f, torque, shtype, mask, groupbit=1):
+        """Host-pointer form; x, v, quat, angmom are updated in place (float64 C-contiguous)."""
+        for a in (x, v, quat, angmom):
+            assert a.dtype == np.float64 and a.flags.c_contiguous
+        f, pf = _d(f)
+        torque, pt = _d(torque)
+        shtype, ps = _i(shtype)
+        mask, pm = _i(mask)
+        self._chk(self._lib.shstep_nve(self._h, int(phase), x.shape[0], float(dt), x.ctypes.data_as(_dp),
+                                       v.ctypes.data_as(_dp), quat.ctypes.data_as(_dp), angmom.ctypes.data_as(_dp),
+                                       pf, pt, ps, pm, int(groupbit)))
+
+    def post_force_device(self, nlocal, gravity, gamma_t, gamma_r, v, quat, angmom, shtype, mask, f, torque,
+                          groupbit=1, stream=None):
+        g, pg = _d(gravity)
+        self._chk(self._lib.shstep_post_force_device(self._h, int(nlocal), pg, float(gamma_t), float(gamma_r), v, quat,
+                                                     angmom, shtype, mask, int(groupbit), f, torque, stream))
+
+    def energies_device(self, nlocal, gravity, x, v, quat, angmom, shtype, mask, out3, groupbit=1, stream=None):
+        g, pg = _d(gravity)
+        self._chk(self._lib.shstep_energies_device(self._h, int(nlocal), pg, x, v, quat, angmom, shtype, mask,
+                                                   int(groupbit), out3, stream))
+
+    def set_box(self, lo, hi, periodic, skin):
+        lo, plo = _d(lo)
+        hi, phi = _d(hi)
+        per, pp = _i(periodic)
+        self._chk(self._lib.shstep_set_box(self._h, plo, phi, pp, float(skin)))
+
+    def borders_device(self, nlocal, nmax, x, quat, type_, shtype, tag=None, stream=None):
+        """Returns nghost (blocks)."""
+        ng = C.c_int(0)
+        self._chk(self._lib.shstep_borders_device(self._h, int(nlocal), int(nmax), x, quat, type_, shtype, tag,
+                                                  C.byref(ng), stream))
+        return ng.value
+
+    def forward_device(self, x, quat, stream=None):
+        self._chk(self._lib.shstep_forward_device(self._h, x, quat, stream))
+
+    def reverse_device(self, f, torque, stream=None):
+        self._chk(self._lib.shstep_reverse_device(self._h, f, torque, stream))
+
+    def neighbor_build_device(self, nlocal, nghost, x, shtype, tag=None, stream=None):
+        """Builds and installs the half list; returns npairs (blocks)."""
+        n = C.c_int(0)
+        self._chk(self._lib.shstep_neighbor_build_device(self._h, int(nlocal), int(nghost), x, shtype, tag,
+                                                         C.byref(n), stream))
+        return n.value
+
+    def neighbor_check_device(self, nlocal, x, stream=None):
+        r = C.c_int(0)
+        self._chk(self._lib.shstep_neighbor_check_device(self._h, int(nlocal), x, C.byref(r), stream))
+        return bool(r.value)
+
+    def copy_neighbors(self, nlocal, npairs):
+        offs = np.zeros(nlocal + 1, dtype=np.int32)
+        jl = np.zeros(max(npairs, 1), dtype=np.int32)
+        self._chk(self._lib.shstep_copy_neighbors(self._h, offs.ctypes.data_as(_ip), jl.ctypes.data_as(_ip)))
+        return offs, jl[:npairs]

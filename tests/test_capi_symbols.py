@@ -1,5 +1,5 @@
 """CPU-only checks of the drop-in boundary: the library loads, exports every
-symbol include/shpair.h declares, its stateless host helpers agree with scipy,
+symbol include/shpair.h and include/shstep.h declare, its stateless host helpers agree with scipy,
 and without a GPU it refuses to create a context (no CPU fallback)."""
 import ctypes
 import os
@@ -15,15 +15,18 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def header_symbols():
-    txt = open(os.path.join(ROOT, "include", "shpair.h")).read()
-    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
-    return sorted(set(re.findall(r"\b(shpair_[a-z_]+)\s*\(", txt)))
+    names = set()
+    for h in ("shpair.h", "shstep.h"):
+        txt = open(os.path.join(ROOT, "include", h)).read()
+        txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+        names |= set(re.findall(r"\b(sh(?:pair|step)_[a-z_]+)\s*\(", txt))
+    return sorted(names)
 
 
 def test_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(capi.library_path())
     names = header_symbols()
-    assert len(names) >= 20
+    assert len(names) >= 34
     for n in names:
         assert hasattr(lib, n), f"libshpair.so does not export {n}"
     assert sorted(capi.SYMBOLS) == names  # the ctypes binding covers exactly the header
@@ -68,3 +71,15 @@ def test_no_gpu_means_no_context(gpu_available):
     with pytest.raises(capi.ShPairError) as e:
         capi.ShPair(0)
     assert e.value.code == -2  # SHPAIR_ENODEV: fails loudly, never computes on the CPU
+
+
+def test_mass_props_helper_agrees_with_oracle(oracle):
+    """Stateless host helper of include/shstep.h (no device needed) vs the oracle's own quadrature."""
+    for lmax, seed in ((0, 1), (4, 2), (6, 3), (12, 4)):
+        a = shapes.random_shape(lmax, seed, amp=0.3)
+        got = capi.shape_mass_props(lmax, a)
+        ref = oracle.mass_props(lmax, a)
+        assert np.abs(got - ref).max() < 1e-13 * max(1.0, np.abs(ref).max())
+    out = np.zeros(10)
+    assert capi.load_library().shstep_shape_mass_props(-1, out.ctypes.data_as(ctypes.POINTER(ctypes.c_double)),
+                                                      out.ctypes.data_as(ctypes.POINTER(ctypes.c_double))) == -1
