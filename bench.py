@@ -64,6 +64,7 @@ def parse():
     ap.add_argument("--verify", action="store_true",
                     help="N > 1: gather the owned forces and compare them with a single-domain compute of the "
                          "whole bed on rank 0 (small beds only)")
+    ap.add_argument("--ts-steps", type=int, default=40, help="steps of the whole-timestep leg (N = 1 only; 0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=16, help="OpenMP threads of the cpu_baseline leg "
                     "(16 = the host-core share of one GPU on the bench box)")
     return ap.parse_args()
@@ -247,7 +248,7 @@ def main():
                 "touching_pairs_rank0": int(n_touching), "contact_pairs_all_ranks": int(contact_all),
                 "ghost_atoms_rank0": int(nall - nlocal),
             },
-            "timesteps_per_sec": args.steps / elapsed,
+            "pair_passes_per_sec": args.steps / elapsed,
             "verify_rel_err": verify_err,
             "roofline": {
                 "bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -266,6 +267,8 @@ def main():
                 "note": "algorithmic FLOP (SURVEY §8d formula) / kernel time; no MFMA by design",
             },
         }
+        if world == 1 and args.ts_steps > 0:
+            out["timestep"] = timestep_leg(args, shp, local_rank)
         if world == 1 and args.cpu_seconds > 0:
             out["cpu_baseline"] = cpu_baseline(args, shp, rmax, gbed, il, of, jl)
         print(json.dumps(out), flush=True)
@@ -273,6 +276,59 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def timestep_leg(args, shp, device):
+    """Whole device-resident timesteps per second (the second half of BASELINE.json's metric): NVE run of
+    a fully periodic dense bed of the same shapes — integrate, rebuild test, ghosts, pair forces, reverse,
+    integrate — everything through the C ABI (include/shstep.h), nothing on the host but launches."""
+    import torch
+    from shpair import ShPair, bed
+    from shpair.run import DeviceRun
+    sp = ShPair(device)
+    sp.settings(args.nq)
+    sp.set_ntypes(1, args.nshapes)
+    for s, a in enumerate(shp):
+        sp.set_shape(s, args.lmax, a)
+    sp.coeff("*", "*", 1000.0, args.exponent)
+    pts, lo, hi = bed.periodic_hcp(args.particles, 1.9, (1, 1, 1))
+    rng = np.random.default_rng(bed.SEED0 + 7)
+    n = pts.shape[0]
+    pts = pts + rng.uniform(-0.04, 0.04, pts.shape)
+    quat = bed.random_quaternions(n, rng)
+    shtype = rng.integers(0, args.nshapes, n).astype(np.int32) if args.nshapes > 1 else np.zeros(n, np.int32)
+    skin, dt = 0.1, 1.0e-3
+    run = DeviceRun(sp, pts, quat, shtype, lo, hi, (1, 1, 1), skin, dt=dt, device=f"cuda:{device}")
+    run.run(5)
+    sp.set_option("count", 1)
+    run.force()
+    torch.cuda.synchronize()
+    contact0 = sp.stats()["n_contact"]
+    sp.set_option("count", 0)
+    b0 = run.builds
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run.run(args.ts_steps)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    rebuilds = run.builds - b0
+    # cost of one rebuild (borders + bins + half list), timed on its own
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    run.rebuild()
+    torch.cuda.synchronize()
+    rebuild_ms = 1e3 * (time.perf_counter() - t1)
+    run.force(eflag=True)
+    pe, kt, kr, _ = run.energies()
+    out = {"timesteps_per_s": args.ts_steps / el, "ms_per_step": 1e3 * el / args.ts_steps, "steps": args.ts_steps,
+           "particles": int(n), "ghosts": int(run.nghost), "half_list_pairs": int(run.npairs),
+           "contact_pairs": int(contact0), "particle_steps_per_s": n * args.ts_steps / el,
+           "rebuilds_in_timed_steps": int(rebuilds), "rebuild_ms": rebuild_ms, "dt": dt, "skin": skin,
+           "periodic": [1, 1, 1], "energy": {"contact": pe, "ke_trans": kt, "ke_rot": kr},
+           "what": "initial_integrate + rebuild test + forward + clear + pair compute + reverse + final_integrate, "
+                   "all arrays resident in HBM (shpair.run.DeviceRun over include/shpair.h + include/shstep.h)"}
+    sp.close()
+    return out
 
 
 def cpu_baseline(args, shp, rmax, gbed, il, of, jl):

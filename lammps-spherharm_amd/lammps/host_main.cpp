@@ -8,11 +8,15 @@
 //            per atom: x y z qw qx qy qz type shtype
 //            inum ; per row: i n j1 .. jn
 // usage: lammps_host <bed> <out> <nq> <kn> <exponent> <shape files...>
+// With LAMMPS_HOST_NSTEPS=<n> and LAMMPS_HOST_DT=<dt> in the environment it then runs n velocity-Verlet
+// steps with FixNVESH (fix nve/sh) from rest, the way Verlet::run orders them, and writes
+// x v quat angmom of the owned atoms to <out>.traj (ghost-free beds only: nghost = 0).
 #include <cstdio>
 #include <cstdlib>
 #include <string>
 #include <vector>
 
+#include "fix_nve_sh.h"
 #include "pair_sh.h"
 
 using namespace LAMMPS_NS;
@@ -107,5 +111,41 @@ int main(int argc, char **argv)
   for (int i = 0; i < nall; i++)
     fprintf(fp, "%.17g %.17g %.17g %.17g %.17g %.17g\n", f[i][0], f[i][1], f[i][2], tq[i][0], tq[i][1], tq[i][2]);
   fclose(fp);
+
+  const char *ns = getenv("LAMMPS_HOST_NSTEPS");
+  if (ns && atoi(ns) > 0 && nghost == 0) {
+    const int nsteps = atoi(ns);
+    const char *dts = getenv("LAMMPS_HOST_DT");
+    lmp.update->dt = dts ? atof(dts) : 1e-3;
+    double **v, **angmom;
+    mem.create(v, nall, 3, "v");
+    mem.create(angmom, nall, 3, "angmom");
+    std::vector<int> mask(nall, 1);
+    atom->v = v;
+    atom->angmom = angmom;
+    atom->mask = mask.data();
+    lmp.force->pair = &pair;
+    std::string a0 = "1", a1 = "all", a2 = "nve/sh", a3 = "density", a4 = "1.5";
+    char *fargs[5] = {a0.data(), a1.data(), a2.data(), a3.data(), a4.data()};
+    FixNVESH fix(&lmp, 5, fargs);
+    if (fix.setmask() != (FixConst::INITIAL_INTEGRATE | FixConst::FINAL_INTEGRATE)) return 5;
+    fix.init();
+    // f, tq hold the forces of the current positions (second compute above)
+    for (int step = 0; step < nsteps; step++) {
+      fix.initial_integrate(0);
+      for (int i = 0; i < nall; i++)
+        for (int a = 0; a < 3; a++) f[i][a] = tq[i][a] = 0.0;
+      pair.compute(0, 0);
+      fix.final_integrate();
+    }
+    std::string tr = std::string(argv[2]) + ".traj";
+    fp = fopen(tr.c_str(), "w");
+    if (!fp) return 4;
+    for (int i = 0; i < nlocal; i++)
+      fprintf(fp, "%.17g %.17g %.17g %.17g %.17g %.17g %.17g %.17g %.17g %.17g %.17g %.17g %.17g\n", x[i][0], x[i][1],
+              x[i][2], v[i][0], v[i][1], v[i][2], quat[i][0], quat[i][1], quat[i][2], quat[i][3], angmom[i][0],
+              angmom[i][1], angmom[i][2]);
+    fclose(fp);
+  }
   return 0;
 }

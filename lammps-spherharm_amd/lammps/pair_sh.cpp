@@ -280,5 +280,6 @@ void *PairSH::extract(const char *str, int &dim)
   if (strcmp(str, "exponent") == 0) return (void *) exponent;
   dim = 0;
   if (strcmp(str, "nq") == 0) return (void *) &nq;
+  if (strcmp(str, "ctx") == 0) return (void *) ctx;    // shared with fix nve/sh
   return nullptr;
 }

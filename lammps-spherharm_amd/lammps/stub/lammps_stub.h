@@ -53,8 +53,9 @@ class Memory {
 class Atom {
  public:
   int ntypes = 1, nlocal = 0, nghost = 0;
-  double **x = nullptr, **f = nullptr, **torque = nullptr;
-  int *type = nullptr;
+  double **x = nullptr, **f = nullptr, **torque = nullptr, **v = nullptr, **angmom = nullptr;
+  int *type = nullptr, *mask = nullptr;
+  int firstgroup = -1, nfirst = 0;
   int **iarray = nullptr;
   int **ivector = nullptr;      // custom per-atom int vectors
   double ***darray = nullptr;   // custom per-atom double arrays
@@ -78,9 +79,12 @@ class Atom {
   }
 };
 
+class Pair;
 class Force {
  public:
   int newton_pair = 1;
+  Pair *pair = nullptr;
+  Pair *pair_match(const char *, int) { return pair; }
   void bounds(const char *, int, char *str, int nmax, int &nlo, int &nhi)
   {
     if (strcmp(str, "*") == 0) {
@@ -113,6 +117,7 @@ class Comm {
 class Update {
  public:
   bigint ntimestep = 0;
+  double dt = 0.005;
 };
 
 class LAMMPS {
@@ -186,6 +191,22 @@ class Pair : protected Pointers {
     eng_vdwl = eng_coul = 0.0;
     for (double &v : virial) v = 0.0;
   }
+};
+
+namespace FixConst {
+enum { INITIAL_INTEGRATE = 1 << 0, POST_FORCE = 1 << 4, FINAL_INTEGRATE = 1 << 5 };
+}
+
+class Fix : protected Pointers {
+ public:
+  int igroup = 0, groupbit = 1;
+  int time_integrate = 0;
+  Fix(LAMMPS *p, int, char **) : Pointers(p) {}
+  virtual int setmask() = 0;
+  virtual void init() {}
+  virtual void initial_integrate(int) {}
+  virtual void final_integrate() {}
+  virtual void reset_dt() {}
 };
 
 }    // namespace LAMMPS_NS

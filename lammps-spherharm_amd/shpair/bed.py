@@ -79,3 +79,26 @@ def half_neighbor_list(x, shtype, rmax_by_shape, skin=0.1, nlocal=None, owner_ru
     np.cumsum(counts, out=offsets[1:])
     ilist = np.arange(nlocal, dtype=np.int32)
     return ilist, offsets, b.astype(np.int32)
+
+
+def periodic_hcp(n_target, spacing, periodic=(1, 1, 1)):
+    """~n_target HCP sites in a box commensurate with the lattice in the periodic directions.
+
+    Returns (points, lo, hi).  Layers repeat every 2 in y and z, so ny and nz are even; the box spans
+    exactly nx dx, ny dy, nz dz in periodic directions and leaves half a spacing of room in the others."""
+    dx, dy, dz = spacing, spacing * np.sqrt(3.0) / 2.0, spacing * np.sqrt(2.0 / 3.0)
+    s = (n_target * dx * dy * dz) ** (1.0 / 3.0)
+    nx = max(2, int(round(s / dx)))
+    ny = max(2, 2 * int(round(s / dy / 2)))
+    nz = max(2, 2 * int(round(n_target / (nx * ny) / 2)))
+    k, j, i = np.meshgrid(np.arange(nz), np.arange(ny), np.arange(nx), indexing="ij")
+    x = (i + 0.5 * (j % 2) + 0.5 * (k % 2)) * dx
+    y = (j + (k % 2) / 3.0) * dy
+    z = k * dz
+    pts = np.stack([x.ravel(), y.ravel(), z.ravel()], axis=1) + 0.25 * spacing
+    ext = np.array([nx * dx, ny * dy, nz * dz])
+    lo = np.zeros(3)
+    per = np.array(periodic, bool)
+    hi = np.where(per, ext, ext + spacing)
+    pts[:, per] = np.mod(pts[:, per], ext[per])
+    return pts, lo, hi

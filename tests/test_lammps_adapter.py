@@ -89,3 +89,44 @@ def test_pairsh_adapter_matches_oracle(tmp_path, oracle, newton, expo):
     assert np.abs(ft[:, 3:] - o["torque"]).max() < 1e-9 * max(fs, np.abs(o["torque"]).max())
     assert abs(e1 - o["eng_virial"][0]) < 1e-9 * o["eng_virial"][0] and abs(e2 - e1) < 1e-11 * e1
     assert np.abs(vir - o["eng_virial"][1:]).max() < 1e-9 * np.abs(o["eng_virial"][1:]).max()
+
+
+@pytest.mark.gpu
+def test_fix_nve_sh_adapter_matches_oracle(tmp_path, oracle):
+    """FixNVESH + PairSH stepped by the C++ host in Verlet::run order from rest, against the same steps
+    made of oracle pieces (sho_compute + sho_nve)."""
+    build_host()
+    case = make_case(200, 4, 2, seed=33, rmax_fn=oracle.shape_rmax)
+    n = case["n"]
+    bedf, shapes = write_inputs(tmp_path, case, n, True, False)
+    out = tmp_path / "out.txt"
+    nsteps, dt, rho = 4, 2e-3, 1.5
+    env = dict(os.environ, LAMMPS_HOST_NSTEPS=str(nsteps), LAMMPS_HOST_DT=repr(dt))
+    r = subprocess.run([HOST, bedf, str(out), "8", "500.0", "1.25", *shapes], capture_output=True, text=True, env=env,
+                       timeout=300)
+    assert r.returncode == 0, r.stderr
+    traj = np.loadtxt(str(out) + ".traj")
+    b = case["bed"]
+    K, E = coeff_tables(1, 500.0, 1.25)
+    mp = np.array([oracle.mass_props(case["lmax"], a) for a in case["shapes"]])
+    # `density 1.5` names one value: shape 0 gets it, shape 1 keeps the default 1
+    dens = np.array([rho, 1.0])
+    x, q = b["x"].copy(), b["quat"].copy()
+    v, L = np.zeros((n, 3)), np.zeros((n, 3))
+    mask = np.ones(n, dtype=np.int32)
+    sh_list = [(case["lmax"], a, rm) for a, rm in zip(case["shapes"], case["rmax"])]
+
+    def force():
+        o = oracle.compute(sh_list, K, E, 8, n, x, q, b["type"], b["shtype"], case["ilist"], case["offsets"], case["jlist"],
+                           nthreads=8)
+        return o["f"], o["torque"]
+    f, t = force()
+    for _ in range(nsteps):
+        oracle.nve(0, dt, mp, dens, x, v, q, L, f, t, b["shtype"], mask)
+        f, t = force()
+        oracle.nve(1, dt, mp, dens, x, v, q, L, f, t, b["shtype"], mask)
+    assert np.abs(v).max() > 1e-3
+    assert np.abs(traj[:, 0:3] - x).max() < 1e-12
+    assert np.abs(traj[:, 3:6] - v).max() < 1e-10 * np.abs(v).max()
+    assert np.abs(traj[:, 6:10] - q).max() < 1e-12
+    assert np.abs(traj[:, 10:13] - L).max() < 1e-10 * np.abs(L).max()
