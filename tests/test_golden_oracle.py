@@ -6,11 +6,12 @@ import numpy as np
 import pytest
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-GOLDEN = sorted(glob.glob(os.path.join(HERE, "golden", "*.npz")))
+GOLDEN = sorted(glob.glob(os.path.join(HERE, "golden", "cfg*.npz")))
+SETTLED = os.path.join(HERE, "golden", "settled_cfg1_L4.npz")
 
 
 def test_fixtures_exist():
-    assert len(GOLDEN) == 4
+    assert len(GOLDEN) == 4 and os.path.exists(SETTLED)
 
 
 @pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p)[:-4] for p in GOLDEN])
@@ -30,3 +31,27 @@ def test_oracle_reproduces_golden(oracle, path):
     assert np.array_equal(o["counts"], g["counts"])
     for s, (a, r) in enumerate(zip(g["anm"], g["rmax"])):
         assert abs(oracle.shape_rmax(lmax, a) - r) < 1e-14
+
+
+def test_oracle_reproduces_settled_bed(oracle):
+    """BASELINE configs[0]: the gravity-settled L = 4 bed (tests/golden/make_settled.py): ghosts, half list,
+    forces, torques and energy from the oracle pieces equal the committed numbers, and the bed is a bed."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_settled", os.path.join(HERE, "golden", "make_settled.py"))
+    ms = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ms)
+    g = np.load(SETTLED)
+    e = ms.expected(g)
+    assert np.array_equal(e["ghost_owner"], g["ghost_owner"]) and np.array_equal(e["ghost_shift"], g["ghost_shift"])
+    assert np.array_equal(e["offsets"], g["offsets"]) and np.array_equal(e["jlist"], g["jlist"])
+    fs = np.abs(g["f"]).max()
+    assert np.abs(e["f"] - g["f"]).max() < 1e-12 * fs
+    assert np.abs(e["torque"] - g["torque"]).max() < 1e-12 * fs
+    assert abs(e["energy"] - g["energy"]) < 1e-12 * g["energy"]
+    # physical sanity of the inputs: 1000 mobile particles resting on the floor, weight carried by contacts
+    nm = int(g["nmobile"])
+    assert nm == 1000 and g["x"].shape[0] == 1400
+    assert g["x"][:nm, 2].min() > 0.3 and g["x"][:nm, 2].max() < 6.0
+    w = float(g["mass"]) * abs(g["gravity"][2])
+    fz = g["f"][:nm, 2].sum()
+    assert abs(fz - nm * w) < 0.02 * nm * w          # the floor carries the bed

@@ -18,7 +18,7 @@ from common import make_case, coeff_tables, oracle_compute, rel_err
 pytestmark = pytest.mark.gpu
 TOL = 1e-9
 HERE = os.path.dirname(os.path.abspath(__file__))
-GOLDEN = sorted(glob.glob(os.path.join(HERE, "golden", "*.npz")))
+GOLDEN = sorted(glob.glob(os.path.join(HERE, "golden", "cfg*.npz")))
 
 
 def make_ctx(case, nq, K, E, rmax=None):

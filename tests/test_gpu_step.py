@@ -404,3 +404,43 @@ def test_periodic_nve_conserves_momentum_and_energy(oracle):
     assert abs(pe0b - pe0) < 1e-12 * pe0                  # atomics: summation order differs run to run
     assert abs((pe1b + ke1b) - (pe1 + ke1)) < 3e-4 * pe0     # halving dt changes the total by far less than that
     sp.close()
+
+
+def test_settled_bed_fixture_through_the_device_pipeline():
+    """BASELINE configs[0] (gravity-settled L = 4 bed, tests/golden/settled_cfg1_L4.npz): ghosts and half list
+    built on the device, pair forces, reverse — against the oracle's committed numbers."""
+    import os
+    import torch
+    from shpair import ShPair
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "settled_cfg1_L4.npz"))
+    lmax, nq, n = int(g["lmax"]), int(g["nq"]), g["x"].shape[0]
+    sp = ShPair(0)
+    sp.settings(nq)
+    sp.set_ntypes(1, 1)
+    sp.set_shape(0, lmax, g["anm"][0])
+    sp.coeff(1, 1, float(g["kn"]), float(g["exponent"]))
+    assert abs(sp.rmax(0) - g["rmax"][0]) < 1e-14
+    sp.set_box(g["lo"], g["hi"], g["periodic"], float(g["skin"]))
+    case = dict(n=n, x=g["x"], quat=g["quat"], type=np.ones(n, np.int32), shtype=np.zeros(n, np.int32))
+    nmax = 3 * n
+    x, q, ty, sh = _device_rows(case, nmax)
+    ng = sp.borders_device(n, nmax, x.data_ptr(), q.data_ptr(), ty.data_ptr(), sh.data_ptr())
+    assert ng == g["ghost_owner"].size
+    npairs = sp.neighbor_build_device(n, ng, x.data_ptr(), sh.data_ptr())
+    offs, jl = sp.copy_neighbors(n, npairs)
+    assert np.array_equal(offs, g["offsets"]) and np.array_equal(jl, g["jlist"])
+    f = torch.zeros(nmax, 3, dtype=torch.float64, device="cuda:0")
+    tq = torch.zeros_like(f)
+    ev = torch.zeros(7, dtype=torch.float64, device="cuda:0")
+    sp.set_option("count", 1)
+    sp.compute_device(n, ng, x.data_ptr(), q.data_ptr(), ty.data_ptr(), sh.data_ptr(), f.data_ptr(), tq.data_ptr(),
+                      eflag=True, ev=ev.data_ptr())
+    sp.reverse_device(f.data_ptr(), tq.data_ptr())
+    torch.cuda.synchronize()
+    st = sp.stats()
+    assert [st["n_candidates"], st["n_contact"], st["n_touching"]] == g["counts"].tolist()
+    fs = np.abs(g["f"]).max()
+    assert np.abs(f[:n].cpu().numpy() - g["f"]).max() < 1e-9 * fs
+    assert np.abs(tq[:n].cpu().numpy() - g["torque"]).max() < 1e-9 * max(fs, np.abs(g["torque"]).max())
+    assert abs(ev[0].item() - float(g["energy"])) < 1e-9 * float(g["energy"])
+    sp.close()
