@@ -444,3 +444,66 @@ def test_settled_bed_fixture_through_the_device_pipeline():
     assert np.abs(tq[:n].cpu().numpy() - g["torque"]).max() < 1e-9 * max(fs, np.abs(g["torque"]).max())
     assert abs(ev[0].item() - float(g["energy"])) < 1e-9 * float(g["energy"])
     sp.close()
+
+
+def test_half_list_with_explicit_tags_and_atoms_outside_an_open_box(oracle):
+    """Tags decide which particle of a pair is the integrated one (not the row index); in non-periodic
+    directions particles beyond the box are clamped into the boundary cells and still find their pairs."""
+    import torch
+    case = _periodic_case(oracle, 512, (1, 0, 0), 64, nshapes=2)
+    n = case["n"]
+    rng = np.random.default_rng(5)
+    case["x"][rng.choice(n, 40, replace=False), 1] += rng.uniform(3.0, 9.0, 40)      # beyond hi in the open y direction
+    case["x"][rng.choice(n, 40, replace=False), 2] -= rng.uniform(3.0, 9.0, 40)      # below lo in z
+    tag0 = rng.permutation(n).astype(np.int32) + 1000
+    sp = make_ctx(case["shapes"], case["lmax"])
+    sp.set_box(case["lo"], case["hi"], case["periodic"], case["skin"])
+    nmax = 3 * n
+    x, q, ty, sh = _device_rows(case, nmax)
+    tag = torch.zeros(nmax, dtype=torch.int32, device="cuda:0")
+    tag[:n] = dev(tag0)
+    ng = sp.borders_device(n, nmax, x.data_ptr(), q.data_ptr(), ty.data_ptr(), sh.data_ptr(), tag=tag.data_ptr())
+    cmax = 2 * case["rmax"].max() + case["skin"]
+    xw = case["x"].copy()
+    own, shift = oracle.borders(xw, case["lo"], case["hi"], case["periodic"], cmax)
+    assert ng == own.size and ng > 0
+    tags = np.concatenate([tag0, tag0[own]])
+    assert np.array_equal(tag[: n + ng].cpu().numpy(), tags)
+    npairs = sp.neighbor_build_device(n, ng, x.data_ptr(), sh.data_ptr(), tag=tag.data_ptr())
+    offs, jl = sp.copy_neighbors(n, npairs)
+    sha = np.concatenate([case["shtype"], case["shtype"][own]])
+    o_offs, o_jl = oracle.half_list(n, x[: n + ng].cpu().numpy(), sha, tags, case["rmax"], case["skin"])
+    assert np.array_equal(offs, o_offs) and np.array_equal(jl, o_jl) and npairs > n
+    sp.close()
+
+
+def test_step_entry_points_with_no_particles_and_far_wraps(oracle):
+    import torch
+    case = _periodic_case(oracle, 216, (1, 1, 1), 65)
+    n = case["n"]
+    sp = make_ctx(case["shapes"], case["lmax"])
+    sp.set_box(case["lo"], case["hi"], (1, 1, 1), case["skin"])
+    # empty system: every entry point is a no-op that succeeds
+    z = torch.zeros(8, 4, dtype=torch.float64, device="cuda:0")
+    zi = torch.zeros(8, dtype=torch.int32, device="cuda:0")
+    assert sp.borders_device(0, 8, z.data_ptr(), z.data_ptr(), zi.data_ptr(), zi.data_ptr()) == 0
+    assert sp.neighbor_build_device(0, 0, z.data_ptr(), zi.data_ptr()) == 0
+    assert not sp.neighbor_check_device(0, z.data_ptr())
+    sp.forward_device(z.data_ptr(), z.data_ptr())
+    sp.reverse_device(z.data_ptr(), z.data_ptr())
+    sp.nve_device(0, 0, 1e-3, *([z.data_ptr()] * 6), zi.data_ptr(), zi.data_ptr())
+    sp.post_force_device(0, [0, 0, -1], 0.0, 0.0, z.data_ptr(), z.data_ptr(), z.data_ptr(), zi.data_ptr(), zi.data_ptr(),
+                         z.data_ptr(), z.data_ptr())
+    sp.compute_device(0, 0, z.data_ptr(), z.data_ptr(), zi.data_ptr(), zi.data_ptr(), z.data_ptr(), z.data_ptr())
+    torch.cuda.synchronize()
+    # particles several box lengths away are wrapped back in one go; the images agree with the oracle's
+    far = case["x"].copy()
+    far[:50] += case["box"] * np.array([3, -2, 5])
+    case2 = dict(case, x=far)
+    x, q, ty, sh = _device_rows(case2, 4 * n)
+    ng = sp.borders_device(n, 4 * n, x.data_ptr(), q.data_ptr(), ty.data_ptr(), sh.data_ptr())
+    xw = far.copy()
+    own, shift = oracle.borders(xw, case["lo"], case["hi"], (1, 1, 1), 2 * case["rmax"].max() + case["skin"])
+    assert ng == own.size
+    assert np.abs(x[:n].cpu().numpy() - xw).max() < 1e-12
+    sp.close()
