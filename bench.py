@@ -4,9 +4,10 @@
   python bench.py --gpus N --steps K --warmup W
   (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
-A "step" is one pass of the hot path over one synthetic bed resident in HBM:
-[forward halo exchange, N > 1] -> clear f/torque -> shpair_compute_device()
--> [reverse halo exchange, N > 1].  Workload at N = 1: BASELINE.json
+A "step" is one pass of the hot path over one synthetic bed resident in HBM,
+inside the two integrator half-steps that surround it in a timestep:
+initial_integrate -> [forward halo exchange, N > 1] -> clear f/torque ->
+shpair_compute_device() -> [reverse halo exchange, N > 1] -> final_integrate.  Workload at N = 1: BASELINE.json
 configs[1] — 100k particles, one L_max = 6 shape, dense packed bed, n_q = 16
 (Q = 512 cap nodes per pair), general force law (exponent 1.25, so the overlap
 volume root finder runs for every touching node).  N > 1: the same bed per
@@ -64,6 +65,9 @@ def parse():
     ap.add_argument("--verify", action="store_true",
                     help="N > 1: gather the owned forces and compare them with a single-domain compute of the "
                          "whole bed on rank 0 (small beds only)")
+    ap.add_argument("--ramp", type=int, default=8, help="extra untimed passes before the W warm-up steps: the first "
+                    "~8 launches of a fresh process run up to 25 %% slower while the GPU clock ramps (rocprof per-launch "
+                    "durations in profiles/); they are never part of the K timed steps")
     ap.add_argument("--ts-steps", type=int, default=40, help="steps of the whole-timestep leg (N = 1 only; 0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=16, help="OpenMP threads of the cpu_baseline leg "
                     "(16 = the host-core share of one GPU on the bench box)")
@@ -136,8 +140,20 @@ def main():
     f = torch.zeros(nall, 3, dtype=torch.float64, device=dev)
     tq = torch.zeros_like(f)
     stream = torch.cuda.current_stream()
+    # the integrator either side of the hot path (include/shstep.h): owned rows only.  The bed starts at
+    # rest and dt is sized so that nothing moves further than 1e-2 of the neighbour skin during the whole
+    # run: the half list (and the contact-pair count) stay valid without a rebuild.  --verify keeps dt = 0.
+    v = torch.zeros(nlocal, 3, dtype=torch.float64, device=dev)
+    angmom = torch.zeros_like(v)
+    mask = torch.ones(nlocal, dtype=torch.int32, device=dev)
+    dt = 0.0 if args.verify else min(1.0e-4, 4.0e-3 / (args.steps + args.warmup + args.ramp + 1))
+
+    def integrate(phase):
+        sp.nve_device(phase, nlocal, dt, x.data_ptr(), v.data_ptr(), q.data_ptr(), angmom.data_ptr(), f.data_ptr(),
+                      tq.data_ptr(), sh.data_ptr(), mask.data_ptr(), stream=stream.cuda_stream)
 
     def step():
+        integrate(0)
         if halo is not None:
             halo.forward(x, q)
         f.zero_()
@@ -146,6 +162,7 @@ def main():
                           f.data_ptr(), tq.data_ptr(), stream=stream.cuda_stream)
         if halo is not None:
             halo.reverse(f, tq)
+        integrate(1)
 
     # ---- untimed: count the contact pairs of this bed (static positions)
     sp.set_option("count", 1)
@@ -155,7 +172,7 @@ def main():
     n_contact, n_touching = st["n_contact"], st["n_touching"]
     sp.set_option("count", 0)
 
-    for _ in range(args.warmup):
+    for _ in range(args.ramp + args.warmup):
         step()
 
     # ---- timed region: exactly K steps between barrier + synchronize
@@ -166,6 +183,7 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for k in range(args.steps):
+        integrate(0)
         if halo is not None:
             halo.forward(x, q)
         f.zero_()
@@ -176,6 +194,7 @@ def main():
         ev[k][1].record(stream)
         if halo is not None:
             halo.reverse(f, tq)
+        integrate(1)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -233,7 +252,8 @@ def main():
         achieved_tf = fpp * n_contact / (kernel_ms * 1e-3) / 1e12
         out = {
             "metric": "contact_pairs_per_sec", "value": value, "unit": "contact-pairs/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ramp_passes": args.ramp,
+            "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic",
             "config": {
@@ -248,7 +268,10 @@ def main():
                 "touching_pairs_rank0": int(n_touching), "contact_pairs_all_ranks": int(contact_all),
                 "ghost_atoms_rank0": int(nall - nlocal),
             },
-            "pair_passes_per_sec": args.steps / elapsed,
+            "timesteps_per_sec": args.steps / elapsed,
+            "timestep_note": "one step = initial_integrate + [forward halo] + clear + pair compute + [reverse halo] + "
+                             f"final_integrate on every rank, dt = {dt:g} from rest, no list rebuild inside the timed "
+                             "steps (see the `timestep` object for whole steps with rebuilds at N = 1)",
             "verify_rel_err": verify_err,
             "roofline": {
                 "bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
