@@ -70,6 +70,8 @@ struct PairParams {
   const double* glw;    // nq weights
   const double* cpsi;   // 2nq cos(psi_l)
   const double* spsi;   // 2nq sin(psi_l)
+  const double* trig;   // per azimuth l: (cos m psi_l, sin m psi_l) for m = 2..lmax, trig_stride doubles per l
+  int trig_stride;      // 2 (lmax - 1), 0 if lmax < 2
   int nq;
   // outputs / flags
   double* ev;           // 7 doubles or null
@@ -335,8 +337,11 @@ __device__ __forceinline__ void cap_frame_rings(const PairParams& P, double* __r
 // r_i (and its mu / psi derivatives) at ring row `row`, azimuth (c1, s1) = (cos psi, sin psi)
 template <int L, bool GRAD>
 __device__ __forceinline__ void ring_eval(const double* __restrict__ row, const int LL, const double c1, const double s1,
-                                          double& r, double& rmu, double& rpsi)
+                                          const double* __restrict__ tr, double& r, double& rmu, double& rpsi)
 {
+  // cos/sin(m psi) of this lane's azimuth: compiled orders read them from the host-built table `tr`
+  // (m = 2..L, 16 bytes per m, vector memory loads that cost no VALU slot); the run-time-order kernel keeps
+  // the Chebyshev recurrence (4 FP64 operations per m).
   r = row[0];
   rmu = GRAD ? row[2] : 0.0;
   rpsi = 0.0;
@@ -344,6 +349,10 @@ __device__ __forceinline__ void ring_eval(const double* __restrict__ row, const 
   const int lim = (L >= 0) ? L : LL;
 #pragma unroll
   for (int m = 1; m <= lim; ++m) {
+    if (L >= 2 && m >= 2) {
+      cm = tr[2 * (m - 2)];
+      sm = tr[2 * (m - 2) + 1];
+    }
     const double A = row[4 * m], B = row[4 * m + 1];
     r = fma(A, cm, r);
     r = fma(B, sm, r);
@@ -354,7 +363,7 @@ __device__ __forceinline__ void ring_eval(const double* __restrict__ row, const 
       rpsi = fma(dm * B, cm, rpsi);
       rpsi = fma(-dm * A, sm, rpsi);
     }
-    if (m < lim) {
+    if (L < 2 && m < lim) {
       const double c = fma(cm, c1, -(sm * s1)), s = fma(cm, s1, sm * c1);
       cm = c;
       sm = s;
@@ -510,7 +519,7 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, SHP_MIN_WAVES) pair_co
       const double mu = row[1], sig = row[3];
       const double c1 = P.cpsi[l], s1 = P.spsi[l];
       double ri, t0, t1;
-      ring_eval<L, false>(row, LL, c1, s1, ri, t0, t1);
+      ring_eval<L, false>(row, LL, c1, s1, P.trig + l * P.trig_stride, ri, t0, t1);
       // the surface point seen from x_j, in j's body frame
       const double a1 = sig * c1, a2 = sig * s1;
       const double uj0 = fma(a1, fr[FR_BJ1], fma(a2, fr[FR_BJ2], mu * fr[FR_BJC]));
@@ -666,7 +675,7 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, SHP_MIN_WAVES) pair_co
     //   u = (sigma c, sigma s, mu), gamma^ = (mu c, mu s, -sigma), psi^ = (-s, c, 0)
     fr = SHP_LDS();
     double r2, rmu, rpsi;
-    ring_eval<L, true>(fr + W.ring + (k - k0) * rowlen, LL, c1, s1, r2, rmu, rpsi);
+    ring_eval<L, true>(fr + W.ring + (k - k0) * rowlen, LL, c1, s1, P.trig + l * P.trig_stride, r2, rmu, rpsi);
     const double rad = ri * fma(ri, sig, rmu * sig * mu);   // r (r sigma + sigma mu r_mu): multiplies (c, s)
     const double tan_ = ri * rpsi / sig;                   // (r / sigma) r_psi
     const double A0 = fma(rad, c1, tan_ * s1);

@@ -376,13 +376,15 @@ static int upload_tables(shpair_ctx* c)
   c->cstride = sh_chunk_stride(L);
   (void)T;
   c->tables_dirty = false;
+  c->quad_dirty = true;  // the cos/sin(m psi) table of upload_quadrature is sized by lmax
   return SHPAIR_OK;
 }
 
 static int upload_quadrature(shpair_ctx* c)
 {
   const int nq = c->nq, npsi = 2 * nq;
-  std::vector<double> t, w, q(2 * nq + 2 * npsi);
+  const int tstride = c->lmax >= 2 ? 2 * (c->lmax - 1) : 0;
+  std::vector<double> t, w, q(2 * nq + 2 * npsi + (size_t)npsi * tstride);
   gauss_legendre(nq, t, w);
   for (int k = 0; k < nq; ++k) {
     q[k] = t[k];
@@ -392,6 +394,10 @@ static int upload_quadrature(shpair_ctx* c)
     const double psi = 2.0 * 3.14159265358979323846264338327950288 * (l + 0.5) / npsi;
     q[2 * nq + l] = std::cos(psi);
     q[2 * nq + npsi + l] = std::sin(psi);
+    for (int m = 2; m <= c->lmax; ++m) {
+      q[2 * nq + 2 * npsi + (size_t)l * tstride + 2 * (m - 2)] = std::cos(m * psi);
+      q[2 * nq + 2 * npsi + (size_t)l * tstride + 2 * (m - 2) + 1] = std::sin(m * psi);
+    }
   }
   HIPCHK(c, hipStreamSynchronize(c->stream));
   HIPCHK(c, c->d_quad.ensure(q.size()));
@@ -436,6 +442,8 @@ int shpair_compute_device(shpair_ctx* c, int nlocal, int nghost, const double* x
   const int nq = c->nq;
   P.glt = c->d_quad.p; P.glw = c->d_quad.p + nq; P.cpsi = c->d_quad.p + 2 * nq; P.spsi = c->d_quad.p + 4 * nq;
   P.nq = nq;
+  P.trig = c->d_quad.p + 6 * nq;
+  P.trig_stride = c->lmax >= 2 ? 2 * (c->lmax - 1) : 0;
   P.creal = c->d_creal.p; P.xval = c->d_xval.p; P.xcol = c->d_xcol.p; P.xinfo = c->d_xinfo.p; P.gscale = c->d_gscale.p;
   {
     // Resident ring rows: all nq if a wave then needs <= 8 KB of LDS (five 4-wave workgroups per CU,
