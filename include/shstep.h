@@ -96,6 +96,32 @@ int shstep_neighbor_check_device(shpair_ctx *ctx, int nlocal, const double *x_de
  * (either may be NULL).  Blocks. */
 int shstep_copy_neighbors(shpair_ctx *ctx, int *offsets, int *jlist);
 
+/* ---- the whole loop, for a host that owns nothing but the arrays ----------- */
+
+/* Device pointers and scalars of one rank's particles; arrays sized for nmax rows (owned + ghosts) except
+ * v, angmom, mask (nlocal rows). */
+typedef struct shstep_arrays {
+  int nlocal, nmax;
+  double *x, *v, *quat, *angmom, *f, *torque;
+  int *type, *shtype, *mask;
+  int groupbit;
+  double dt;
+  double gravity[3], gamma_t, gamma_r; /* all zero: no post_force pass */
+  int check_every;                      /* rebuild test every this many steps (>= 1), neigh_modify every N check yes */
+} shstep_arrays;
+
+/* Verlet::run for nsteps: initial_integrate -> [rebuild test -> borders + neighbour build] -> forward ->
+ * clear -> pair compute -> reverse -> post_force -> final_integrate, entirely on `stream` (must not be
+ * NULL when use_graph is set: the legacy null stream cannot be captured).  On entry the ghosts / list
+ * of the current positions must exist (shstep_borders_device + shstep_neighbor_build_device) and f, torque
+ * must hold their forces (as after Verlet::setup); *nghost is the current ghost count and is updated.
+ * use_graph != 0: the launches of a step are replayed from two captured hipGraphs (re-captured after every
+ * rebuild) instead of being issued one by one — the launch-bound regime of small systems.
+ * Returns after the last step is enqueued and the stream is idle (blocks).  *rebuilds (nullable) counts
+ * the list rebuilds. */
+int shstep_run_device(shpair_ctx *ctx, const shstep_arrays *a, int nsteps, int use_graph, int *nghost, int *rebuilds,
+                      void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -406,6 +406,26 @@ static int upload_quadrature(shpair_ctx* c)
   return SHPAIR_OK;
 }
 
+}  // extern "C"
+
+// Uploads whatever table is stale (blocking copies): what shpair_compute_device() does on demand, callable
+// ahead of a stream capture in which such copies are not allowed (shstep_run_device).
+int shpair_prepare_tables(shpair_ctx* c)
+{
+  HIPCHK(c, hipSetDevice(c->device));
+  if (c->tables_dirty) {
+    const int rc = upload_tables(c);
+    if (rc) return rc;
+  }
+  if (c->quad_dirty) {
+    const int rc = upload_quadrature(c);
+    if (rc) return rc;
+  }
+  return SHPAIR_OK;
+}
+
+extern "C" {
+
 int shpair_compute_device(shpair_ctx* c, int nlocal, int nghost, const double* x, const double* quat, const int* type,
                           const int* shtype, int newton_pair, int eflag, int vflag, double* f, double* torque,
                           double* ev, void* stream)

@@ -88,6 +88,7 @@ struct shpair_ctx {
 
 void shstep_release_state(shpair_ctx* c);   // shstep_api.hip
 void shstep_invalidate_list(shpair_ctx* c);
+int shpair_prepare_tables(shpair_ctx* c);    // shpair_api.hip
 
 #define CTX_FAIL(ctx, code, ...)                         \
   do {                                                   \

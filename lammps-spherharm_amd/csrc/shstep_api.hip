@@ -500,3 +500,154 @@ int shstep_copy_neighbors(shpair_ctx* c, int* offsets, int* jlist)
 }
 
 }  // extern "C"
+
+namespace {
+struct StepGraphs {
+  hipGraphExec_t a = nullptr, b = nullptr;
+  void reset()
+  {
+    if (a) (void)hipGraphExecDestroy(a);
+    if (b) (void)hipGraphExecDestroy(b);
+    a = b = nullptr;
+  }
+};
+}  // namespace
+
+// segment A of a step: half kick + drift, and (when asked) the displacement test with its flag read-back
+static int enqueue_a(shpair_ctx* c, shstep_state* s, const shstep_arrays* a, bool with_check, hipStream_t st)
+{
+  RC(shstep_nve_device(c, 0, a->nlocal, a->dt, a->x, a->v, a->quat, a->angmom, a->f, a->torque, a->shtype, a->mask,
+                       a->groupbit, st));
+  if (with_check) {
+    const double trig = 0.5 * s->skin;
+    HIPCHK(c, hipMemsetAsync(s->d_flags.p + 1, 0, sizeof(int), st));
+    hipLaunchKernelGGL(check_distance_kernel, dim3(nblk(a->nlocal, kStepBlock)), dim3(kStepBlock), 0, st, a->nlocal,
+                       (const double*)a->x, (const double*)s->d_xhold.p, trig * trig, s->d_flags.p + 1);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(s->h_flags, s->d_flags.p, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
+  }
+  return SHPAIR_OK;
+}
+
+// segment B: ghosts, forces, second half kick
+static int enqueue_b(shpair_ctx* c, shstep_state* s, const shstep_arrays* a, int nghost, bool body, hipStream_t st)
+{
+  const size_t nall = (size_t)a->nlocal + nghost;
+  RC(shstep_forward_device(c, a->x, a->quat, st));
+  HIPCHK(c, hipMemsetAsync(a->f, 0, 3 * nall * sizeof(double), st));
+  HIPCHK(c, hipMemsetAsync(a->torque, 0, 3 * nall * sizeof(double), st));
+  RC(shpair_compute_device(c, a->nlocal, nghost, a->x, a->quat, a->type, a->shtype, 1, 0, 0, a->f, a->torque, nullptr, st));
+  RC(shstep_reverse_device(c, a->f, a->torque, st));
+  if (body)
+    RC(shstep_post_force_device(c, a->nlocal, a->gravity, a->gamma_t, a->gamma_r, a->v, a->quat, a->angmom, a->shtype,
+                                a->mask, a->groupbit, a->f, a->torque, st));
+  RC(shstep_nve_device(c, 1, a->nlocal, a->dt, a->x, a->v, a->quat, a->angmom, a->f, a->torque, a->shtype, a->mask,
+                       a->groupbit, st));
+  (void)s;
+  return SHPAIR_OK;
+}
+
+template <typename F>
+static int capture(shpair_ctx* c, hipStream_t st, hipGraphExec_t* out, F&& body)
+{
+  hipGraph_t g = nullptr;
+  HIPCHK(c, hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+  const int rc = body();
+  const hipError_t e = hipStreamEndCapture(st, &g);
+  if (rc) {
+    if (g) (void)hipGraphDestroy(g);
+    return rc;
+  }
+  if (e != hipSuccess) CTX_FAIL(c, SHPAIR_EHIP, "hipStreamEndCapture failed: %s", hipGetErrorString(e));
+  const hipError_t e2 = hipGraphInstantiate(out, g, nullptr, nullptr, 0);
+  (void)hipGraphDestroy(g);
+  if (e2 != hipSuccess) CTX_FAIL(c, SHPAIR_EHIP, "hipGraphInstantiate failed: %s", hipGetErrorString(e2));
+  return SHPAIR_OK;
+}
+
+extern "C" {
+
+int shstep_run_device(shpair_ctx* c, const shstep_arrays* a, int nsteps, int use_graph, int* nghost_io, int* rebuilds,
+                      void* stream)
+{
+  STEP_PROLOGUE(c);
+  if (rebuilds) *rebuilds = 0;
+  if (!a || !nghost_io || nsteps < 0) CTX_FAIL(c, SHPAIR_EINVAL, "null arguments or nsteps < 0");
+  if (a->nlocal < 0 || a->nmax < a->nlocal || a->check_every < 1 || !std::isfinite(a->dt))
+    CTX_FAIL(c, SHPAIR_EINVAL, "bad nlocal (%d) / nmax (%d) / check_every (%d) / dt", a->nlocal, a->nmax, a->check_every);
+  if (nsteps == 0 || a->nlocal == 0) return SHPAIR_OK;
+  if (!a->x || !a->v || !a->quat || !a->angmom || !a->f || !a->torque || !a->type || !a->shtype || !a->mask)
+    CTX_FAIL(c, SHPAIR_EINVAL, "null array pointer");
+  if (s->l_nlocal != a->nlocal || !c->have_neighbors || s->b_nlocal != a->nlocal || *nghost_io != s->nghost)
+    CTX_FAIL(c, SHPAIR_ESTATE, "run: ghosts and neighbour list of the current particles must be built first "
+             "(shstep_borders_device + shstep_neighbor_build_device)");
+  hipStream_t st = (hipStream_t)stream;
+  if (use_graph && !st) CTX_FAIL(c, SHPAIR_EINVAL, "run: graph replay needs an explicit stream (the null stream cannot be captured)");
+  if (use_graph && (c->opt_timing || c->opt_count)) CTX_FAIL(c, SHPAIR_ESTATE, "run: switch the timing / count options off for graph replay");
+  RC(refresh_mass(c, s));
+  RC(refresh_box(c, s));
+  RC(shpair_prepare_tables(c));
+  const bool body = a->gravity[0] != 0.0 || a->gravity[1] != 0.0 || a->gravity[2] != 0.0 || a->gamma_t != 0.0 || a->gamma_r != 0.0;
+  int nghost = *nghost_io, nreb = 0;
+  StepGraphs G;
+  hipGraphExec_t g_nocheck = nullptr;
+  int rc = SHPAIR_OK;
+  // the graphs hold kernel arguments (ghost and pair counts, the context's list and x-hold buffers): they
+  // are captured once and again after every rebuild
+  auto recapture = [&]() -> int {
+    G.reset();
+    if (g_nocheck) (void)hipGraphExecDestroy(g_nocheck);
+    g_nocheck = nullptr;
+    int r = capture(c, st, &G.a, [&] { return enqueue_a(c, s, a, true, st); });
+    if (!r && a->check_every > 1) r = capture(c, st, &g_nocheck, [&] { return enqueue_a(c, s, a, false, st); });
+    if (!r) r = capture(c, st, &G.b, [&] { return enqueue_b(c, s, a, nghost, body, st); });
+    return r;
+  };
+  auto launch = [&](hipGraphExec_t g) -> int {
+    const hipError_t e = hipGraphLaunch(g, st);
+    if (e != hipSuccess) {
+      c->err = std::string("hipGraphLaunch failed: ") + hipGetErrorString(e);
+      return SHPAIR_EHIP;
+    }
+    return SHPAIR_OK;
+  };
+  if (use_graph) rc = recapture();
+  for (int step = 0; step < nsteps && rc == SHPAIR_OK; ++step) {
+    const bool check = ((step + 1) % a->check_every) == 0;
+    rc = use_graph ? launch(check ? G.a : g_nocheck) : enqueue_a(c, s, a, check, st);
+    if (rc) break;
+    if (check) {
+      const hipError_t e = hipStreamSynchronize(st);
+      if (e != hipSuccess) {
+        c->err = std::string("hipStreamSynchronize failed: ") + hipGetErrorString(e);
+        rc = SHPAIR_EHIP;
+        break;
+      }
+      if (s->h_flags[0]) {
+        (void)hipMemsetAsync(s->d_flags.p, 0, sizeof(int), st);
+        c->err = "a shape index (shtype) outside the table reached a kernel; those particles were skipped";
+        rc = SHPAIR_EINVAL;
+        break;
+      }
+      if (s->h_flags[1]) {
+        int np = 0;
+        rc = shstep_borders_device(c, a->nlocal, a->nmax, a->x, a->quat, a->type, a->shtype, nullptr, &nghost, st);
+        if (!rc) rc = shstep_neighbor_build_device(c, a->nlocal, nghost, a->x, a->shtype, nullptr, &np, st);
+        if (!rc) ++nreb;
+        if (!rc && use_graph) rc = recapture();
+        if (rc) break;
+      }
+    }
+    rc = use_graph ? launch(G.b) : enqueue_b(c, s, a, nghost, body, st);
+  }
+  const hipError_t es = hipStreamSynchronize(st);
+  G.reset();
+  if (g_nocheck) (void)hipGraphExecDestroy(g_nocheck);
+  *nghost_io = nghost;
+  if (rebuilds) *rebuilds = nreb;
+  if (rc) return rc;
+  if (es != hipSuccess) CTX_FAIL(c, SHPAIR_EHIP, "hipStreamSynchronize failed: %s", hipGetErrorString(es));
+  return SHPAIR_OK;
+}
+
+}  // extern "C"

@@ -28,6 +28,15 @@ class Stats(C.Structure):
                 ("kernel_ms", C.c_double), ("total_ms", C.c_double)]
 
 
+class StepArrays(C.Structure):
+    """shstep_arrays of include/shstep.h."""
+    _fields_ = [("nlocal", C.c_int), ("nmax", C.c_int),
+                ("x", C.c_void_p), ("v", C.c_void_p), ("quat", C.c_void_p), ("angmom", C.c_void_p), ("f", C.c_void_p),
+                ("torque", C.c_void_p), ("type", C.c_void_p), ("shtype", C.c_void_p), ("mask", C.c_void_p),
+                ("groupbit", C.c_int), ("dt", C.c_double), ("gravity", C.c_double * 3), ("gamma_t", C.c_double),
+                ("gamma_r", C.c_double), ("check_every", C.c_int)]
+
+
 # every symbol include/shpair.h declares: name -> (restype, argtypes)
 SYMBOLS = {
     "shpair_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int]),
@@ -73,6 +82,7 @@ SYMBOLS = {
                                                C.c_void_p]),
     "shstep_neighbor_check_device": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, _ip, C.c_void_p]),
     "shstep_copy_neighbors": (C.c_int, [C.c_void_p, _ip, _ip]),
+    "shstep_run_device": (C.c_int, [C.c_void_p, C.POINTER(StepArrays), C.c_int, C.c_int, _ip, _ip, C.c_void_p]),
 }
 
 
@@ -351,3 +361,11 @@ class ShPair:
         jl = np.zeros(max(npairs, 1), dtype=np.int32)
         self._chk(self._lib.shstep_copy_neighbors(self._h, offs.ctypes.data_as(_ip), jl.ctypes.data_as(_ip)))
         return offs, jl[:npairs]
+
+    def run_device(self, arrays, nsteps, nghost, use_graph=False, stream=None):
+        """shstep_run_device: the whole loop in the library. Returns (nghost, rebuilds). Blocks."""
+        ng = C.c_int(int(nghost))
+        nr = C.c_int(0)
+        self._chk(self._lib.shstep_run_device(self._h, C.byref(arrays), int(nsteps), int(bool(use_graph)), C.byref(ng),
+                                              C.byref(nr), stream))
+        return ng.value, nr.value

@@ -96,6 +96,23 @@ class DeviceRun:
         for k in range(nsteps):
             self.step(eflag=eflag_last and k == nsteps - 1)
 
+    def run_native(self, nsteps, use_graph=False, check_every=1):
+        """The same loop inside the library (shstep_run_device): C++ host code, optionally replayed from
+        captured hipGraphs — for small, launch-bound systems.  Runs on the context's own stream."""
+        from .capi import StepArrays
+        a = StepArrays()
+        a.nlocal, a.nmax = self.n, self.nmax
+        a.x, a.v, a.quat, a.angmom = self.x.data_ptr(), self.v.data_ptr(), self.q.data_ptr(), self.L.data_ptr()
+        a.f, a.torque = self.f.data_ptr(), self.tq.data_ptr()
+        a.type, a.shtype, a.mask = self.ty.data_ptr(), self.sh.data_ptr(), self.mask.data_ptr()
+        a.groupbit, a.dt = self.groupbit, self.dt
+        a.gravity = (self.g[0], self.g[1], self.g[2])
+        a.gamma_t, a.gamma_r, a.check_every = self.gamma_t, self.gamma_r, int(check_every)
+        torch.cuda.synchronize()          # everything enqueued on torch's stream is visible to the context's stream
+        self.nghost, nreb = self.sp.run_device(a, nsteps, self.nghost, use_graph=use_graph, stream=self.sp.own_stream())
+        self.builds += nreb
+        self.steps += nsteps
+
     def energies(self):
         """(contact energy of the last eflag force call, translational KE, rotational KE, gravitational PE)."""
         self.en.zero_()

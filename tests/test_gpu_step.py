@@ -507,3 +507,46 @@ def test_step_entry_points_with_no_particles_and_far_wraps(oracle):
     assert ng == own.size
     assert np.abs(x[:n].cpu().numpy() - xw).max() < 1e-12
     sp.close()
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_native_run_loop_matches_the_python_driver(oracle, use_graph):
+    """shstep_run_device (C++ loop in the library, optionally replayed from hipGraphs) takes the same steps as
+    the call-by-call driver: same rebuild decisions, same trajectory (forces are atomically summed, so
+    equality is to rounding, not bitwise)."""
+    from shpair.run import DeviceRun
+    case = _periodic_case(oracle, 512, (1, 1, 0), 66, lmax=4, nshapes=2, skin=0.2, jitter=0.15)
+    runs = []
+    for native in (False, True):
+        sp = make_ctx(case["shapes"], case["lmax"], nq=8, kn=300.0, expo=1.25, rho=[1.0, 1.4])
+        r = DeviceRun(sp, case["x"], case["quat"], case["shtype"], case["lo"], case["hi"], case["periodic"], case["skin"],
+                      dt=2e-3, gravity=(0.0, 0.0, -2.0), gamma_t=0.3, gamma_r=0.1)
+        if native:
+            r.run_native(120, use_graph=use_graph)
+        else:
+            r.run(120)
+        r.force(eflag=True)
+        runs.append((r, sp, r.energies()))
+    (a, spa, ea), (b, spb, eb) = runs
+    n = case["n"]
+    assert a.builds == b.builds and a.builds >= 3 and a.nghost == b.nghost
+    assert np.abs(a.x[:n].cpu().numpy() - b.x[:n].cpu().numpy()).max() < 1e-10
+    assert np.abs(a.v.cpu().numpy() - b.v.cpu().numpy()).max() < 1e-9
+    assert np.abs(a.q[:n].cpu().numpy() - b.q[:n].cpu().numpy()).max() < 1e-10
+    assert abs(ea[0] - eb[0]) < 1e-9 * abs(ea[0]) and abs(ea[1] - eb[1]) < 1e-8 * abs(ea[1])
+    spa.close()
+    spb.close()
+
+
+def test_native_run_loop_argument_checks(oracle):
+    from shpair.capi import ShPairError, StepArrays
+    case = _periodic_case(oracle, 216, (1, 1, 1), 67)
+    sp = make_ctx(case["shapes"], case["lmax"])
+    a = StepArrays()
+    a.nlocal, a.nmax, a.check_every, a.dt = 10, 20, 1, 1e-3
+    with pytest.raises(ShPairError):                  # null arrays
+        sp.run_device(a, 5, 0)
+    a.check_every = 0
+    with pytest.raises(ShPairError):
+        sp.run_device(a, 5, 0)
+    sp.close()
