@@ -70,8 +70,9 @@ struct PairParams {
   const double* glw;    // nq weights
   const double* cpsi;   // 2nq cos(psi_l)
   const double* spsi;   // 2nq sin(psi_l)
-  const double* trig;   // per azimuth l: (cos m psi_l, sin m psi_l) for m = 2..lmax, trig_stride doubles per l
-  int trig_stride;      // 2 (lmax - 1), 0 if lmax < 2
+  const double* trig;   // (cos m psi_l, sin m psi_l) at trig[(m - 2) * trig_stride + 2 l], m = 2..lmax: for one m the
+                        // lanes of a wave read consecutive 16-byte entries (4 cache lines per load, not 20)
+  int trig_stride;      // 4 nq doubles between consecutive m
   int nq;
   // outputs / flags
   double* ev;           // 7 doubles or null
@@ -337,7 +338,8 @@ __device__ __forceinline__ void cap_frame_rings(const PairParams& P, double* __r
 // r_i (and its mu / psi derivatives) at ring row `row`, azimuth (c1, s1) = (cos psi, sin psi)
 template <int L, bool GRAD>
 __device__ __forceinline__ void ring_eval(const double* __restrict__ row, const int LL, const double c1, const double s1,
-                                          const double* __restrict__ tr, double& r, double& rmu, double& rpsi)
+                                          const double* __restrict__ tr, const int tstride, double& r, double& rmu,
+                                          double& rpsi)
 {
   // cos/sin(m psi) of this lane's azimuth: compiled orders read them from the host-built table `tr`
   // (m = 2..L, 16 bytes per m, vector memory loads that cost no VALU slot); the run-time-order kernel keeps
@@ -350,8 +352,8 @@ __device__ __forceinline__ void ring_eval(const double* __restrict__ row, const 
 #pragma unroll
   for (int m = 1; m <= lim; ++m) {
     if (L >= 2 && m >= 2) {
-      cm = tr[2 * (m - 2)];
-      sm = tr[2 * (m - 2) + 1];
+      cm = tr[(m - 2) * tstride];
+      sm = tr[(m - 2) * tstride + 1];
     }
     const double A = row[4 * m], B = row[4 * m + 1];
     r = fma(A, cm, r);
@@ -519,7 +521,7 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, SHP_MIN_WAVES) pair_co
       const double mu = row[1], sig = row[3];
       const double c1 = P.cpsi[l], s1 = P.spsi[l];
       double ri, t0, t1;
-      ring_eval<L, false>(row, LL, c1, s1, P.trig + l * P.trig_stride, ri, t0, t1);
+      ring_eval<L, false>(row, LL, c1, s1, P.trig + 2 * l, P.trig_stride, ri, t0, t1);
       // the surface point seen from x_j, in j's body frame
       const double a1 = sig * c1, a2 = sig * s1;
       const double uj0 = fma(a1, fr[FR_BJ1], fma(a2, fr[FR_BJ2], mu * fr[FR_BJC]));
@@ -675,7 +677,7 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, SHP_MIN_WAVES) pair_co
     //   u = (sigma c, sigma s, mu), gamma^ = (mu c, mu s, -sigma), psi^ = (-s, c, 0)
     fr = SHP_LDS();
     double r2, rmu, rpsi;
-    ring_eval<L, true>(fr + W.ring + (k - k0) * rowlen, LL, c1, s1, P.trig + l * P.trig_stride, r2, rmu, rpsi);
+    ring_eval<L, true>(fr + W.ring + (k - k0) * rowlen, LL, c1, s1, P.trig + 2 * l, P.trig_stride, r2, rmu, rpsi);
     const double rad = ri * fma(ri, sig, rmu * sig * mu);   // r (r sigma + sigma mu r_mu): multiplies (c, s)
     const double tan_ = ri * rpsi / sig;                   // (r / sigma) r_psi
     const double A0 = fma(rad, c1, tan_ * s1);

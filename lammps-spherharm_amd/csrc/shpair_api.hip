@@ -383,8 +383,8 @@ static int upload_tables(shpair_ctx* c)
 static int upload_quadrature(shpair_ctx* c)
 {
   const int nq = c->nq, npsi = 2 * nq;
-  const int tstride = c->lmax >= 2 ? 2 * (c->lmax - 1) : 0;
-  std::vector<double> t, w, q(2 * nq + 2 * npsi + (size_t)npsi * tstride);
+  const int nm = c->lmax >= 2 ? c->lmax - 1 : 0;  // orders m = 2..lmax of the cos/sin(m psi) table, m-major
+  std::vector<double> t, w, q(2 * nq + 2 * npsi + (size_t)nm * 2 * npsi);
   gauss_legendre(nq, t, w);
   for (int k = 0; k < nq; ++k) {
     q[k] = t[k];
@@ -395,8 +395,8 @@ static int upload_quadrature(shpair_ctx* c)
     q[2 * nq + l] = std::cos(psi);
     q[2 * nq + npsi + l] = std::sin(psi);
     for (int m = 2; m <= c->lmax; ++m) {
-      q[2 * nq + 2 * npsi + (size_t)l * tstride + 2 * (m - 2)] = std::cos(m * psi);
-      q[2 * nq + 2 * npsi + (size_t)l * tstride + 2 * (m - 2) + 1] = std::sin(m * psi);
+      q[2 * nq + 2 * npsi + ((size_t)(m - 2) * npsi + l) * 2] = std::cos(m * psi);
+      q[2 * nq + 2 * npsi + ((size_t)(m - 2) * npsi + l) * 2 + 1] = std::sin(m * psi);
     }
   }
   HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -463,7 +463,7 @@ int shpair_compute_device(shpair_ctx* c, int nlocal, int nghost, const double* x
   P.glt = c->d_quad.p; P.glw = c->d_quad.p + nq; P.cpsi = c->d_quad.p + 2 * nq; P.spsi = c->d_quad.p + 4 * nq;
   P.nq = nq;
   P.trig = c->d_quad.p + 6 * nq;
-  P.trig_stride = c->lmax >= 2 ? 2 * (c->lmax - 1) : 0;
+  P.trig_stride = 4 * nq;
   P.creal = c->d_creal.p; P.xval = c->d_xval.p; P.xcol = c->d_xcol.p; P.xinfo = c->d_xinfo.p; P.gscale = c->d_gscale.p;
   {
     // Resident ring rows: all nq if a wave then needs <= 8 KB of LDS (five 4-wave workgroups per CU,
