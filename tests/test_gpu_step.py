@@ -550,3 +550,49 @@ def test_native_run_loop_argument_checks(oracle):
     with pytest.raises(ShPairError):
         sp.run_device(a, 5, 0)
     sp.close()
+
+
+def test_random_boxes_ghosts_and_lists_match_oracle(oracle):
+    """Property test over random boxes (any mix of periodic / open directions, edges down to the minimum
+    2 c_max, particles outside open faces, one to a few hundred particles, dense and dilute): the
+    device-built ghosts and half list equal the oracle's, entry for entry."""
+    import torch
+    from shpair import shapes
+    rng = np.random.default_rng(2026)
+    lmax = 3
+    shp = [shapes.random_shape(lmax, 70, amp=0.15), shapes.random_shape(lmax, 71, amp=0.3)]
+    rmax = np.array([oracle.shape_rmax(lmax, a) for a in shp])
+    sp = make_ctx(shp, lmax)
+    checked_pairs = 0
+    for trial in range(40):
+        periodic = tuple(int(v) for v in rng.integers(0, 2, 3))
+        skin = float(rng.choice([0.0, 0.05, 0.4]))
+        cmax = 2 * rmax.max() + skin
+        edge = np.where(np.array(periodic, bool), rng.uniform(2.0 * cmax + 1e-9, 5 * cmax, 3), rng.uniform(0.3, 6 * cmax, 3))
+        lo = rng.uniform(-5, 5, 3)
+        hi = lo + edge
+        n = int(rng.choice([1, 2, 7, 60, 300]))
+        x = lo + rng.uniform(-0.2, 1.2, (n, 3)) * edge      # some outside: wrapped if periodic, clamped into edge cells if not
+        if trial % 5 == 0:
+            x[: n // 2] = x[0] + rng.normal(0, 0.3, (n // 2, 3))   # a dense clump: long rows
+        case = dict(n=n, x=x, quat=random_quats(rng, n), type=np.ones(n, np.int32),
+                    shtype=rng.integers(0, 2, n).astype(np.int32))
+        sp.set_box(lo, hi, periodic, skin)
+        nmax = 27 * n + 8
+        xd, qd, tyd, shd = _device_rows(case, nmax)
+        ng = sp.borders_device(n, nmax, xd.data_ptr(), qd.data_ptr(), tyd.data_ptr(), shd.data_ptr())
+        xw = x.copy()
+        own, shift = oracle.borders(xw, lo, hi, periodic, cmax)
+        assert ng == own.size, (trial, periodic)
+        xa = xd[: n + ng].cpu().numpy()
+        assert np.abs(xa - np.concatenate([xw, xw[own] + shift * edge])).max() < 1e-12
+        npairs = sp.neighbor_build_device(n, ng, xd.data_ptr(), shd.data_ptr())
+        offs, jl = sp.copy_neighbors(n, npairs)
+        tag = np.concatenate([np.arange(n), own]).astype(np.int32)
+        sha = np.concatenate([case["shtype"], case["shtype"][own]])
+        o_offs, o_jl = oracle.half_list(n, xa, sha, tag, rmax, skin)
+        assert np.array_equal(offs, o_offs) and np.array_equal(jl, o_jl), (trial, periodic, n)
+        checked_pairs += npairs
+    assert checked_pairs > 5000
+    torch.cuda.synchronize()
+    sp.close()
