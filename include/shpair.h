@@ -146,6 +146,14 @@ int shpair_get_stats(shpair_ctx *ctx, shpair_stats *out);
  * memory owned by the caller; NULL disables. */
 int shpair_set_pair_output(shpair_ctx *ctx, double *pair_out_dev);
 
+/* Per-atom tallies (Pair::eatom / vatom, filled as LAMMPS' ev_tally_xyz does: half of a pair's energy
+ * and virial to each of its atoms this rank tallies for).  Device form: eatom_dev[nall] and
+ * vatom_dev[nall][6] (xx,yy,zz,xy,xz,yz) are ADDED to by every following shpair_compute_device(); NULL
+ * switches either off.  A non-NULL eatom makes the overlap-volume root finder run. */
+int shpair_set_peratom_output(shpair_ctx *ctx, double *eatom_dev, double *vatom_dev);
+/* Host form for shpair_compute(): host arrays of the same shapes, staged through the device. */
+int shpair_set_peratom_host(shpair_ctx *ctx, double *eatom, double *vatom);
+
 /* The context's own non-blocking stream (a hipStream_t), used by
  * shpair_compute() for its staging copies and kernels. */
 int shpair_get_stream(shpair_ctx *ctx, void **stream);

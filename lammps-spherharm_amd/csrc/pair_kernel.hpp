@@ -70,6 +70,8 @@ struct PairParams {
   const double* glw;    // nq weights
   const double* cpsi;   // 2nq cos(psi_l)
   const double* spsi;   // 2nq sin(psi_l)
+  double* eatom;        // nullable: per-atom energy  [nall], LAMMPS eatom (ev_tally_xyz halves)
+  double* vatom;        // nullable: per-atom virial  [nall][6] (xx,yy,zz,xy,xz,yz)
   const double* trig;   // (cos m psi_l, sin m psi_l) at trig[(m - 2) * trig_stride + 2 l], m = 2..lmax: for one m the
                         // lanes of a wave read consecutive 16-byte entries (4 cache lines per load, not 20)
   int trig_stride;      // 4 nq doubles between consecutive m
@@ -750,6 +752,23 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, SHP_MIN_WAVES) pair_co
     atomicAdd(&P.torque[3 * j], -M0 - (d1 * G2 - d2 * G1));
     atomicAdd(&P.torque[3 * j + 1], -M1 - (d2 * G0 - d0 * G2));
     atomicAdd(&P.torque[3 * j + 2], -M2 - (d0 * G1 - d1 * G0));
+  }
+  if (P.eatom || P.vatom) {
+    // ev_tally_xyz per-atom part: half of the pair's energy / virial to each atom this rank tallies for
+    const bool owni = P.newton_pair || i < P.nlocal;
+    if (P.eatom) {
+      const double eh = 0.5 * knij * (vm1 * aV);
+      if (owni) atomicAdd(&P.eatom[i], eh);
+      if (applyj) atomicAdd(&P.eatom[j], eh);
+    }
+    if (P.vatom) {
+      const double v[6] = {0.5 * (-d0) * F0, 0.5 * (-d1) * F1, 0.5 * (-d2) * F2,
+                           0.5 * (-d0) * F1, 0.5 * (-d0) * F2, 0.5 * (-d1) * F2};
+      for (int a = 0; a < 6; ++a) {
+        if (owni) atomicAdd(&P.vatom[6 * (size_t)i + a], v[a]);
+        if (applyj) atomicAdd(&P.vatom[6 * (size_t)j + a], v[a]);
+      }
+    }
   }
   if ((P.eflag || P.vflag) && P.ev) {
     const double share = P.newton_pair ? 1.0 : (0.5 + (j < P.nlocal ? 0.5 : 0.0));

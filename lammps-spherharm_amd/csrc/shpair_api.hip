@@ -119,6 +119,7 @@ void shpair_destroy(shpair_ctx* c)
   c->d_creal.release(); c->d_xval.release(); c->d_gscale.release(); c->d_xcol.release(); c->d_xinfo.release();
   c->d_x.release(); c->d_quat.release(); c->d_f.release(); c->d_torque.release(); c->d_ev.release();
   c->d_type.release(); c->d_shtype.release(); c->d_counters.release(); c->d_flags.release();
+  c->d_eatom.release(); c->d_vatom.release();
   if (c->h_ft) (void)hipHostFree(c->h_ft);
   if (c->h_ev) (void)hipHostFree(c->h_ev);
   if (c->h_counters) (void)hipHostFree(c->h_counters);
@@ -461,6 +462,8 @@ int shpair_compute_device(shpair_ctx* c, int nlocal, int nghost, const double* x
   P.kn = c->d_kn.p; P.expo = c->d_expo.p; P.ntypes = c->ntypes;
   const int nq = c->nq;
   P.glt = c->d_quad.p; P.glw = c->d_quad.p + nq; P.cpsi = c->d_quad.p + 2 * nq; P.spsi = c->d_quad.p + 4 * nq;
+  P.eatom = c->eatom_dev;
+  P.vatom = c->vatom_dev;
   P.nq = nq;
   P.trig = c->d_quad.p + 6 * nq;
   P.trig_stride = 4 * nq;
@@ -506,7 +509,7 @@ int shpair_compute_device(shpair_ctx* c, int nlocal, int nghost, const double* x
     HIPCHK(c, hipMemsetAsync(c->d_flags.p, 0, c->npairs, st));
     P.flags = c->d_flags.p;
   }
-  const bool needv = c->opt_force_volume || eflag || c->any_nonunit_exponent;
+  const bool needv = c->opt_force_volume || eflag || c->any_nonunit_exponent || c->eatom_dev != nullptr;
   if (c->opt_timing) HIPCHK(c, hipEventRecord(c->ev0, st));
   if (c->lmax <= kMaxUnrolledL && c->opt_variant != 1) {
     P.coef = c->d_coefm.p;  // compiled orders read the monomial (Horner) table
@@ -569,6 +572,19 @@ int shpair_compute(shpair_ctx* c, int nlocal, int nghost, const double* x, const
     c->h_ft_cap = 6 * nall + 64;
   }
   hipStream_t st = c->stream;
+  // per-atom tallies of the host form: staged like the forces (shpair_set_peratom_host)
+  double *const keep_e = c->eatom_dev, *const keep_v = c->vatom_dev;
+  const bool pe = c->eatom_host != nullptr, pv = c->vatom_host != nullptr;
+  std::vector<double> h_pa;
+  if (pe || pv) {
+    if (pe) HIPCHK(c, c->d_eatom.ensure(nall));
+    if (pv) HIPCHK(c, c->d_vatom.ensure(6 * nall));
+    if (pe) HIPCHK(c, hipMemsetAsync(c->d_eatom.p, 0, nall * sizeof(double), st));
+    if (pv) HIPCHK(c, hipMemsetAsync(c->d_vatom.p, 0, 6 * nall * sizeof(double), st));
+    c->eatom_dev = pe ? c->d_eatom.p : nullptr;
+    c->vatom_dev = pv ? c->d_vatom.p : nullptr;
+    h_pa.resize(7 * nall);
+  }
   HIPCHK(c, hipEventRecord(c->evA, st));
   HIPCHK(c, hipMemcpyAsync(c->d_x.p, x, 3 * nall * sizeof(double), hipMemcpyHostToDevice, st));
   HIPCHK(c, hipMemcpyAsync(c->d_quat.p, quat, 4 * nall * sizeof(double), hipMemcpyHostToDevice, st));
@@ -579,7 +595,11 @@ int shpair_compute(shpair_ctx* c, int nlocal, int nghost, const double* x, const
   HIPCHK(c, hipMemsetAsync(c->d_ev.p, 0, 7 * sizeof(double), st));
   const int rc = shpair_compute_device(c, nlocal, nghost, c->d_x.p, c->d_quat.p, c->d_type.p, c->d_shtype.p,
                                        newton_pair, eflag, vflag, c->d_f.p, c->d_torque.p, c->d_ev.p, st);
+  c->eatom_dev = keep_e;
+  c->vatom_dev = keep_v;
   if (rc) return rc;
+  if (pe) HIPCHK(c, hipMemcpyAsync(h_pa.data(), c->d_eatom.p, nall * sizeof(double), hipMemcpyDeviceToHost, st));
+  if (pv) HIPCHK(c, hipMemcpyAsync(h_pa.data() + nall, c->d_vatom.p, 6 * nall * sizeof(double), hipMemcpyDeviceToHost, st));
   HIPCHK(c, hipMemcpyAsync(c->h_ft, c->d_f.p, 3 * nall * sizeof(double), hipMemcpyDeviceToHost, st));
   HIPCHK(c, hipMemcpyAsync(c->h_ft + 3 * nall, c->d_torque.p, 3 * nall * sizeof(double), hipMemcpyDeviceToHost, st));
   HIPCHK(c, hipMemcpyAsync(c->h_ev, c->d_ev.p, 7 * sizeof(double), hipMemcpyDeviceToHost, st));
@@ -593,6 +613,26 @@ int shpair_compute(shpair_ctx* c, int nlocal, int nghost, const double* x, const
   if (eflag) *eng_vdwl += c->h_ev[0];
   if (vflag)
     for (int a = 0; a < 6; ++a) virial[a] += c->h_ev[1 + a];
+  if (pe)
+    for (size_t k = 0; k < nall; ++k) c->eatom_host[k] += h_pa[k];
+  if (pv)
+    for (size_t k = 0; k < 6 * nall; ++k) c->vatom_host[k] += h_pa[nall + k];
+  return SHPAIR_OK;
+}
+
+int shpair_set_peratom_output(shpair_ctx* c, double* eatom_dev, double* vatom_dev)
+{
+  if (!c) return SHPAIR_EINVAL;
+  c->eatom_dev = eatom_dev;
+  c->vatom_dev = vatom_dev;
+  return SHPAIR_OK;
+}
+
+int shpair_set_peratom_host(shpair_ctx* c, double* eatom, double* vatom)
+{
+  if (!c) return SHPAIR_EINVAL;
+  c->eatom_host = eatom;
+  c->vatom_host = vatom;
   return SHPAIR_OK;
 }
 

@@ -78,6 +78,9 @@ struct shpair_ctx {
 
   int opt_force_volume = 0, opt_timing = 0, opt_count = 0, opt_variant = 0, opt_ring_rows = 0, opt_wpb = 0;
   double* pair_out = nullptr;
+  double *eatom_dev = nullptr, *vatom_dev = nullptr;    // shpair_set_peratom_output
+  double *eatom_host = nullptr, *vatom_host = nullptr;  // shpair_set_peratom_host
+  shp::DevBuf<double> d_eatom, d_vatom;                 // staging of the host form
   unsigned long long* dbg = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr, evA = nullptr, evB = nullptr;
   bool timed_last = false, counted_last = false, total_timed_last = false;

@@ -96,8 +96,15 @@ int main(int argc, char **argv)
   for (int i = 1; i <= ntypes; i++)
     for (int j = i; j <= ntypes; j++) cut = pair.init_one(i, j);
 
-  pair.compute(eflag, eflag);    // step 1
+  pair.compute(eflag ? 3 : 0, eflag ? 3 : 0);    // step 1: global and per-atom tallies
   const double e1 = pair.eng_vdwl;
+  std::vector<double> ea(nall, 0.0), va(6 * (size_t) nall, 0.0);
+  if (eflag) {
+    for (int i = 0; i < nall; i++) {
+      ea[i] = pair.eatom[i];
+      for (int a = 0; a < 6; a++) va[6 * (size_t) i + a] = pair.vatom[i][a];
+    }
+  }
   // step 2 reuses the uploaded neighbour list (lastcall unchanged); LAMMPS clears forces in between
   for (int i = 0; i < nall; i++)
     for (int a = 0; a < 3; a++) f[i][a] = tq[i][a] = 0.0;
@@ -111,6 +118,15 @@ int main(int argc, char **argv)
   for (int i = 0; i < nall; i++)
     fprintf(fp, "%.17g %.17g %.17g %.17g %.17g %.17g\n", f[i][0], f[i][1], f[i][2], tq[i][0], tq[i][1], tq[i][2]);
   fclose(fp);
+  if (eflag) {    // per-atom tallies of step 1
+    std::string pa = std::string(argv[2]) + ".peratom";
+    fp = fopen(pa.c_str(), "w");
+    if (!fp) return 4;
+    for (int i = 0; i < nall; i++)
+      fprintf(fp, "%.17g %.17g %.17g %.17g %.17g %.17g %.17g\n", ea[i], va[6 * (size_t) i], va[6 * (size_t) i + 1],
+              va[6 * (size_t) i + 2], va[6 * (size_t) i + 3], va[6 * (size_t) i + 4], va[6 * (size_t) i + 5]);
+    fclose(fp);
+  }
 
   const char *ns = getenv("LAMMPS_HOST_NSTEPS");
   if (ns && atoi(ns) > 0 && nghost == 0) {

@@ -263,6 +263,9 @@ void PairSH::compute(int eflag, int vflag)
   double *q0 = nall ? quat[0] : nullptr;
   double *f0 = nall ? atom->f[0] : nullptr;
   double *t0 = nall ? atom->torque[0] : nullptr;
+  // per-atom tallies (compute pe/atom, stress/atom): Pair's own eatom / vatom arrays, sized by ev_init
+  check(shpair_set_peratom_host(ctx, (eflag_atom && nall) ? eatom : nullptr, (vflag_atom && nall) ? vatom[0] : nullptr),
+        "shpair_set_peratom_host");
   check(shpair_compute(ctx, nlocal, atom->nghost, x0, q0, atom->type, shtype, force->newton_pair, eflag_global ? 1 : 0,
                        vflag_global ? 1 : 0, f0, t0, &eng, vir),
         "shpair_compute");
@@ -270,7 +273,6 @@ void PairSH::compute(int eflag, int vflag)
   if (eflag_global) eng_vdwl += eng;
   if (vflag_global)
     for (int a = 0; a < 6; a++) virial[a] += vir[a];
-  if (eflag_atom || vflag_atom) error->all(FLERR, "pair sh does not tally per-atom energy/virial");
 }
 
 void *PairSH::extract(const char *str, int &dim)

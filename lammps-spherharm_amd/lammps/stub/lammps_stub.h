@@ -174,6 +174,8 @@ class Pair : protected Pointers {
   NeighList *list = nullptr;
   int eflag_either = 0, eflag_global = 0, eflag_atom = 0, vflag_either = 0, vflag_global = 0, vflag_atom = 0;
   int evflag = 0;
+  double *eatom = nullptr, **vatom = nullptr;    // per-atom tallies, (re)sized by ev_init as in LAMMPS
+  int maxeatom = 0, maxvatom = 0;
 
   explicit Pair(LAMMPS *p) : Pointers(p) {}
   virtual void compute(int, int) = 0;
@@ -184,10 +186,32 @@ class Pair : protected Pointers {
   virtual void *extract(const char *, int &) { return nullptr; }
   void ev_init(int eflag, int vflag)
   {
-    eflag_either = eflag_global = eflag ? 1 : 0;
-    vflag_either = vflag_global = vflag ? 1 : 0;
-    eflag_atom = vflag_atom = 0;
+    // LAMMPS bit convention: 1 = global, 2 = per-atom
+    eflag_either = eflag ? 1 : 0;
+    vflag_either = vflag ? 1 : 0;
+    eflag_global = eflag & 1;
+    vflag_global = vflag & 1;
+    eflag_atom = (eflag & 2) ? 1 : 0;
+    vflag_atom = (vflag & 2) ? 1 : 0;
     evflag = eflag || vflag;
+    const int nall = atom->nlocal + atom->nghost;
+    if (eflag_atom) {
+      if (nall > maxeatom) {
+        free(eatom);
+        eatom = (double *) malloc(sizeof(double) * nall);
+        maxeatom = nall;
+      }
+      for (int i = 0; i < nall; i++) eatom[i] = 0.0;
+    }
+    if (vflag_atom) {
+      if (nall > maxvatom) {
+        memory->destroy(vatom);
+        memory->create(vatom, nall, 6, "pair:vatom");
+        maxvatom = nall;
+      }
+      for (int i = 0; i < nall; i++)
+        for (int a = 0; a < 6; a++) vatom[i][a] = 0.0;
+    }
     eng_vdwl = eng_coul = 0.0;
     for (double &v : virial) v = 0.0;
   }

@@ -63,6 +63,8 @@ SYMBOLS = {
     "shpair_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
     "shpair_get_stats": (C.c_int, [C.c_void_p, C.POINTER(Stats)]),
     "shpair_set_pair_output": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "shpair_set_peratom_output": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "shpair_set_peratom_host": (C.c_int, [C.c_void_p, _dp, _dp]),
     "shpair_get_stream": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
     "shpair_synchronize": (C.c_int, [C.c_void_p]),
     # include/shstep.h
@@ -267,6 +269,18 @@ class ShPair:
 
     def set_option(self, key, value):
         self._chk(self._lib.shpair_set_option(self._h, key.encode(), int(value)))
+
+    def set_peratom_output(self, eatom_ptr, vatom_ptr):
+        """Device arrays eatom[nall], vatom[nall,6] that following compute_device calls add into (None = off)."""
+        self._chk(self._lib.shpair_set_peratom_output(self._h, eatom_ptr, vatom_ptr))
+
+    def set_peratom_host(self, eatom, vatom):
+        """Host arrays (float64, C-contiguous; None = off) that following compute() calls add into."""
+        for a in (eatom, vatom):
+            assert a is None or (a.dtype == np.float64 and a.flags.c_contiguous)
+        self._keep_peratom = (eatom, vatom)
+        self._chk(self._lib.shpair_set_peratom_host(self._h, None if eatom is None else eatom.ctypes.data_as(_dp),
+                                                    None if vatom is None else vatom.ctypes.data_as(_dp)))
 
     def set_pair_output(self, dev_ptr):
         self._chk(self._lib.shpair_set_pair_output(self._h, dev_ptr))

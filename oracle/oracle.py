@@ -46,6 +46,8 @@ def lib():
                                   C.c_int, C.c_int, C.c_int, _dp, _dp, _dp,
                                   C.POINTER(C.c_longlong), _dp, C.c_int]
         L.sho_max_threads.restype = C.c_int
+        L.sho_set_peratom.restype = None
+        L.sho_set_peratom.argtypes = [_dp, _dp]
         L.sho_mass_props.restype = None
         L.sho_mass_props.argtypes = [C.c_int, _dp, _dp]
         L.sho_nve.restype = None
@@ -113,7 +115,7 @@ def pair(li, anmi, ri, lj, anmj, rj, xi, qi, xj, qj, nq, need_volume=True):
 
 def compute(shapes, kn, expo, nq, nlocal, x, quat, type_, shtype, ilist, offs, jlist,
             newton_pair=True, eflag=False, vflag=False, force_volume=False, nthreads=1,
-            want_pairs=False):
+            want_pairs=False, want_peratom=False):
     """shapes: list of (lmax, anm, rmax). kn/expo: (ntypes+1, ntypes+1) arrays.
     Returns dict(f, torque, eng_virial, counts[, pairs])."""
     lmax, plm = _i([s[0] for s in shapes])
@@ -137,13 +139,21 @@ def compute(shapes, kn, expo, nq, nlocal, x, quat, type_, shtype, ilist, offs, j
     ev = np.zeros(7)
     counts = np.zeros(3, dtype=np.int64)
     pairs = np.zeros((max(1, jlist.size), 7)) if want_pairs else None
+    eatom = np.zeros(nall) if want_peratom else None
+    vatom = np.zeros((nall, 6)) if want_peratom else None
+    if want_peratom:
+        lib().sho_set_peratom(eatom.ctypes.data_as(_dp), vatom.ctypes.data_as(_dp))
     lib().sho_compute(len(shapes), plm, pao, paa, prm, ntypes, pkn, pex, nq,
                       nlocal, px, pq, pt, ps, ilist.size, pil, pof, pjl, int(newton_pair),
                       int(eflag), int(vflag), int(force_volume),
                       f.ctypes.data_as(_dp), tq.ctypes.data_as(_dp), ev.ctypes.data_as(_dp),
                       counts.ctypes.data_as(C.POINTER(C.c_longlong)),
                       pairs.ctypes.data_as(_dp) if want_pairs else None, nthreads)
+    if want_peratom:
+        lib().sho_set_peratom(None, None)
     out = dict(f=f, torque=tq, eng_virial=ev, counts=counts)
+    if want_peratom:
+        out["eatom"], out["vatom"] = eatom, vatom
     if want_pairs:
         out["pairs"] = pairs[: jlist.size]
     return out

@@ -294,6 +294,15 @@ int sho_pair(int Li, const double *anmi, double Ri, int Lj, const double *anmj, 
  * spheres overlap), [2]=pairs with V>0 / any inside node.
  * pair_out (nullable): 7 doubles per CSR slot (V,S_n,T_n).
  */
+/* Per-atom tallies of the NEXT sho_compute calls (LAMMPS ev_tally_xyz per-atom part, SPEC §2.7): eatom[nall],
+ * vatom[nall][6], added to; NULL switches them off. */
+static double *g_eatom = NULL, *g_vatom = NULL;
+void sho_set_peratom(double *eatom, double *vatom)
+{
+  g_eatom = eatom;
+  g_vatom = vatom;
+}
+
 int sho_compute(int nshape, const int *lmax, const int *anm_off, const double *anm_all,
                 const double *rmax, int ntypes, const double *kn, const double *expo, int nq,
                 int nlocal, const double *x, const double *quat, const int *type, const int *shtype,
@@ -318,7 +327,7 @@ int sho_compute(int nshape, const int *lmax, const int *anm_off, const double *a
       const int sj = shtype[j];
       const double knij = kn[type[i] * (ntypes + 1) + type[j]];
       const double mij = expo[type[i] * (ntypes + 1) + type[j]];
-      const int needV = force_volume || eflag || (mij != 1.0);
+      const int needV = force_volume || eflag || (mij != 1.0) || (g_eatom != NULL);
       double o[7];
       ++ncand;
       const int hit = sho_pair(lmax[si], anm_all + anm_off[si], rmax[si], lmax[sj], anm_all + anm_off[sj],
@@ -350,6 +359,35 @@ int sho_compute(int nshape, const int *lmax, const int *anm_off, const double *a
           f[3 * j + a] += Fj[a];
 #pragma omp atomic
           torque[3 * j + a] += -Ti[a] - dxF[a];
+        }
+      }
+      if (g_eatom || g_vatom) {
+        const int owni = newton_pair || i < nlocal;
+        if (g_eatom) {
+          const double eh = 0.5 * knij * pow(V, mij);
+          if (owni) {
+#pragma omp atomic
+            g_eatom[i] += eh;
+          }
+          if (applyj) {
+#pragma omp atomic
+            g_eatom[j] += eh;
+          }
+        }
+        if (g_vatom) {
+          const double del[3] = { -d[0], -d[1], -d[2] };
+          const double v[6] = { 0.5 * del[0] * Fi[0], 0.5 * del[1] * Fi[1], 0.5 * del[2] * Fi[2],
+                                0.5 * del[0] * Fi[1], 0.5 * del[0] * Fi[2], 0.5 * del[1] * Fi[2] };
+          for (int a = 0; a < 6; ++a) {
+            if (owni) {
+#pragma omp atomic
+              g_vatom[6 * (size_t)i + a] += v[a];
+            }
+            if (applyj) {
+#pragma omp atomic
+              g_vatom[6 * (size_t)j + a] += v[a];
+            }
+          }
         }
       }
       if (eflag || vflag) {

@@ -631,3 +631,50 @@ def test_flat_spectrum_shapes(oracle, lmax):
     assert rel_err(f, o["f"]) < 1e-11      # far inside TOL even in this worst case
     assert abs(eng - o["eng_virial"][0]) < TOL * o["eng_virial"][0]
     sp.close()
+
+
+@pytest.mark.parametrize("newton", [True, False])
+def test_peratom_energy_and_virial(oracle, newton):
+    """Pair::eatom / vatom (ev_tally_xyz halves), device and host forms, against the oracle."""
+    import torch
+    case = make_case(300, 6, 2, seed=45, rmax_fn=oracle.shape_rmax)
+    nlocal = 300 if newton else 170
+    if not newton:
+        case = dict(case)
+        case["ilist"] = case["ilist"][:nlocal]
+        case["jlist"] = case["jlist"][:case["offsets"][nlocal]]
+        case["offsets"] = case["offsets"][:nlocal + 1]
+    K, E = coeff_tables(1, 900.0, 1.25)
+    sp = make_ctx(case, 12, K, E)
+    b = case["bed"]
+    n = case["n"]
+    o = oracle_compute(oracle, case, 12, K, E, nlocal=nlocal, newton_pair=newton, eflag=True, vflag=True, want_peratom=True)
+    es, vs = o["eatom"].max(), np.abs(o["vatom"]).max()
+    # host form
+    ea, va = np.zeros(n), np.zeros((n, 6))
+    sp.set_peratom_host(ea, va)
+    f, tq, eng, vir = sp.compute(nlocal, b["x"], b["quat"], b["type"], b["shtype"], newton_pair=newton, eflag=True, vflag=True)
+    check(f, tq, o)
+    assert np.abs(ea - o["eatom"]).max() < TOL * es and np.abs(va - o["vatom"]).max() < TOL * vs
+    if newton:
+        assert abs(ea.sum() - eng) < 1e-12 * eng and np.abs(va.sum(0) - vir).max() < 1e-11 * np.abs(vir).max()
+    else:
+        assert ea[nlocal:].max() == 0.0           # ghosts are not tallied with newton off
+    sp.set_peratom_host(None, None)
+    # device form, without eflag: the per-atom energy alone switches the volume path on
+    dev = torch.device("cuda:0")
+    x, q = torch.from_numpy(b["x"]).to(dev), torch.from_numpy(b["quat"]).to(dev)
+    ty, sh = torch.from_numpy(b["type"]).to(dev), torch.from_numpy(b["shtype"]).to(dev)
+    fd = torch.zeros(n, 3, dtype=torch.float64, device=dev)
+    td = torch.zeros_like(fd)
+    ed = torch.zeros(n, dtype=torch.float64, device=dev)
+    vd = torch.zeros(n, 6, dtype=torch.float64, device=dev)
+    sp.set_peratom_output(ed.data_ptr(), vd.data_ptr())
+    for _ in range(2):                            # ADD semantics: two calls, twice the tallies
+        sp.compute_device(nlocal, n - nlocal, x.data_ptr(), q.data_ptr(), ty.data_ptr(), sh.data_ptr(), fd.data_ptr(),
+                          td.data_ptr(), newton_pair=newton)
+    torch.cuda.synchronize()
+    assert np.abs(ed.cpu().numpy() - 2 * o["eatom"]).max() < TOL * es
+    assert np.abs(vd.cpu().numpy() - 2 * o["vatom"]).max() < TOL * vs
+    sp.set_peratom_output(None, None)
+    sp.close()

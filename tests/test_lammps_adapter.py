@@ -82,13 +82,17 @@ def test_pairsh_adapter_matches_oracle(tmp_path, oracle, newton, expo):
     vir = np.array([float(v) for v in lines[1].split()])
     ft = np.array([[float(v) for v in ln.split()] for ln in lines[2:] if ln.strip()])
     K, E = coeff_tables(1, 750.0, expo)
-    o = oracle_compute(oracle, case, 12, K, E, nlocal=nlocal, newton_pair=newton, eflag=True, vflag=True)
+    o = oracle_compute(oracle, case, 12, K, E, nlocal=nlocal, newton_pair=newton, eflag=True, vflag=True, want_peratom=True)
     fs = np.abs(o["f"]).max()
     assert abs(cut - 2 * max(case["rmax"])) < 1e-14
     assert np.abs(ft[:, :3] - o["f"]).max() < 1e-9 * fs
     assert np.abs(ft[:, 3:] - o["torque"]).max() < 1e-9 * max(fs, np.abs(o["torque"]).max())
     assert abs(e1 - o["eng_virial"][0]) < 1e-9 * o["eng_virial"][0] and abs(e2 - e1) < 1e-11 * e1
     assert np.abs(vir - o["eng_virial"][1:]).max() < 1e-9 * np.abs(o["eng_virial"][1:]).max()
+    # per-atom tallies through Pair::eatom / vatom (eflag, vflag bit 2)
+    pa = np.loadtxt(str(out) + ".peratom")
+    assert np.abs(pa[:, 0] - o["eatom"]).max() < 1e-9 * o["eatom"].max()
+    assert np.abs(pa[:, 1:] - o["vatom"]).max() < 1e-9 * np.abs(o["vatom"]).max()
 
 
 @pytest.mark.gpu

@@ -84,3 +84,17 @@ def test_empty_and_ragged_lists(oracle):
     assert c["jlist"].size == 0
     o = oracle_compute(oracle, c, 6, K, E)
     assert not o["f"].any() and tuple(o["counts"]) == (0, 0, 0)
+
+
+def test_peratom_tallies_sum_to_the_global_ones(oracle):
+    """ev_tally_xyz: with newton on, the per-atom halves add up to the global energy and virial."""
+    case = make_case(120, 4, 2, seed=44, rmax_fn=oracle.shape_rmax)
+    K, E = coeff_tables(1, 800.0, 1.5)
+    o = oracle_compute(oracle, case, 8, K, E, eflag=True, vflag=True, want_peratom=True)
+    assert o["counts"][2] > 50
+    assert abs(o["eatom"].sum() - o["eng_virial"][0]) < 1e-12 * o["eng_virial"][0]
+    assert np.abs(o["vatom"].sum(0) - o["eng_virial"][1:]).max() < 1e-12 * np.abs(o["eng_virial"][1:]).max()
+    assert (o["eatom"] >= 0).all() and (o["eatom"] > 0).sum() > 60
+    # forces unchanged by asking for the tallies
+    o2 = oracle_compute(oracle, case, 8, K, E)
+    assert np.array_equal(o["f"], o2["f"])
