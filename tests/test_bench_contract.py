@@ -52,3 +52,15 @@ def test_two_rank_rehearsal_reproduces_single_domain_forces():
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["backend"] == "gloo-rehearsal"
     assert d["verify_rel_err"] is not None and d["verify_rel_err"] < 1e-12
     assert d["config"]["ghost_atoms_rank0"] > 0 and d["config"]["contact_pairs_all_ranks"] > d["config"]["contact_pairs_rank0"]
+
+
+def test_halo_exchange_over_real_rccl_with_the_rank_as_its_own_peer():
+    """The product transport on the one GPU there is: `nccl` backend (RCCL), world size 1, send/recv to self
+    — the batched P2POp groups, receives straight into the ghost rows and the index_add fold-in of
+    shpair/halo.py (tools/nccl_self_halo.py asserts the results)."""
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29578",
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "nccl_self_halo.py")], capture_output=True, text=True,
+                       timeout=600, cwd=ROOT, env=env)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    assert "RCCL self-peer halo exchange OK" in r.stdout
