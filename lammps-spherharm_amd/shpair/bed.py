@@ -46,13 +46,16 @@ def make_bed(n, rmax_by_shape, nshapes=1, spacing=1.9, jitter=0.04, seed=SEED0, 
                 rmax=np.asarray(rmax_by_shape, dtype=np.float64))
 
 
-def half_neighbor_list(x, shtype, rmax_by_shape, skin=0.1, nlocal=None, owner_rule=None):
+def half_neighbor_list(x, shtype, rmax_by_shape, skin=0.1, nlocal=None, owner_rule=None, cross_rule=None):
     """LAMMPS-layout half list in CSR form: (ilist, offsets, jlist).
 
     Every unordered pair within Rmax_i + Rmax_j + skin appears once, stored with
     the lower index as i (newton on).  With `nlocal`, only pairs with at least
-    one local atom are kept, i is always local, and `owner_rule(i, j)` (bool
-    array) may drop local-ghost pairs that another rank evaluates.
+    one local atom are kept, and local-ghost pairs are filtered by ONE of
+      owner_rule(i_local, j_ghost) -> bool array: keep with the local atom as i;
+      cross_rule(i_local, j_ghost) -> int array: 0 drop (another rank evaluates the pair), 1 keep with the
+        local atom as i, 2 keep with the GHOST as i (rows of ghost atoms then follow the owned rows; needs
+        newton on: the force on the ghost travels home with the reverse exchange).
     """
     from scipy.spatial import cKDTree
     rmax = np.asarray(rmax_by_shape, dtype=np.float64)
@@ -68,16 +71,30 @@ def half_neighbor_list(x, shtype, rmax_by_shape, skin=0.1, nlocal=None, owner_ru
     sw = a >= nlocal
     a, b = np.where(sw, b, a), np.where(sw, a, b)
     keep = a < nlocal
-    if owner_rule is not None:
-        gh = b >= nlocal
+    gh = b >= nlocal
+    if cross_rule is not None:
+        code = np.ones(a.size, dtype=np.int64)
+        sel = keep & gh
+        code[sel] = cross_rule(a[sel], b[sel])
+        keep &= code > 0
+        flip = keep & (code == 2)
+        a, b = np.where(flip, b, a), np.where(flip, a, b)
+    elif owner_rule is not None:
         keep &= ~gh | owner_rule(a, b)
     a, b = a[keep], b[keep]
     order = np.lexsort((b, a))
     a, b = a[order], b[order]
-    counts = np.bincount(a, minlength=nlocal)[:nlocal]
-    offsets = np.zeros(nlocal + 1, dtype=np.int32)
+    if a.size and a.max() >= nlocal:
+        # rows of ghost atoms: only the non-empty ones, after the owned rows
+        grow = np.unique(a[a >= nlocal])
+        ilist = np.concatenate([np.arange(nlocal), grow]).astype(np.int32)
+        counts = np.concatenate([np.bincount(a[a < nlocal], minlength=nlocal)[:nlocal],
+                                 np.bincount(np.searchsorted(grow, a[a >= nlocal]), minlength=grow.size)])
+    else:
+        ilist = np.arange(nlocal, dtype=np.int32)
+        counts = np.bincount(a, minlength=nlocal)[:nlocal]
+    offsets = np.zeros(ilist.size + 1, dtype=np.int32)
     np.cumsum(counts, out=offsets[1:])
-    ilist = np.arange(nlocal, dtype=np.int32)
     return ilist, offsets, b.astype(np.int32)
 
 

@@ -38,7 +38,7 @@ def _worker(rank, world, port, grid, out_dir):
         dec = Decomposition(b["x"], b["shtype"], case["rmax"], grid)
         view = dec.plan(rank)
         gid, nlocal = view["gid"], view["nlocal"]
-        il, of, jl = dec.neighbor_list(view)
+        il, of, jl = dec.neighbor_list(view, balanced=(world == 4))   # world 4 also covers rows whose i is a ghost
         halo = HaloExchange(view, torch.device("cpu"), dist)
         # owners hold the truth; ghosts start as garbage and must be filled by forward()
         x = torch.from_numpy(b["x"][gid].copy())
