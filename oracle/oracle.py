@@ -46,6 +46,8 @@ def lib():
                                   C.c_int, C.c_int, C.c_int, _dp, _dp, _dp,
                                   C.POINTER(C.c_longlong), _dp, C.c_int]
         L.sho_max_threads.restype = C.c_int
+        L.sho_set_rule.restype = None
+        L.sho_set_rule.argtypes = [C.c_int]
         L.sho_set_peratom.restype = None
         L.sho_set_peratom.argtypes = [_dp, _dp]
         L.sho_mass_props.restype = None
@@ -243,3 +245,9 @@ def half_list(nlocal, x, shtype, tag, rmax, skin):
     jl = np.zeros(max(n, 1), dtype=np.int32)
     lib().sho_half_list(nlocal, x.shape[0], px, ps, pt, pr, skin, offs.ctypes.data_as(_ip), jl.ctypes.data_as(_ip))
     return offs, jl[:n]
+
+
+def set_rule(rule):
+    """0 / "sharp": the inside test of SPEC §2.5; 1 / "weighted": covered-fraction weights of SPEC §2.8.
+    Applies to the following pair() / compute() calls of this process."""
+    lib().sho_set_rule(1 if rule in (1, True, "weighted") else 0)

@@ -161,10 +161,61 @@ static double g_ray(int Lj, const double *anmj, double Rj, const double uj[3], c
  * root-finder evaluations, [3]=cos(alpha).
  * Returns 1 if the bounding spheres overlap (a contact pair), else 0.
  */
+/* SPEC §2.6: inner radius of the ray x_i + lambda u for a node whose surface point (lambda = ri) lies inside j. */
+static double inner_radius(int Lj, const double *anmj, double Rj, const double Rmj[3][3], const double u[3],
+                           const double d[3], const double dj[3], double rho, double rho2, double ri, double s,
+                           double rj0, double *diag)
+{
+  double uj[3];
+  tmatvec(Rmj, u, uj);
+  const double bp = dot3(u, d);
+  double lo = 0.0;
+  if (!(rho < Rj)) lo = bp - sqrt(fmax(0.0, bp * bp - (rho2 - Rj * Rj)));
+  double hi = ri;
+  double lam = bp - sqrt(fmax(0.0, bp * bp - (rho2 - rj0 * rj0)));
+  if (!(lam > lo && lam < hi)) lam = 0.5 * (lo + hi);
+  /* three most recent points: (xa,ga) oldest, (xb,gb), (lam,gl) newest */
+  double xa = ri, ga = s - rj0, xb = ri, gb = s - rj0;
+  double rin = lam;
+  for (int it = 0; it < 60; ++it) {
+    const double gl = g_ray(Lj, anmj, Rj, uj, dj, lam);
+    if (diag) diag[2] += 1.0;
+    if (gl >= 0.0) lo = lam; else hi = lam;
+    const int have3 = (it >= 1);
+    const double sec = lam - gl * (lam - xb) / (gl - gb);
+    double ext = sec;  /* extrapolation through all known points */
+    if (have3)
+      ext = xa * gb * gl / ((ga - gb) * (ga - gl)) + xb * ga * gl / ((gb - ga) * (gb - gl)) +
+            lam * ga * gb / ((gl - ga) * (gl - gb));
+    if (!(fabs(ext) <= 1e300)) ext = sec;
+    if (fabs(gl) <= (have3 ? 1e-4 : 1e-7) * Rj) {  /* accept the extrapolated point */
+      rin = (fabs(ext) <= 1e300) ? fmin(fmax(ext, lo), hi) : lam;
+      break;
+    }
+    double nxt = ext;
+    if (!(nxt > lo && nxt < hi)) nxt = sec;
+    if (!(nxt > lo && nxt < hi)) nxt = 0.5 * (lo + hi);
+    if (hi - lo <= 1e-14 * Rj) { rin = 0.5 * (lo + hi); break; }
+    rin = nxt;
+    xa = xb; ga = gb; xb = lam; gb = gl; lam = nxt;
+  }
+  return rin;
+}
+
+/* SPEC §2.8: 0 = sharp inside test (default), 1 = covered-fraction weights. Applies to the next sho_pair /
+ * sho_compute calls. */
+static int g_rule = 0;
+void sho_set_rule(int rule) { g_rule = rule ? 1 : 0; }
+
+static int sho_pair_weighted(int Li, const double *anmi, double Ri, int Lj, const double *anmj, double Rj,
+                             const double xi[3], const double qi[4], const double xj[3], const double qj[4],
+                             int nq, int need_volume, double out[7], double diag[4]);
+
 int sho_pair(int Li, const double *anmi, double Ri, int Lj, const double *anmj, double Rj,
              const double xi[3], const double qi[4], const double xj[3], const double qj[4],
              int nq, int need_volume, double out[7], double diag[4])
 {
+  if (g_rule) return sho_pair_weighted(Li, anmi, Ri, Lj, anmj, Rj, xi, qi, xj, qj, nq, need_volume, out, diag);
   for (int a = 0; a < 7; ++a) out[a] = 0.0;
   if (diag) for (int a = 0; a < 4; ++a) diag[a] = 0.0;
   const double d[3] = { xj[0] - xi[0], xj[1] - xi[1], xj[2] - xi[2] };
@@ -241,44 +292,119 @@ int sho_pair(int Li, const double *anmi, double Ri, int Lj, const double *anmj, 
 
       /* SPEC §2.6 inner radius */
       double rin = 0.0;
-      if (!centre_inside) {
-        double uj[3];
-        tmatvec(Rmj, u, uj);
-        const double bp = dot3(u, d);
-        double lo = 0.0;
-        if (!(rho < Rj)) lo = bp - sqrt(fmax(0.0, bp * bp - (rho2 - Rj * Rj)));
-        double hi = ri;
-        double lam = bp - sqrt(fmax(0.0, bp * bp - (rho2 - rj0 * rj0)));
-        if (!(lam > lo && lam < hi)) lam = 0.5 * (lo + hi);
-        /* three most recent points: (xa,ga) oldest, (xb,gb), (lam,gl) newest */
-        double xa = ri, ga = s - rj0, xb = ri, gb = s - rj0;
-        rin = lam;
-        for (int it = 0; it < 60; ++it) {
-          const double gl = g_ray(Lj, anmj, Rj, uj, dj, lam);
-          if (diag) diag[2] += 1.0;
-          if (gl >= 0.0) lo = lam; else hi = lam;
-          const int have3 = (it >= 1);
-          const double sec = lam - gl * (lam - xb) / (gl - gb);
-          double ext = sec;  /* extrapolation through all known points */
-          if (have3)
-            ext = xa * gb * gl / ((ga - gb) * (ga - gl)) + xb * ga * gl / ((gb - ga) * (gb - gl)) +
-                  lam * ga * gb / ((gl - ga) * (gl - gb));
-          if (!(fabs(ext) <= 1e300)) ext = sec;
-          if (fabs(gl) <= (have3 ? 1e-4 : 1e-7) * Rj) {  /* accept the extrapolated point */
-            rin = (fabs(ext) <= 1e300) ? fmin(fmax(ext, lo), hi) : lam;
-            break;
-          }
-          double nxt = ext;
-          if (!(nxt > lo && nxt < hi)) nxt = sec;
-          if (!(nxt > lo && nxt < hi)) nxt = 0.5 * (lo + hi);
-          if (hi - lo <= 1e-14 * Rj) { rin = 0.5 * (lo + hi); break; }
-          rin = nxt;
-          xa = xb; ga = gb; xb = lam; gb = gl; lam = nxt;
-        }
-      }
+      if (!centre_inside) rin = inner_radius(Lj, anmj, Rj, Rmj, u, d, dj, rho, rho2, ri, s, rj0, diag);
       out[0] += om * (ri * ri * ri - rin * rin * rin) / 3.0;
     }
   }
+  return 1;
+}
+
+/* SPEC §2.8: the same pair with covered-fraction weights. Two passes over the Q nodes: residuals, then
+ * weights and contributions. */
+static int sho_pair_weighted(int Li, const double *anmi, double Ri, int Lj, const double *anmj, double Rj,
+                             const double xi[3], const double qi[4], const double xj[3], const double qj[4],
+                             int nq, int need_volume, double out[7], double diag[4])
+{
+  for (int a = 0; a < 7; ++a) out[a] = 0.0;
+  if (diag) for (int a = 0; a < 4; ++a) diag[a] = 0.0;
+  const double d[3] = { xj[0] - xi[0], xj[1] - xi[1], xj[2] - xi[2] };
+  const double rho2 = dot3(d, d), rho = sqrt(rho2);
+  if (rho >= Ri + Rj) return 0;
+  double cosa;
+  if (rho <= Rj) cosa = -1.0;
+  else if (rho2 - Rj * Rj <= Ri * Ri) cosa = sqrt(rho2 - Rj * Rj) / rho;
+  else cosa = (rho2 + Ri * Ri - Rj * Rj) / (2.0 * rho * Ri);
+  if (diag) diag[3] = cosa;
+  const double c[3] = { d[0] / rho, d[1] / rho, d[2] / rho };
+  const double sg = copysign(1.0, c[2]);
+  const double aa = -1.0 / (sg + c[2]);
+  const double bb = c[0] * c[1] * aa;
+  const double e1[3] = { 1.0 + sg * c[0] * c[0] * aa, sg * bb, -sg * c[0] };
+  const double e2[3] = { bb, sg + c[1] * c[1] * aa, -c[1] };
+  double Rmi[3][3], Rmj[3][3];
+  quat_to_mat(qi, Rmi);
+  quat_to_mat(qj, Rmj);
+  double dj[3];
+  tmatvec(Rmj, d, dj);
+  int centre_inside = 0;
+  if (rho < Rj) {
+    const double zero[3] = { 0.0, 0.0, 0.0 };
+    centre_inside = (g_ray(Lj, anmj, Rj, zero, dj, 0.0) <= 0.0);
+  }
+  double t[SHO_MAX_NQ], w[SHO_MAX_NQ];
+  sho_gauss_legendre(nq, t, w);
+  const int npsi = 2 * nq, Q = nq * npsi;
+  const double hw = 0.5 * (1.0 - cosa), hm = 0.5 * (1.0 + cosa);
+  /* per node: g~, s, rj0, ri, u[3], gradient gi[3] (body frame of i), inB */
+  double *G = malloc(sizeof(double) * Q * 11);
+  if (!G) return 0;
+  double *S = G + Q, *RJ0 = G + 2 * Q, *RI = G + 3 * Q, *UU = G + 4 * Q, *GI = G + 7 * Q, *INB = G + 10 * Q;
+  for (int k = 0; k < nq; ++k) {
+    const double mu = hm + hw * t[k];
+    const double sig = sqrt(fmax(0.0, 1.0 - mu * mu));
+    for (int l = 0; l < npsi; ++l) {
+      const int p = k * npsi + l;
+      const double psi = 2.0 * SHO_PI * (l + 0.5) / npsi;
+      const double cp = cos(psi), sp = sin(psi);
+      double u[3], ui[3], gi[3];
+      for (int a = 0; a < 3; ++a) u[a] = sig * (cp * e1[a] + sp * e2[a]) + mu * c[a];
+      tmatvec(Rmi, u, ui);
+      const double ri = sho_sh_eval(Li, anmi, ui, gi);
+      const double ps[3] = { ri * u[0] - d[0], ri * u[1] - d[1], ri * u[2] - d[2] };
+      double q[3];
+      tmatvec(Rmj, ps, q);
+      const double s = sqrt(dot3(q, q));
+      double rj0 = Rj, g;
+      if (s >= Rj) {
+        g = s - Rj;
+        INB[p] = 0.0;
+      } else {
+        if (diag) diag[1] += 1.0;
+        if (s > 0.0) {
+          const double qh[3] = { q[0] / s, q[1] / s, q[2] / s };
+          rj0 = sho_sh_eval(Lj, anmj, qh, NULL);
+        }
+        g = s - rj0;
+        INB[p] = 1.0;
+      }
+      G[p] = g; S[p] = s; RJ0[p] = rj0; RI[p] = ri;
+      for (int a = 0; a < 3; ++a) { UU[3 * p + a] = u[a]; GI[3 * p + a] = gi[a]; }
+    }
+  }
+  for (int k = 0; k < nq; ++k) {
+    const double om = hw * w[k] * (2.0 * SHO_PI / npsi);
+    for (int l = 0; l < npsi; ++l) {
+      const int p = k * npsi + l;
+      if (INB[p] == 0.0) continue;
+      const double g = G[p];
+      const double Dl = 0.5 * fabs(G[k * npsi + (l + 1) % npsi] - G[k * npsi + (l + npsi - 1) % npsi]);
+      double Dk = 0.0;
+      if (nq > 1) Dk = (k < nq - 1) ? fabs(G[p + npsi] - g) : fabs(g - G[p - npsi]);
+      const double den = Dk + Dl;
+      double wt;
+      if (den > 0.0) wt = fmin(1.0, fmax(0.0, 0.5 - g / den));
+      else wt = (g < 0.0) ? 1.0 : 0.0;
+      if (!(wt > 0.0)) continue;
+      if (diag) diag[0] += 1.0;
+      const double ri = RI[p], *u = UU + 3 * p, *gi = GI + 3 * p;
+      double ui[3];
+      tmatvec(Rmi, u, ui);
+      const double ug = dot3(ui, gi);
+      double Ab[3], A[3];
+      for (int a = 0; a < 3; ++a) Ab[a] = ri * ri * ui[a] - ri * (gi[a] - ug * ui[a]);
+      matvec(Rmi, Ab, A);
+      const double pr[3] = { ri * u[0], ri * u[1], ri * u[2] };
+      double pxA[3];
+      cross3(pr, A, pxA);
+      const double ow = om * wt;
+      for (int a = 0; a < 3; ++a) { out[1 + a] += ow * A[a]; out[4 + a] += ow * pxA[a]; }
+      if (!need_volume || !(g < 0.0)) continue;
+      double rin = 0.0;
+      if (!centre_inside) rin = inner_radius(Lj, anmj, Rj, Rmj, u, d, dj, rho, rho2, ri, S[p], RJ0[p], diag);
+      out[0] += ow * (ri * ri * ri - rin * rin * rin) / 3.0;
+    }
+  }
+  free(G);
   return 1;
 }
 
