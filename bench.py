@@ -68,6 +68,8 @@ def parse():
     ap.add_argument("--ramp", type=int, default=8, help="extra untimed passes before the W warm-up steps: the first "
                     "~8 launches of a fresh process run up to 25 %% slower while the GPU clock ramps (rocprof per-launch "
                     "durations in profiles/); they are never part of the K timed steps")
+    ap.add_argument("--rule", default="sharp", choices=["sharp", "weighted"],
+                    help="cap rule: sharp inside test (docs/SPEC.md §2.5, the headline) or covered-fraction weights (§2.8)")
     ap.add_argument("--ts-steps", type=int, default=40, help="steps of the whole-timestep leg (N = 1 only; 0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=16, help="OpenMP threads of the cpu_baseline leg "
                     "(16 = the host-core share of one GPU on the bench box)")
@@ -113,6 +115,7 @@ def main():
     for s, a in enumerate(shp):
         sp.set_shape(s, lmax, a)
     sp.coeff("*", "*", 1000.0, args.exponent)
+    sp.set_option("rule", 1 if args.rule == "weighted" else 0)
     rmax = [sp.rmax(s) for s in range(nshapes)]
 
     # ---- the bed: world x particles, bricks of the processor grid (weak scaling)
@@ -262,7 +265,7 @@ def main():
                             f"pair_coeff kn=1000 exponent={args.exponent} (overlap volume + force + torque), "
                             "inputs resident in HBM",
                 "particles_per_gpu": args.particles, "lmax": lmax, "nq": nq, "nshapes": nshapes,
-                "exponent": args.exponent, "proc_grid": list(grid),
+                "exponent": args.exponent, "rule": args.rule, "proc_grid": list(grid),
                 "backend": "rccl" if (world > 1 and not rehearsal) else ("gloo-rehearsal" if world > 1 else "none"),
                 "half_list_pairs_rank0": int(jl.size), "contact_pairs_rank0": int(n_contact),
                 "touching_pairs_rank0": int(n_touching), "contact_pairs_all_ranks": int(contact_all),
@@ -314,6 +317,7 @@ def timestep_leg(args, shp, device):
     for s, a in enumerate(shp):
         sp.set_shape(s, args.lmax, a)
     sp.coeff("*", "*", 1000.0, args.exponent)
+    sp.set_option("rule", 1 if args.rule == "weighted" else 0)
     pts, lo, hi = bed.periodic_hcp(args.particles, 1.9, (1, 1, 1))
     rng = np.random.default_rng(bed.SEED0 + 7)
     n = pts.shape[0]
@@ -359,6 +363,7 @@ def cpu_baseline(args, shp, rmax, gbed, il, of, jl):
     sample of the same bed: the first rows of the same half list, all host cores via OpenMP."""
     from oracle import oracle as O  # checker / baseline only
     O.build()
+    O.set_rule(args.rule)
     avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     nthreads = max(1, min(args.cpu_threads, avail))
     K = np.full((2, 2), 1000.0)

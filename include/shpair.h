@@ -134,7 +134,9 @@ int shpair_compute_device(shpair_ctx *ctx, int nlocal, int nghost, const double 
 /* Options. key = "force_volume" (1: always run the overlap-volume root finder,
  * even when exponent == 1 and eflag == 0), "timing" (1: bracket the pair
  * kernels with hipEvents for shpair_get_stats), "count" (1: count contact
- * pairs every call), "variant" (1: force the run-time-order loop kernel), "ring_rows" (> 0:
+ * pairs every call), "variant" (1: force the run-time-order loop kernel), "rule" (0: sharp inside
+ * test, the default; 1: the covered-fraction weights of docs/SPEC.md §2.8 — `pair_style sh <nq> rule weighted`;
+ * needs lmax <= 12 and nq <= 32), "ring_rows" (> 0:
  * override the number of quadrature rings whose tables are LDS resident at a time; tuning). */
 int shpair_set_option(shpair_ctx *ctx, const char *key, int value);
 

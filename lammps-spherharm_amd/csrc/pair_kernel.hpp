@@ -70,6 +70,7 @@ struct PairParams {
   const double* glw;    // nq weights
   const double* cpsi;   // 2nq cos(psi_l)
   const double* spsi;   // 2nq sin(psi_l)
+  int rule;             // 0: sharp inside test (SPEC §2.5); 1: covered-fraction weights (SPEC §2.8)
   double* eatom;        // nullable: per-atom energy  [nall], LAMMPS eatom (ev_tally_xyz halves)
   double* vatom;        // nullable: per-atom virial  [nall][6] (xx,yy,zz,xy,xz,yz)
   const double* trig;   // (cos m psi_l, sin m psi_l) at trig[(m - 2) * trig_stride + 2 l], m = 2..lmax: for one m the
@@ -112,9 +113,10 @@ enum { FR_BJ1 = 0, FR_BJ2 = 3, FR_BJC = 6, FR_DJ = 9, FR_E1 = 12, FR_E2 = 15, FR
 
 struct WaveLdsLayout {
   int trig, v0, v1, ring, qri, qrj, qp, bytes;  // offsets in doubles (qp: in doubles too), total bytes
+  int qw;                                        // weighted rule only: the queued nodes' weights
   int coef;                                      // SHP_COEF_LDS ablation build only
 };
-__host__ __device__ inline WaveLdsLayout wave_lds_layout(const int L, const int rows)
+__host__ __device__ inline WaveLdsLayout wave_lds_layout(const int L, const int rows, const bool weighted = false)
 {
   WaveLdsLayout w;
   const int ns = (L + 1) * (L + 1);
@@ -126,7 +128,8 @@ __host__ __device__ inline WaveLdsLayout wave_lds_layout(const int L, const int 
   w.qri = w.ring + 4 * rows * (L + 1);
   w.qrj = w.qri + kQueue;
   w.qp = w.qrj + kQueue;
-  w.coef = w.qp + kQueue / 2;
+  w.qw = w.qp + kQueue / 2;
+  w.coef = w.qw + (weighted ? kQueue : 0);
   w.coef += w.coef & 1;
 #ifdef SHP_COEF_LDS
   w.bytes = 8 * (w.coef + sh_chunk_stride(L));
@@ -375,8 +378,12 @@ __device__ __forceinline__ void ring_eval(const double* __restrict__ row, const 
   }
 }
 
-template <int L, bool NEEDV>
-__global__ void __launch_bounds__(64 * kMaxWavesPerBlock, SHP_MIN_WAVES) pair_contact_kernel(const PairParams P)
+// WEIGHTED (SPEC §2.8): phase 1 keeps the residuals g~ of three consecutive slabs in registers, so that a
+// node's azimuth and ring neighbours are a cross-lane read away, and queues every node with a positive
+// covered fraction together with that fraction; phase 2 scales the node's weight by it.  All ring tables are
+// resident (one ring group), n_q <= 32 (a ring neighbour is at most one slab away): checked on the host.
+template <int L, bool NEEDV, bool WEIGHTED = false>
+__global__ void __launch_bounds__(64 * kMaxWavesPerBlock, WEIGHTED ? 4 : SHP_MIN_WAVES) pair_contact_kernel(const PairParams P)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int lane = threadIdx.x & 63;
@@ -385,7 +392,7 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, SHP_MIN_WAVES) pair_co
   if (w >= P.npairs) return;
   const int LL = (L >= 0) ? L : P.lmax;
   const int nq = P.nq;
-  const WaveLdsLayout W = wave_lds_layout(LL, P.ring_rows);
+  const WaveLdsLayout W = wave_lds_layout(LL, P.ring_rows, WEIGHTED);
   // The frame and ring tables are loop invariant: a plain LDS load would be
   // hoisted out of the node loops and pinned in VGPRs, which is what they are
   // in LDS to avoid.  Each loop iteration therefore re-derives its base pointer
@@ -493,10 +500,12 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, SHP_MIN_WAVES) pair_co
 
   double aV = 0.0, aS0 = 0.0, aS1 = 0.0, aS2 = 0.0, aT0 = 0.0, aT1 = 0.0, aT2 = 0.0;
   int qhead = 0, qcount = 0, slab = 0;  // wave-uniform
+  double wg1 = 0.0, wg2 = 0.0, wri1 = 0.0, wrj1 = 0.0;  // WEIGHTED: residuals of slabs t-1, t-2; r_i, r_j of slab t-1
+  bool win1 = false;
 
   // Ring groups: the tables of P.ring_rows consecutive rings are resident at a time (all nq of
   // them unless that would starve the CU of waves); the queue is drained at the end of a group.
-  while (slab < nslabs) {
+  while (WEIGHTED ? (slab == 0) : (slab < nslabs)) {   // WEIGHTED: one ring group holds all rings
   const int k0 = (int)(((unsigned)(slab << 6) * magic) >> 24);
   const int kend = (k0 + P.ring_rows < nq) ? k0 + P.ring_rows : nq;
   const int slab_end = (kend == nq) ? nslabs : ((kend * npsi) >> 6);
@@ -512,6 +521,90 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, SHP_MIN_WAVES) pair_co
   for (;;) {
     // ---------------------------------------------------------------- phase 1
     // classify slabs of 64 cap nodes until 64 inside nodes are queued
+    if constexpr (WEIGHTED) {
+    // iteration t: residuals of slab t (if any), then the weights of slab t - 1 from slabs t - 2, t - 1, t
+    while (qcount < 64 && slab <= nslabs) {
+      fr = SHP_LDS();
+      const int t = slab;
+      ++slab;
+      double g0 = 0.0, ri0 = 0.0, rj00 = 0.0;
+      bool in0 = false;
+      if (t < nslabs) {  // wave-uniform
+        const int p = (t << 6) + lane;
+        const bool valid = p < Q;
+        const int k = valid ? (int)(((unsigned)p * magic) >> 24) : 0;
+        const int l = valid ? p - k * npsi : 0;
+        const double* row = fr + W.ring + (k - k0) * rowlen;
+        const double mu = row[1], sig = row[3];
+        const double c1 = P.cpsi[l], s1 = P.spsi[l];
+        double ri, t0, t1;
+        ring_eval<L, false>(row, LL, c1, s1, P.trig + 2 * l, P.trig_stride, ri, t0, t1);
+        const double a1 = sig * c1, a2 = sig * s1;
+        const double uj0 = fma(a1, fr[FR_BJ1], fma(a2, fr[FR_BJ2], mu * fr[FR_BJC]));
+        const double uj1 = fma(a1, fr[FR_BJ1 + 1], fma(a2, fr[FR_BJ2 + 1], mu * fr[FR_BJC + 1]));
+        const double uj2 = fma(a1, fr[FR_BJ1 + 2], fma(a2, fr[FR_BJ2 + 2], mu * fr[FR_BJC + 2]));
+        const double q0 = fma(ri, uj0, -fr[FR_DJ]), q1 = fma(ri, uj1, -fr[FR_DJ + 1]),
+                     q2 = fma(ri, uj2, -fr[FR_DJ + 2]);
+        const double s2 = q0 * q0 + q1 * q1 + q2 * q2;
+        const bool cand = valid && (s2 < fr[FR_RJ2]);
+        const bool szero = !(s2 > 0.0);
+        const double inv = rsqrt_nr(fmax(s2, 1e-300));
+        const double sN = s2 * inv;
+        g0 = sN - fr[FR_RJ];  // outside B_j: the stand-in of SPEC §2.8 (>= 0)
+        double rj0 = fr[FR_RJ];
+        if (__any(cand)) {  // wave-uniform
+          const double rj0e = sh_eval<L>(rc, cwj, lrt, q0 * inv, q1 * inv, q2 * inv);
+          if (!szero) rj0 = rj0e;
+          if (cand) g0 = szero ? -rj0 : sN - rj0;
+        }
+        in0 = cand;
+        ri0 = ri;
+        rj00 = rj0;
+      }
+      if (t >= 1) {
+        const int p1 = ((t - 1) << 6) + lane;
+        const bool valid1 = p1 < Q;
+        const int k1 = valid1 ? (int)(((unsigned)p1 * magic) >> 24) : 0;
+        const int l1 = valid1 ? p1 - k1 * npsi : 0;
+        // neighbours as lane offsets within the three-slab window [t-2 | t-1 | t]
+        const int o_lp = (l1 == npsi - 1) ? -(npsi - 1) : 1;
+        const int o_lm = (l1 == 0) ? (npsi - 1) : -1;
+        const int o_k = (k1 < nq - 1) ? npsi : -npsi;
+        double nb[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+          const int idx = lane + (a == 0 ? o_lp : (a == 1 ? o_lm : o_k));
+          const int src = idx & 63;
+          const double v2 = __shfl(wg2, src, 64), v1 = __shfl(wg1, src, 64), v0 = __shfl(g0, src, 64);
+          nb[a] = (idx < 0) ? v2 : ((idx < 64) ? v1 : v0);
+        }
+        const double Dl = 0.5 * fabs(nb[0] - nb[1]);
+        const double Dk = (nq > 1) ? fabs(nb[2] - wg1) : 0.0;
+        const double den = Dk + Dl;
+        double wt = (wg1 < 0.0) ? 1.0 : 0.0;
+        if (den > 0.0) wt = fmin(1.0, fmax(0.0, fma(-wg1, rcp_nr(den), 0.5)));
+        const bool take = valid1 && win1 && (wt > 0.0);
+        const unsigned long long m = __ballot(take);
+        if (m != 0ULL) {
+          if (take) {
+            const int pos = (qhead + qcount + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32),
+                                                     __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u))) & (kQueue - 1);
+            double* lq = (double*)fr;
+            ((int*)(lq + W.qp))[pos] = p1;
+            lq[W.qri + pos] = wri1;
+            lq[W.qrj + pos] = wrj1;
+            lq[W.qw + pos] = (wg1 < 0.0) ? wt : -wt;  // the sign carries [g~ < 0] to phase 2 (no second opinion there)
+          }
+          qcount += __builtin_popcountll(m);
+        }
+      }
+      wg2 = wg1;
+      wg1 = g0;
+      wri1 = ri0;
+      wrj1 = rj00;
+      win1 = in0;
+    }
+    } else {
     while (qcount < 64 && slab < slab_end) {
       fr = SHP_LDS();
       const int p = (slab << 6) + lane;
@@ -563,6 +656,7 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, SHP_MIN_WAVES) pair_co
       }
       qcount += __builtin_popcountll(m);
     }
+    }
     if (qcount == 0) break;
 #if defined(SHP_ABL) && SHP_ABL == 3   // timing-only build: phase 1 only, the queue is discarded
     qhead = (qhead + qcount) & (kQueue - 1);
@@ -587,7 +681,13 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, SHP_MIN_WAVES) pair_co
     const double ri = fr[W.qri + e];
     const int k = (int)(((unsigned)p * magic) >> 24);
     const int l = p - k * npsi;
-    const double omi = active ? fr[FR_WSC] * P.glw[k] : 0.0;
+    double omi = active ? fr[FR_WSC] * P.glw[k] : 0.0;
+    bool outside = false;  // WEIGHTED: a node with g~ >= 0 has no ray segment inside j
+    if (WEIGHTED) {
+      const double qw = fr[W.qw + e];
+      outside = !(qw > 0.0);
+      omi *= fabs(qw);
+    }
     const double c1 = P.cpsi[l], s1 = P.spsi[l];
     double mu, sig;
     {
@@ -604,7 +704,7 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, SHP_MIN_WAVES) pair_co
       const double uj0 = fma(a1, fr[FR_BJ1], fma(a2, fr[FR_BJ2], mu * fr[FR_BJC]));
       const double uj1 = fma(a1, fr[FR_BJ1 + 1], fma(a2, fr[FR_BJ2 + 1], mu * fr[FR_BJC + 1]));
       const double uj2 = fma(a1, fr[FR_BJ1 + 2], fma(a2, fr[FR_BJ2 + 2], mu * fr[FR_BJC + 2]));
-      bool act = active && !centre_inside;
+      bool act = active && !centre_inside && !outside;
       // three most recent points: (xa,ga) oldest, (xb,gb), (lam,gl) newest
       double lo = 0.0, hi = ri, lam, xa = ri, ga, xb = ri, gb;
       {
@@ -671,7 +771,10 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, SHP_MIN_WAVES) pair_co
           }
         }
       }
-      aV = fma(omi * (1.0 / 3.0), ri * ri * ri - rin * rin * rin, aV);
+      // a node outside j contributes exactly nothing (r^3 - r^3 under FMA contraction is a rounding residue, and
+      // V^(m-1) turns a residue of 1e-22 into a visible force)
+      const double dv3 = (WEIGHTED && outside) ? 0.0 : ri * ri * ri - rin * rin * rin;
+      aV = fma(omi * (1.0 / 3.0), dv3, aV);
     }
 
     // surface gradient of i at the node, in the cap frame:
@@ -795,6 +898,15 @@ void launch_pair_contact(const PairParams& P, bool needv, hipStream_t st)
   const int wpb = P.waves_per_block;
   const dim3 grid((P.npairs + wpb - 1) / wpb), block(64 * wpb);
   const size_t lds = (size_t)wpb * P.wave_lds_bytes;
+  if (P.rule) {
+    // SPEC §2.8; one instantiation (with the volume path) serves both force laws
+    if constexpr (L >= 0) {
+      if (lds > 65536) (void)hipFuncSetAttribute((const void*)pair_contact_kernel<L, true, true>,
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL((pair_contact_kernel<L, true, true>), grid, block, lds, st, P);
+    }
+    return;
+  }
   if (needv) {
     if (lds > 65536) (void)hipFuncSetAttribute((const void*)pair_contact_kernel<L, true>,
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -462,6 +462,7 @@ int shpair_compute_device(shpair_ctx* c, int nlocal, int nghost, const double* x
   P.kn = c->d_kn.p; P.expo = c->d_expo.p; P.ntypes = c->ntypes;
   const int nq = c->nq;
   P.glt = c->d_quad.p; P.glw = c->d_quad.p + nq; P.cpsi = c->d_quad.p + 2 * nq; P.spsi = c->d_quad.p + 4 * nq;
+  P.rule = c->opt_rule;
   P.eatom = c->eatom_dev;
   P.vatom = c->vatom_dev;
   P.nq = nq;
@@ -483,7 +484,15 @@ int shpair_compute_device(shpair_ctx* c, int nlocal, int nghost, const double* x
     }
     if (rows < rows_min) rows = rows_min;
     if (rows > nq) rows = nq;
-    const WaveLdsLayout wl = wave_lds_layout(c->lmax, rows);
+    if (c->opt_rule) {
+      // SPEC §2.8: the weights of a slab need its neighbours' residuals, which the kernel keeps in a window of
+      // three slabs with every ring table resident
+      if (c->lmax > kMaxUnrolledL || c->opt_variant == 1 || nq > 32)
+        CTX_FAIL(c, SHPAIR_ELMAX, "the weighted rule needs lmax <= %d and nq <= 32 (have lmax %d, nq %d)", kMaxUnrolledL,
+                 c->lmax, nq);
+      rows = nq;
+    }
+    const WaveLdsLayout wl = wave_lds_layout(c->lmax, rows, c->opt_rule != 0);
     if (wl.bytes > 160 * 1024)
       CTX_FAIL(c, SHPAIR_ELMAX, "lmax %d with nq %d needs %d bytes of LDS per pair, more than a CU has", c->lmax, nq,
                wl.bytes);
@@ -643,6 +652,10 @@ int shpair_set_option(shpair_ctx* c, const char* key, int value)
   else if (!strcmp(key, "timing")) c->opt_timing = value ? 1 : 0;
   else if (!strcmp(key, "count")) c->opt_count = value ? 1 : 0;
   else if (!strcmp(key, "variant")) c->opt_variant = value;
+  else if (!strcmp(key, "rule")) {
+    if (value != 0 && value != 1) CTX_FAIL(c, SHPAIR_EINVAL, "rule %d is neither 0 (sharp) nor 1 (weighted)", value);
+    c->opt_rule = value;
+  }
   else if (!strcmp(key, "ring_rows")) c->opt_ring_rows = value;
   else if (!strcmp(key, "waves_per_block")) c->opt_wpb = value;
   else CTX_FAIL(c, SHPAIR_EINVAL, "unknown option '%s'", key);

@@ -42,7 +42,7 @@ using namespace LAMMPS_NS;
 /* ---------------------------------------------------------------------- */
 
 PairSH::PairSH(LAMMPS *lmp) :
-    Pair(lmp), ctx(nullptr), nq(16), device(-1), nshapes(0), kn(nullptr), exponent(nullptr), maxrad(0.0),
+    Pair(lmp), ctx(nullptr), nq(16), device(-1), rule(0), nshapes(0), kn(nullptr), exponent(nullptr), maxrad(0.0),
     last_neigh_build(-1)
 {
   single_enable = 0;
@@ -72,7 +72,7 @@ void PairSH::check(int rc, const char *what)
 }
 
 /* ----------------------------------------------------------------------
-   pair_style sh <nq> [device <id>] [shapes f1 f2 ...]
+   pair_style sh <nq> [device <id>] [rule sharp|weighted] [shapes f1 f2 ...]
 ------------------------------------------------------------------------- */
 
 void PairSH::settings(int narg, char **arg)
@@ -87,9 +87,16 @@ void PairSH::settings(int narg, char **arg)
       if (iarg + 2 > narg) error->all(FLERR, "Illegal pair_style sh command: device needs an id");
       device = atoi(arg[iarg + 1]);
       iarg += 2;
+    } else if (strcmp(arg[iarg], "rule") == 0) {
+      if (iarg + 2 > narg) error->all(FLERR, "Illegal pair_style sh command: rule needs sharp or weighted");
+      if (strcmp(arg[iarg + 1], "sharp") == 0) rule = 0;
+      else if (strcmp(arg[iarg + 1], "weighted") == 0) rule = 1;
+      else error->all(FLERR, "Illegal pair_style sh command: rule must be sharp or weighted");
+      iarg += 2;
     } else if (strcmp(arg[iarg], "shapes") == 0) {
       ++iarg;
-      while (iarg < narg && strcmp(arg[iarg], "device") != 0) shape_files.emplace_back(arg[iarg++]);
+      while (iarg < narg && strcmp(arg[iarg], "device") != 0 && strcmp(arg[iarg], "rule") != 0)
+        shape_files.emplace_back(arg[iarg++]);
       if (shape_files.empty()) error->all(FLERR, "Illegal pair_style sh command: shapes needs file names");
     } else
       error->all(FLERR, "Illegal pair_style sh command: unknown keyword");
@@ -111,6 +118,7 @@ void PairSH::settings(int narg, char **arg)
     }
   }
   check(shpair_settings(ctx, nq), "shpair_settings");
+  check(shpair_set_option(ctx, "rule", rule), "shpair_set_option(rule)");
 }
 
 void PairSH::allocate()

@@ -46,6 +46,7 @@ class PairSH : public Pair {
   struct shpair_ctx *ctx;
   int nq;                               // pair_style sh <nq>
   int device;                           // HIP device (default: local rank of the node communicator)
+  int rule;                             // 0 sharp inside test, 1 covered-fraction weights (docs/SPEC.md §2.8)
   std::vector<std::string> shape_files; // pair_style ... shapes f1 f2 ...
   int nshapes;
   double **kn, **exponent;              // [ntypes+1][ntypes+1], as pair_coeff sets them
