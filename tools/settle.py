@@ -4,7 +4,8 @@ the device-resident loop (shpair.run.DeviceRun).  Writes the settled state to an
 forces of the committed fixture are then computed by the CPU oracle (tests/golden/make_settled.py) —
 this script only produces INPUTS (positions and orientations).
 
-  python tools/settle.py gpurun_out/settled_cfg1.npz
+  python tools/settle.py gpurun_out/settled_cfg1.npz [sharp|weighted]
+(the committed fixture was made with the sharp rule; `weighted` is for comparing how quietly the bed rests)
 """
 import os
 import sys
@@ -22,7 +23,7 @@ LMAX, NQ, KN, EXPO = 4, 10, 1000.0, 1.25
 G = (0.0, 0.0, -10.0)
 
 
-def main(out):
+def main(out, rule="sharp"):
     rng = np.random.default_rng(bed.SEED0)
     shp = shapes.ellipsoid(1.0, 0.8, 0.6, LMAX)
     sp = ShPair(0)
@@ -30,6 +31,7 @@ def main(out):
     sp.set_ntypes(1, 1)
     sp.set_shape(0, LMAX, shp)
     sp.coeff(1, 1, KN, EXPO)
+    sp.set_option("rule", 1 if rule == "weighted" else 0)
     nf, fsp = 20, 1.3                       # floor: 20 x 20 frozen particles
     box = nf * fsp
     gx, gy = np.meshgrid(np.arange(nf), np.arange(nf), indexing="ij")
@@ -69,4 +71,4 @@ def main(out):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/settled_cfg1.npz")
+    main(sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/settled_cfg1.npz", sys.argv[2] if len(sys.argv) > 2 else "sharp")
