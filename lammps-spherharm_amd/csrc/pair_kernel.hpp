@@ -87,6 +87,11 @@ struct PairParams {
 };
 
 constexpr int kMaxWavesPerBlock = 4;
+// The same for the WEIGHTED variant (three-slab window): 5 fits without spills up to L = 6 (A/B at L = 6:
+// n_q = 16 5.29 -> 5.12 ms, n_q = 8 2.45 -> 2.27 ms); from L = 7 it would spill 25-30 VGPRs, so 4 there.
+#ifndef SHP_WMIN_WAVES
+#define SHP_WMIN_WAVES(L) (((L) >= 0 && (L) <= 6) ? 5 : 4)
+#endif
 #ifndef SHP_MIN_WAVES
 #define SHP_MIN_WAVES 5  // waves per SIMD the register allocator must leave room for (<= 96 VGPRs); A/B: 5 beats 4 and 6
 #endif
@@ -383,7 +388,7 @@ __device__ __forceinline__ void ring_eval(const double* __restrict__ row, const 
 // covered fraction together with that fraction; phase 2 scales the node's weight by it.  All ring tables are
 // resident (one ring group), n_q <= 32 (a ring neighbour is at most one slab away): checked on the host.
 template <int L, bool NEEDV, bool WEIGHTED = false>
-__global__ void __launch_bounds__(64 * kMaxWavesPerBlock, WEIGHTED ? 4 : SHP_MIN_WAVES) pair_contact_kernel(const PairParams P)
+__global__ void __launch_bounds__(64 * kMaxWavesPerBlock, WEIGHTED ? SHP_WMIN_WAVES(L) : SHP_MIN_WAVES) pair_contact_kernel(const PairParams P)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int lane = threadIdx.x & 63;

@@ -18,6 +18,7 @@ ap.add_argument("--nq", type=int, default=16)
 ap.add_argument("--expo", type=float, default=1.25)
 ap.add_argument("--n", type=int, default=100000)
 ap.add_argument("--rounds", type=int, default=5)
+ap.add_argument("--rule", type=int, default=0, help="0 sharp, 1 weighted (docs/SPEC.md §2.8)")
 ap.add_argument("--wpb", type=int, nargs="*", default=[0], help="waves per workgroup per lib (0 = default)")
 ap.add_argument("--ring-rows", type=int, nargs="*", default=[0], help="one value per lib (0 = library default)")
 a = ap.parse_args()
@@ -44,6 +45,8 @@ for sp, rows, w in zip(ctxs, rr, wp):
         b = bed.make_bed(a.n, rmax, seed=bed.SEED0 + 2)
         il, of, jl = bed.half_neighbor_list(b["x"], b["shtype"], rmax)
     sp.set_neighbors_csr(il, of, jl)
+    if a.rule:
+        sp.set_option("rule", a.rule)
     sp.set_option("timing", 1)
 dev = torch.device("cuda:0")
 x = torch.from_numpy(b["x"]).to(dev)
