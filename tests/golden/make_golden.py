@@ -27,6 +27,8 @@ CONFIGS = {
     "cfg2_L6_single": (30, 6, 16, 1, 1000.0, 1.25, "random"),
     "cfg3_L6_mixed4": (30, 6, 16, 4, 1000.0, 1.0, "random"),
     "cfg5_L12_high": (24, 12, 32, 1, 1000.0, 1.5, "random"),
+    # the optional weighted cap rule (docs/SPEC.md §2.8) on the config-2 bed at a ring length that straddles slabs
+    "cfg2w_L6_weighted": (30, 6, 12, 2, 1000.0, 1.25, "random"),
 }
 
 
@@ -44,10 +46,13 @@ def build(name):
     il, of, jl = bed.half_neighbor_list(b["x"], b["shtype"], rmax)
     K = np.full((2, 2), kn)
     E = np.full((2, 2), expo)
+    rule = 1 if "weighted" in name else 0
+    O.set_rule(rule)
     o = O.compute([(lmax, a, r) for a, r in zip(shp, rmax)], K, E, nq, n, b["x"], b["quat"], b["type"],
                   b["shtype"], il, of, jl, eflag=True, vflag=True, want_pairs=True)
+    O.set_rule(0)
     assert jl.size <= 100 and o["counts"][2] > 10, (name, jl.size, o["counts"])
-    return dict(lmax=lmax, nq=nq, kn=kn, exponent=expo, anm=np.stack(shp), rmax=np.array(rmax), x=b["x"],
+    return dict(rule=rule, lmax=lmax, nq=nq, kn=kn, exponent=expo, anm=np.stack(shp), rmax=np.array(rmax), x=b["x"],
                 quat=b["quat"], type=b["type"], shtype=b["shtype"], ilist=il, offsets=of, jlist=jl, f=o["f"],
                 torque=o["torque"], eng_virial=o["eng_virial"], counts=o["counts"], pairs=o["pairs"])
 

@@ -11,7 +11,7 @@ SETTLED = os.path.join(HERE, "golden", "settled_cfg1_L4.npz")
 
 
 def test_fixtures_exist():
-    assert len(GOLDEN) == 4 and os.path.exists(SETTLED)
+    assert len(GOLDEN) == 5 and os.path.exists(SETTLED)
 
 
 @pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p)[:-4] for p in GOLDEN])
@@ -20,9 +20,13 @@ def test_oracle_reproduces_golden(oracle, path):
     lmax, nq = int(g["lmax"]), int(g["nq"])
     K = np.full((2, 2), float(g["kn"]))
     E = np.full((2, 2), float(g["exponent"]))
-    o = oracle.compute([(lmax, a, r) for a, r in zip(g["anm"], g["rmax"])], K, E, nq, g["x"].shape[0], g["x"],
-                       g["quat"], g["type"], g["shtype"], g["ilist"], g["offsets"], g["jlist"], eflag=True,
-                       vflag=True, want_pairs=True)
+    oracle.set_rule(int(g["rule"]) if "rule" in g else 0)
+    try:
+        o = oracle.compute([(lmax, a, r) for a, r in zip(g["anm"], g["rmax"])], K, E, nq, g["x"].shape[0], g["x"],
+                           g["quat"], g["type"], g["shtype"], g["ilist"], g["offsets"], g["jlist"], eflag=True,
+                           vflag=True, want_pairs=True)
+    finally:
+        oracle.set_rule(0)
     fs = np.abs(g["f"]).max()
     assert np.abs(o["f"] - g["f"]).max() < 1e-12 * fs
     assert np.abs(o["torque"] - g["torque"]).max() < 1e-12 * fs

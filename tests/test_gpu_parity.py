@@ -114,6 +114,7 @@ def test_golden_vectors(path):
     sp.coeff("*", "*", float(g["kn"]), float(g["exponent"]))
     sp.set_neighbors_csr(g["ilist"], g["offsets"], g["jlist"])
     sp.set_option("count", 1)
+    sp.set_option("rule", int(g["rule"]) if "rule" in g else 0)
     f, tq, eng, vir = sp.compute(g["x"].shape[0], g["x"], g["quat"], g["type"], g["shtype"], eflag=True, vflag=True)
     fs = np.abs(g["f"]).max()
     assert np.abs(f - g["f"]).max() < TOL * fs
