@@ -469,6 +469,10 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, WEIGHTED ? SHP_WMIN_WA
     return;
 #endif
     cap_frame_rotate<L>(P, lw, W, LL, si, lane, b1, b2, bc);
+#if defined(SHP_ABL) && SHP_ABL == 4   // timing-only build: stop after the coefficient rotation
+    asm volatile("" ::"v"(lw[W.v0 + lane]));
+    return;
+#endif
   }
 
   const double* rc = P.rc;
