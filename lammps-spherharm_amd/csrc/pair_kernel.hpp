@@ -691,7 +691,8 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, WEIGHTED ? SHP_WMIN_WA
     const int k = (int)(((unsigned)p * magic) >> 24);
     const int l = p - k * npsi;
     double omi = active ? fr[FR_WSC] * P.glw[k] : 0.0;
-    bool outside = false;  // WEIGHTED: a node with g~ >= 0 has no ray segment inside j
+    const double omv = omi;  // the volume keeps the node's plain weight (SPEC §2.8)
+    bool outside = false;    // WEIGHTED: a node with g~ >= 0 has no ray segment inside j
     if (WEIGHTED) {
       const double qw = fr[W.qw + e];
       outside = !(qw > 0.0);
@@ -783,7 +784,7 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, WEIGHTED ? SHP_WMIN_WA
       // a node outside j contributes exactly nothing (r^3 - r^3 under FMA contraction is a rounding residue, and
       // V^(m-1) turns a residue of 1e-22 into a visible force)
       const double dv3 = (WEIGHTED && outside) ? 0.0 : ri * ri * ri - rin * rin * rin;
-      aV = fma(omi * (1.0 / 3.0), dv3, aV);
+      aV = fma(omv * (1.0 / 3.0), dv3, aV);
     }
 
     // surface gradient of i at the node, in the cap frame:

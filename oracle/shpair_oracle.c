@@ -401,7 +401,7 @@ static int sho_pair_weighted(int Li, const double *anmi, double Ri, int Lj, cons
       if (!need_volume || !(g < 0.0)) continue;
       double rin = 0.0;
       if (!centre_inside) rin = inner_radius(Lj, anmj, Rj, Rmj, u, d, dj, rho, rho2, ri, S[p], RJ0[p], diag);
-      out[0] += ow * (ri * ri * ri - rin * rin * rin) / 3.0;
+      out[0] += om * (ri * ri * ri - rin * rin * rin) / 3.0;  /* unweighted: the integrand vanishes at the boundary */
     }
   }
   free(G);

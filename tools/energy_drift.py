@@ -10,7 +10,7 @@ sys.path.insert(0, os.path.join(ROOT, "lammps-spherharm_amd"))
 from shpair import ShPair, shapes  # noqa: E402
 
 
-def run(m, jitter, nq, dt, nsteps, lmax=4, kn=200.0, expo=1.5, skin=0.3, seed=63):
+def run(m, jitter, nq, dt, nsteps, lmax=4, kn=200.0, expo=1.5, skin=0.3, seed=63, rule=0):
     rng = np.random.default_rng(seed)
     shp = shapes.random_shape(lmax, 50, amp=0.2)
     sp = ShPair(0)
@@ -18,6 +18,7 @@ def run(m, jitter, nq, dt, nsteps, lmax=4, kn=200.0, expo=1.5, skin=0.3, seed=63
     sp.set_ntypes(1, 1)
     sp.set_shape(0, lmax, shp)
     sp.coeff(1, 1, kn, expo)
+    sp.set_option("rule", rule)
     box = np.array([m, m, m]) * 1.9
     g = np.stack(np.meshgrid(*[np.arange(m)] * 3, indexing="ij"), -1).reshape(-1, 3)
     x0 = (g + 0.5) * 1.9 + rng.uniform(-jitter, jitter, (g.shape[0], 3))
@@ -79,10 +80,12 @@ def run(m, jitter, nq, dt, nsteps, lmax=4, kn=200.0, expo=1.5, skin=0.3, seed=63
 
 if __name__ == "__main__":
     T = 0.3
-    for jitter in (0.3, 0.1):
-        for nq in (8, 12, 24):
-            for dt in (2e-3, 1e-3, 5e-4):
-                e0, e1, hist, nb = run(8, jitter, nq, dt, int(round(T / dt)))
+    rules = (0, 1) if len(sys.argv) > 1 and sys.argv[1] == "rules" else (0,)
+    for rule in rules:
+      for jitter in ((0.1,) if len(rules) > 1 else (0.3, 0.1)):
+        for nq in ((8, 12) if len(rules) > 1 else (8, 12, 24)):
+            for dt in ((1e-3, 5e-4) if len(rules) > 1 else (2e-3, 1e-3, 5e-4)):
+                e0, e1, hist, nb = run(8, jitter, nq, dt, int(round(T / dt)), rule=rule)
                 tot0, tot1 = sum(e0), sum(e1)
-                print(f"jitter {jitter} nq {nq:2d} dt {dt:.0e}: E0 {tot0:.4f} (pe) -> pe {e1[0]:.2f} ket {e1[1]:.2f} ker {e1[2]:.2f}; "
+                print(f"rule {rule} jitter {jitter} nq {nq:2d} dt {dt:.0e}: E0 {tot0:.4f} (pe) -> pe {e1[0]:.2f} ket {e1[1]:.2f} ker {e1[2]:.2f}; "
                       f"drift {(tot1 - tot0) / tot0:+.3e}  builds {nb}  hist {[f'{(h - tot0) / tot0:+.1e}' for h in hist]}", flush=True)
