@@ -511,6 +511,7 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, WEIGHTED ? SHP_WMIN_WA
   int qhead = 0, qcount = 0, slab = 0;  // wave-uniform
   double wg1 = 0.0, wg2 = 0.0, wri1 = 0.0, wrj1 = 0.0;  // WEIGHTED: residuals of slabs t-1, t-2; r_i, r_j of slab t-1
   bool win1 = false;
+  const bool aligned = (npsi <= 64) && ((64 % npsi) == 0);  // wave-uniform
 
   // Ring groups: the tables of P.ring_rows consecutive rings are resident at a time (all nq of
   // them unless that would starve the CU of waves); the queue is drained at the end of a group.
@@ -575,17 +576,33 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, WEIGHTED ? SHP_WMIN_WA
         const bool valid1 = p1 < Q;
         const int k1 = valid1 ? (int)(((unsigned)p1 * magic) >> 24) : 0;
         const int l1 = valid1 ? p1 - k1 * npsi : 0;
-        // neighbours as lane offsets within the three-slab window [t-2 | t-1 | t]
-        const int o_lp = (l1 == npsi - 1) ? -(npsi - 1) : 1;
-        const int o_lm = (l1 == 0) ? (npsi - 1) : -1;
-        const int o_k = (k1 < nq - 1) ? npsi : -npsi;
         double nb[3];
+        if (aligned) {
+          // rings do not straddle slabs (n_psi divides 64): the azimuth neighbours sit in slab t-1 itself and the
+          // ring neighbour one ring further in slab t-1 or at the start of slab t (n_psi = 64: the same lane of
+          // slab t, or of slab t-2 for the last ring) — 4 (2) cross-lane reads instead of 9
+          const int base = lane & ~(npsi - 1);
+          nb[0] = __shfl(wg1, base | ((lane + 1) & (npsi - 1)), 64);
+          nb[1] = __shfl(wg1, base | ((lane - 1) & (npsi - 1)), 64);
+          if (npsi == 64) {
+            nb[2] = (k1 < nq - 1) ? g0 : wg2;
+          } else {
+            const int idx = lane + ((k1 < nq - 1) ? npsi : -npsi);
+            const double v1 = __shfl(wg1, idx & 63, 64), v0 = __shfl(g0, idx & 63, 64);
+            nb[2] = (idx < 64) ? v1 : v0;
+          }
+        } else {
+          // neighbours as lane offsets within the three-slab window [t-2 | t-1 | t]
+          const int o_lp = (l1 == npsi - 1) ? -(npsi - 1) : 1;
+          const int o_lm = (l1 == 0) ? (npsi - 1) : -1;
+          const int o_k = (k1 < nq - 1) ? npsi : -npsi;
 #pragma unroll
-        for (int a = 0; a < 3; ++a) {
-          const int idx = lane + (a == 0 ? o_lp : (a == 1 ? o_lm : o_k));
-          const int src = idx & 63;
-          const double v2 = __shfl(wg2, src, 64), v1 = __shfl(wg1, src, 64), v0 = __shfl(g0, src, 64);
-          nb[a] = (idx < 0) ? v2 : ((idx < 64) ? v1 : v0);
+          for (int a = 0; a < 3; ++a) {
+            const int idx = lane + (a == 0 ? o_lp : (a == 1 ? o_lm : o_k));
+            const int src = idx & 63;
+            const double v2 = __shfl(wg2, src, 64), v1 = __shfl(wg1, src, 64), v0 = __shfl(g0, src, 64);
+            nb[a] = (idx < 0) ? v2 : ((idx < 64) ? v1 : v0);
+          }
         }
         const double Dl = 0.5 * fabs(nb[0] - nb[1]);
         const double Dk = (nq > 1) ? fabs(nb[2] - wg1) : 0.0;
