@@ -509,8 +509,8 @@ def test_step_entry_points_with_no_particles_and_far_wraps(oracle):
     sp.close()
 
 
-@pytest.mark.parametrize("use_graph", [False, True])
-def test_native_run_loop_matches_the_python_driver(oracle, use_graph):
+@pytest.mark.parametrize("use_graph,rule", [(False, 0), (True, 0), (True, 1)])
+def test_native_run_loop_matches_the_python_driver(oracle, use_graph, rule):
     """shstep_run_device (C++ loop in the library, optionally replayed from hipGraphs) takes the same steps as
     the call-by-call driver: same rebuild decisions, same trajectory (forces are atomically summed, so
     equality is to rounding, not bitwise)."""
@@ -519,6 +519,7 @@ def test_native_run_loop_matches_the_python_driver(oracle, use_graph):
     runs = []
     for native in (False, True):
         sp = make_ctx(case["shapes"], case["lmax"], nq=8, kn=300.0, expo=1.25, rho=[1.0, 1.4])
+        sp.set_option("rule", rule)                      # 1: the weighted cap rule inside the captured graphs
         r = DeviceRun(sp, case["x"], case["quat"], case["shtype"], case["lo"], case["hi"], case["periodic"], case["skin"],
                       dt=2e-3, gravity=(0.0, 0.0, -2.0), gamma_t=0.3, gamma_r=0.1)
         if native:
