@@ -1,9 +1,10 @@
-"""Synthetic spherical-harmonic shapes for the BASELINE.json configs (setup only).
+"""Spherical-harmonic shapes: synthetic ones for the BASELINE.json configs, the text file format the PairSH
+adapter reads, and a least-squares fit of an expansion to surface points (setup only).
 
 Coefficient storage follows docs/SPEC.md §1: a_nm for m >= 0, n-major,
 anm[2k] = Re, anm[2k+1] = Im with k = n(n+1)/2 + m; scipy `sph_harm_y`
 normalisation and phase.  The reference's shape-file reader is ABSENT FROM
-MOUNT, so shapes are generated, not read.
+MOUNT: the file format below is this repo's own.
 """
 import numpy as np
 
@@ -99,3 +100,89 @@ def random_shape(lmax, seed, amp=0.1, rmin=0.5):
             break
         scale *= 0.8
     return anm.ravel()
+
+
+# ---- shape files and fitting (the data format on the input side of the path) --------------------------------
+# Text format read by the PairSH adapter (lammps/pair_sh.cpp::load_shapes): first line `lmax`, then one line
+# `n m Re(a_nm) Im(a_nm)` per stored coefficient, m >= 0.  The reference's own format is unknown (its reader
+# is absent from the mount), so this is the repo's format, not a reimplementation of theirs.
+
+def write_shape_file(path, lmax, anm):
+    a = np.asarray(anm, dtype=np.float64).reshape(-1, 2)
+    if a.shape[0] != nterms(lmax):
+        raise ValueError(f"anm has {a.shape[0]} terms, lmax {lmax} needs {nterms(lmax)}")
+    with open(path, "w") as fp:
+        fp.write(f"{lmax}\n")
+        for n in range(lmax + 1):
+            for m in range(n + 1):
+                k = n * (n + 1) // 2 + m
+                fp.write(f"{n} {m} {float(a[k, 0])!r} {float(a[k, 1])!r}\n")
+
+
+def read_shape_file(path):
+    """Returns (lmax, anm). Coefficients that the file does not list are zero; Im(a_n0) must be zero."""
+    with open(path) as fp:
+        lines = [ln.split("#")[0].strip() for ln in fp]
+    lines = [ln for ln in lines if ln]
+    lmax = int(lines[0])
+    a = np.zeros((nterms(lmax), 2))
+    for ln in lines[1:]:
+        n, m, re, im = ln.split()
+        n, m = int(n), int(m)
+        if not (0 <= m <= n <= lmax):
+            raise ValueError(f"{path}: (n, m) = ({n}, {m}) outside lmax {lmax}")
+        if m == 0 and float(im) != 0.0:
+            raise ValueError(f"{path}: a_{n}0 must be real")
+        a[n * (n + 1) // 2 + m] = (float(re), float(im))
+    return lmax, a.ravel()
+
+
+def basis_matrix(lmax, u):
+    """Real design matrix B with r(u_k) = B[k] @ anm for the SPEC storage (column 2k: Re a, 2k+1: Im a)."""
+    u = np.asarray(u, dtype=np.float64)
+    nt = nterms(lmax)
+    B = np.zeros((u.shape[0], 2 * nt))
+    e = np.zeros(2 * nt)
+    for c in range(2 * nt):
+        if c % 2 == 1 and _m_of(c // 2) == 0:
+            continue          # Im a_n0 does not enter r
+        e[:] = 0.0
+        e[c] = 1.0
+        B[:, c] = sh_radius_np(lmax, e, u)
+    return B
+
+
+def _m_of(k):
+    n = int((np.sqrt(8 * k + 1) - 1) // 2)
+    return k - n * (n + 1) // 2
+
+
+def fit_points(points, lmax, centre=None, ridge=0.0):
+    """Least-squares SH expansion of a star-shaped surface sampled by `points` (N x 3, e.g. the vertices of a
+    scanned grain): r(u_k) = |p_k - centre| in direction u_k.  centre defaults to the mean of the points.
+    ridge > 0 adds n^2 (n+1)^2 smoothing (useful when N is small for the order).
+    Returns (anm, centre, rms residual)."""
+    p = np.asarray(points, dtype=np.float64)
+    c = p.mean(axis=0) if centre is None else np.asarray(centre, dtype=np.float64)
+    d = p - c
+    r = np.linalg.norm(d, axis=1)
+    if not np.all(r > 0):
+        raise ValueError("a point coincides with the centre")
+    B = basis_matrix(lmax, d / r[:, None])
+    use = np.array([not (cidx % 2 == 1 and _m_of(cidx // 2) == 0) for cidx in range(B.shape[1])])
+    A = B[:, use]
+    if ridge > 0.0:
+        pen = []
+        for cidx in np.flatnonzero(use):
+            k = cidx // 2
+            n = int((np.sqrt(8 * k + 1) - 1) // 2)
+            pen.append(np.sqrt(ridge) * n * (n + 1))
+        A = np.vstack([A, np.diag(pen)])
+        rhs = np.concatenate([r, np.zeros(len(pen))])
+    else:
+        rhs = r
+    sol, *_ = np.linalg.lstsq(A, rhs, rcond=None)
+    anm = np.zeros(B.shape[1])
+    anm[use] = sol
+    res = B @ anm - r
+    return anm, c, float(np.sqrt(np.mean(res * res)))
