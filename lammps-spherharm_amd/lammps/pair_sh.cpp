@@ -150,22 +150,47 @@ void PairSH::load_shapes()
   for (int s = 0; s < nshapes; s++) {
     FILE *fp = fopen(shape_files[s].c_str(), "r");
     if (!fp) error->one(FLERR, "pair sh: cannot open shape file");
+    // line based: `#` starts a comment, blank lines are skipped; first data line `lmax`, then `n m Re Im`
+    // for any subset of the coefficients (the others are zero); anything else is an error, not an end of file
     int lmax = -1;
-    if (fscanf(fp, "%d", &lmax) != 1 || lmax < 0 || lmax > SHPAIR_MAX_LMAX) {
-      fclose(fp);
-      error->one(FLERR, "pair sh: bad lmax in shape file");
-    }
-    std::vector<double> anm((size_t) (lmax + 1) * (lmax + 2), 0.0);
-    int n, m;
-    double re, im;
-    while (fscanf(fp, "%d %d %lf %lf", &n, &m, &re, &im) == 4) {
+    std::vector<double> anm;
+    char line[512];
+    while (fgets(line, sizeof(line), fp)) {
+      if (char *hash = strchr(line, '#')) *hash = '\0';
+      char *p = line;
+      while (*p == ' ' || *p == '\t' || *p == '\r' || *p == '\n') ++p;
+      if (*p == '\0') continue;
+      if (lmax < 0) {
+        char extra;
+        if (sscanf(p, "%d %c", &lmax, &extra) != 1 || lmax < 0 || lmax > SHPAIR_MAX_LMAX) {
+          fclose(fp);
+          error->one(FLERR, "pair sh: bad lmax in shape file");
+        }
+        anm.assign((size_t) (lmax + 1) * (lmax + 2), 0.0);
+        continue;
+      }
+      int n, m;
+      double re, im;
+      char extra;
+      if (sscanf(p, "%d %d %lf %lf %c", &n, &m, &re, &im, &extra) != 4) {
+        fclose(fp);
+        error->one(FLERR, "pair sh: malformed line in shape file (expected: n m Re Im)");
+      }
       if (n < 0 || n > lmax || m < 0 || m > n) {
         fclose(fp);
         error->one(FLERR, "pair sh: (n, m) out of range in shape file");
       }
+      if (m == 0 && im != 0.0) {
+        fclose(fp);
+        error->one(FLERR, "pair sh: a_n0 must be real in shape file");
+      }
       const int k = n * (n + 1) / 2 + m;
       anm[2 * k] = re;
       anm[2 * k + 1] = im;
+    }
+    if (lmax < 0) {
+      fclose(fp);
+      error->one(FLERR, "pair sh: empty shape file");
     }
     fclose(fp);
     check(shpair_set_shape(ctx, s, lmax, anm.data(), 0.0), "shpair_set_shape");

@@ -35,16 +35,14 @@ def write_inputs(tmp_path, case, nlocal, newton, eflag):
         for ii in rows:
             js = jl[of[ii]:of[ii + 1]]
             fp.write(f"{case['ilist'][ii]} {len(js)} " + " ".join(str(int(j)) for j in js) + "\n")
+    from shpair import shapes as shp_mod
     shapes = []
     for s, a in enumerate(case["shapes"]):
         p = tmp_path / f"shape{s}.txt"
-        a2 = np.asarray(a).reshape(-1, 2)
-        with open(p, "w") as fp:
-            fp.write(f"{case['lmax']}\n")
-            for nn in range(case["lmax"] + 1):
-                for m in range(nn + 1):
-                    k = nn * (nn + 1) // 2 + m
-                    fp.write(f"{nn} {m} {float(a2[k, 0])!r} {float(a2[k, 1])!r}\n")
+        shp_mod.write_shape_file(p, case["lmax"], a)
+        # the adapter's reader takes comments and blank lines too
+        txt = open(p).read().split("\n")
+        open(p, "w").write("# shape %d of the test bed\n\n" % s + txt[0] + "   # lmax\n" + "\n".join(txt[1:]))
         shapes.append(str(p))
     return str(bedf), shapes
 
