@@ -385,8 +385,8 @@ __device__ __forceinline__ void ring_eval(const double* __restrict__ row, const 
 
 // WEIGHTED (SPEC §2.8): phase 1 keeps the residuals g~ of three consecutive slabs in registers, so that a
 // node's azimuth and ring neighbours are a cross-lane read away, and queues every node with a positive
-// covered fraction together with that fraction; phase 2 scales the node's weight by it.  All ring tables are
-// resident (one ring group), n_q <= 32 (a ring neighbour is at most one slab away): checked on the host.
+// covered fraction together with that fraction; phase 2 scales the node's weight by it.  n_q <= 32 (a ring
+// neighbour is at most one slab away) and ring groups of at least two slabs' worth of rings: checked on the host.
 template <int L, bool NEEDV, bool WEIGHTED = false>
 __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, WEIGHTED ? SHP_WMIN_WAVES(L) : SHP_MIN_WAVES) pair_contact_kernel(const PairParams P)
 {
@@ -515,10 +515,15 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, WEIGHTED ? SHP_WMIN_WA
 
   // Ring groups: the tables of P.ring_rows consecutive rings are resident at a time (all nq of
   // them unless that would starve the CU of waves); the queue is drained at the end of a group.
-  while (WEIGHTED ? (slab == 0) : (slab < nslabs)) {   // WEIGHTED: one ring group holds all rings
-  const int k0 = (int)(((unsigned)(slab << 6) * magic) >> 24);
+  // WEIGHTED: iteration t = slab computes slab t and weighs slab t - 1, so a group starts at the ring of the
+  // still unweighed slab (its nodes are queued, and read their ring rows, only after the switch) and the last
+  // group runs one iteration past the last slab.  The host sizes ring_rows so that every group advances.
+  while (WEIGHTED ? (slab <= nslabs) : (slab < nslabs)) {
+  const int sfirst = (WEIGHTED && slab > 0) ? slab - 1 : slab;
+  const int k0 = (int)(((unsigned)(sfirst << 6) * magic) >> 24);
   const int kend = (k0 + P.ring_rows < nq) ? k0 + P.ring_rows : nq;
-  const int slab_end = (kend == nq) ? nslabs : ((kend * npsi) >> 6);
+  const int slab_end = (kend == nq) ? (WEIGHTED ? nslabs + 1 : nslabs) : ((kend * npsi) >> 6);
+  if (slab_end <= slab) return;  // cannot happen with the host's ring_rows; never spin
   {
     double* lr = SHP_LDS();
     cap_frame_rings<L>(P, lr, W, LL, lane, k0, kend - k0, lr[FR_HW], lr[FR_HM]);
@@ -533,7 +538,7 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, WEIGHTED ? SHP_WMIN_WA
     // classify slabs of 64 cap nodes until 64 inside nodes are queued
     if constexpr (WEIGHTED) {
     // iteration t: residuals of slab t (if any), then the weights of slab t - 1 from slabs t - 2, t - 1, t
-    while (qcount < 64 && slab <= nslabs) {
+    while (qcount < 64 && slab < slab_end) {
       fr = SHP_LDS();
       const int t = slab;
       ++slab;

@@ -486,11 +486,20 @@ int shpair_compute_device(shpair_ctx* c, int nlocal, int nghost, const double* x
     if (rows > nq) rows = nq;
     if (c->opt_rule) {
       // SPEC §2.8: the weights of a slab need its neighbours' residuals, which the kernel keeps in a window of
-      // three slabs with every ring table resident
+      // three slabs; a ring group must hold the rings of the slab being weighed and of the next one
       if (c->lmax > kMaxUnrolledL || c->opt_variant == 1 || nq > 32)
         CTX_FAIL(c, SHPAIR_ELMAX, "the weighted rule needs lmax <= %d and nq <= 32 (have lmax %d, nq %d)", kMaxUnrolledL,
                  c->lmax, nq);
-      rows = nq;
+      // the queue carries the weights too (+1 KB): all rings resident up to 8.75 KB per wave (18 waves per CU;
+      // L = 6, n_q = 16 needs 8.5 KB and runs 6 % faster that way than in two groups), 8 KB groups beyond
+      rows = (c->opt_ring_rows > 0) ? c->opt_ring_rows : nq;
+      if (c->opt_ring_rows <= 0 && wave_lds_layout(c->lmax, nq, true).bytes > 8960) {
+        const int fixed = wave_lds_layout(c->lmax, 0, true).bytes;
+        rows = (8 * 1024 - fixed) / (32 * (c->lmax + 1));
+      }
+      const int rows_min_w = 2 + (127 + npsi - 1) / npsi;
+      if (rows < rows_min_w) rows = rows_min_w;
+      if (rows > nq) rows = nq;
     }
     const WaveLdsLayout wl = wave_lds_layout(c->lmax, rows, c->opt_rule != 0);
     if (wl.bytes > 160 * 1024)

@@ -129,3 +129,25 @@ def test_weighted_rule_limits_are_refused(weighted):
     sp.set_option("rule", 0)                           # the sharp rule has no such limit
     sp.compute(40, case["bed"]["x"], case["bed"]["quat"], case["bed"]["type"], case["bed"]["shtype"])
     sp.close()
+
+
+@pytest.mark.parametrize("lmax,nq,rows", [(6, 16, 6), (6, 12, 8), (4, 10, 9), (12, 32, 0), (6, 31, 5), (8, 24, 1)])
+def test_weighted_rule_with_ring_groups(weighted, lmax, nq, rows):
+    """Ring tables resident a group at a time (forced small, or the library's own 8 KB policy for rows = 0): the
+    slab that is still unweighed when a group ends is carried in registers into the next group, whose tables start
+    at its first ring.  Same results as with all rings resident."""
+    n = 120 if nq >= 24 else 200
+    case = make_case(n, lmax, 2, seed=170 + lmax + nq, rmax_fn=weighted.shape_rmax)
+    K, E = coeff_tables(1, 900.0, 1.25)
+    sp = make_ctx(case, nq, K, E)
+    if rows:
+        sp.set_option("ring_rows", rows)           # clamped up to the minimum the window needs
+    b = case["bed"]
+    f, tq, eng, _ = sp.compute(n, b["x"], b["quat"], b["type"], b["shtype"], eflag=True)
+    o = oracle_compute(weighted, case, nq, K, E, eflag=True, nthreads=8)
+    fs = np.abs(o["f"]).max()
+    assert o["counts"][2] > 30
+    assert rel_err(f, o["f"], fs) < TOL
+    assert rel_err(tq, o["torque"], max(fs, np.abs(o["torque"]).max())) < TOL
+    assert abs(eng - o["eng_virial"][0]) < TOL * o["eng_virial"][0]
+    sp.close()
