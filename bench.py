@@ -370,21 +370,25 @@ def cpu_baseline(args, shp, rmax, gbed, il, of, jl):
     E = np.full((2, 2), args.exponent)
     sh_list = [(args.lmax, a, r) for a, r in zip(shp, rmax)]
 
-    def run(nrows):
+    def run(nrows, nt):
         t = time.perf_counter()
         o = O.compute(sh_list, K, E, args.nq, gbed["x"].shape[0], gbed["x"], gbed["quat"], gbed["type"],
-                      gbed["shtype"], il[:nrows], of[:nrows + 1], jl[:of[nrows]], nthreads=nthreads)
+                      gbed["shtype"], il[:nrows], of[:nrows + 1], jl[:of[nrows]], nthreads=nt)
         return time.perf_counter() - t, int(o["counts"][1])
     probe_rows = min(len(il), 2000)
-    t_probe, c_probe = run(probe_rows)
+    t_probe, c_probe = run(probe_rows, nthreads)
     rate = c_probe / max(t_probe, 1e-6)
     per_row = max(c_probe / probe_rows, 1e-9)
     nrows = int(min(len(il), max(probe_rows, args.cpu_seconds * rate / per_row)))
-    t_main, c_main = run(nrows)
+    t_main, c_main = run(nrows, nthreads)
+    # one thread, on a sample sized for about a fifth of the budget (a plain LAMMPS rank is one core)
+    rows1 = int(min(len(il), max(200, 0.2 * args.cpu_seconds * (rate / nthreads) / per_row)))
+    t_one, c_one = run(rows1, 1)
     return {"value": c_main / t_main, "unit": "contact-pairs/s", "cores": nthreads, "kind": "port",
+            "value_one_core": c_one / t_one,
             "sample": f"first {nrows} rows of the same half list ({c_main} contact pairs, {t_main:.1f} s, "
-                      f"OpenMP x{nthreads}); own CPU restatement of docs/SPEC.md, not the reference's PairSH "
-                      "(absent from the mount)"}
+                      f"OpenMP x{nthreads}; one core: first {rows1} rows, {t_one:.1f} s); own CPU restatement of "
+                      "docs/SPEC.md, not the reference's PairSH (absent from the mount)"}
 
 
 if __name__ == "__main__":
