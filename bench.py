@@ -287,6 +287,8 @@ def main():
                         "traffic: bytes/launch from profiles/pmc_traffic.json (rocprofv3 FETCH_SIZE + WRITE_SIZE "
                         "passes of this workload; uncalibrated access widths, see the file)",
             },
+            "occupancy": dict(sp.kernel_info(), note="static footprint of pair_contact_kernel as launched: one wave = one pair "
+                              "= one workgroup; waves_per_cu = min(4 x VGPR limit, LDS limit) of a gfx950 CU"),
             "valu_f64": {
                 "bound": "valu_f64", "achieved": achieved_tf, "peak": F64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved_tf / F64_VALU_PEAK_TFLOPS, "flop_per_pair": fpp,

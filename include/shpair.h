@@ -140,6 +140,19 @@ int shpair_compute_device(shpair_ctx *ctx, int nlocal, int nghost, const double 
  * override the number of quadrature rings whose tables are LDS resident at a time; tuning). */
 int shpair_set_option(shpair_ctx *ctx, const char *key, int value);
 
+/* Static footprint of the pair kernel the last compute launched (occupancy evidence): registers per lane, LDS
+ * per wave (one wave = one pair = one workgroup), and the resident waves those allow on a gfx950 CU (4 SIMDs,
+ * 512 VGPRs per lane and SIMD, 160 KiB LDS). */
+typedef struct shpair_kernel_info {
+  int lmax, compiled_order;   /* compiled_order 0: the run-time-order loop kernel */
+  int vgprs, scratch_bytes;
+  int lds_bytes_per_wave, ring_rows;
+  int waves_per_simd_vgpr;    /* limit from registers */
+  int waves_per_cu_lds;       /* limit from LDS */
+  int waves_per_cu;           /* min(4 x waves_per_simd_vgpr, waves_per_cu_lds) */
+} shpair_kernel_info;
+int shpair_get_kernel_info(shpair_ctx *ctx, shpair_kernel_info *out);
+
 /* Blocks until the last compute finished, then fills `out`. */
 int shpair_get_stats(shpair_ctx *ctx, shpair_stats *out);
 

@@ -922,6 +922,19 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, WEIGHTED ? SHP_WMIN_WA
 
 // Host-callable launcher, one per compiled order (pair_kernels_L*.hip).
 typedef void (*pair_launch_fn)(const PairParams&, bool needv, hipStream_t);
+// Register / LDS footprint of the kernel that launch would pick (occupancy evidence for bench.py).
+typedef hipError_t (*pair_attr_fn)(bool needv, bool weighted, hipFuncAttributes*);
+
+template <int L>
+hipError_t pair_contact_attributes(bool needv, bool weighted, hipFuncAttributes* a)
+{
+  if (weighted) {
+    if constexpr (L >= 0) return hipFuncGetAttributes(a, (const void*)pair_contact_kernel<L, true, true>);
+    return hipErrorInvalidValue;
+  }
+  return needv ? hipFuncGetAttributes(a, (const void*)pair_contact_kernel<L, true>)
+               : hipFuncGetAttributes(a, (const void*)pair_contact_kernel<L, false>);
+}
 
 template <int L>
 void launch_pair_contact(const PairParams& P, bool needv, hipStream_t st)

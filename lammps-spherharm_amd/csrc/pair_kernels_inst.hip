@@ -11,10 +11,13 @@
 #define SHP_CAT(a, b) SHP_CAT2(a, b)
 #if SHP_L < 0
 #define SHP_FN shp_launch_Lrt
+#define SHP_AFN shp_attr_Lrt
 #else
 #define SHP_FN SHP_CAT(shp_launch_L, SHP_L)
+#define SHP_AFN SHP_CAT(shp_attr_L, SHP_L)
 #endif
 
 namespace shp {
 void SHP_FN(const PairParams& P, bool needv, hipStream_t st) { launch_pair_contact<SHP_L>(P, needv, st); }
+hipError_t SHP_AFN(bool needv, bool weighted, hipFuncAttributes* a) { return pair_contact_attributes<SHP_L>(needv, weighted, a); }
 }  // namespace shp

@@ -20,16 +20,21 @@
 #include "sh_tables.hpp"
 
 namespace shp {
-#define SHP_DECL(L) void shp_launch_L##L(const PairParams&, bool, hipStream_t);
+#define SHP_DECL(L) void shp_launch_L##L(const PairParams&, bool, hipStream_t); \
+  hipError_t shp_attr_L##L(bool, bool, hipFuncAttributes*);
 SHP_DECL(0) SHP_DECL(1) SHP_DECL(2) SHP_DECL(3) SHP_DECL(4) SHP_DECL(5) SHP_DECL(6)
 SHP_DECL(7) SHP_DECL(8) SHP_DECL(9) SHP_DECL(10) SHP_DECL(11) SHP_DECL(12)
 #undef SHP_DECL
 void shp_launch_Lrt(const PairParams&, bool, hipStream_t);
+hipError_t shp_attr_Lrt(bool, bool, hipFuncAttributes*);
 
 constexpr int kMaxUnrolledL = 12;
 static const pair_launch_fn kLaunch[kMaxUnrolledL + 1] = {
     shp_launch_L0, shp_launch_L1, shp_launch_L2, shp_launch_L3, shp_launch_L4, shp_launch_L5, shp_launch_L6,
     shp_launch_L7, shp_launch_L8, shp_launch_L9, shp_launch_L10, shp_launch_L11, shp_launch_L12};
+static const pair_attr_fn kAttr[kMaxUnrolledL + 1] = {
+    shp_attr_L0, shp_attr_L1, shp_attr_L2, shp_attr_L3, shp_attr_L4, shp_attr_L5, shp_attr_L6,
+    shp_attr_L7, shp_attr_L8, shp_attr_L9, shp_attr_L10, shp_attr_L11, shp_attr_L12};
 
 // Sums the per-slot flags the pair kernel wrote: out[0] = contact pairs
 // (flag >= 1), out[1] = touching pairs (flag == 2). One atomic per wave.
@@ -516,6 +521,8 @@ int shpair_compute_device(shpair_ctx* c, int nlocal, int nghost, const double* x
     P.wave_lds_bytes = wl.bytes;
     P.waves_per_block = wpb;
     P.ring_rows = rows;
+    c->last_lds_bytes = wl.bytes;
+    c->last_ring_rows = rows;
   }
   P.ev = ev; P.pair_out = c->pair_out;
   P.flags = nullptr;
@@ -528,6 +535,7 @@ int shpair_compute_device(shpair_ctx* c, int nlocal, int nghost, const double* x
     P.flags = c->d_flags.p;
   }
   const bool needv = c->opt_force_volume || eflag || c->any_nonunit_exponent || c->eatom_dev != nullptr;
+  c->last_needv = needv;
   if (c->opt_timing) HIPCHK(c, hipEventRecord(c->ev0, st));
   if (c->lmax <= kMaxUnrolledL && c->opt_variant != 1) {
     P.coef = c->d_coefm.p;  // compiled orders read the monomial (Horner) table
@@ -635,6 +643,32 @@ int shpair_compute(shpair_ctx* c, int nlocal, int nghost, const double* x, const
     for (size_t k = 0; k < nall; ++k) c->eatom_host[k] += h_pa[k];
   if (pv)
     for (size_t k = 0; k < 6 * nall; ++k) c->vatom_host[k] += h_pa[nall + k];
+  return SHPAIR_OK;
+}
+
+int shpair_get_kernel_info(shpair_ctx* c, shpair_kernel_info* out)
+{
+  if (!c || !out) return SHPAIR_EINVAL;
+  if (c->lmax < 0 || c->last_lds_bytes <= 0) CTX_FAIL(c, SHPAIR_ESTATE, "kernel info: no compute has run yet");
+  HIPCHK(c, hipSetDevice(c->device));
+  hipFuncAttributes a;
+  const bool compiled = c->lmax <= kMaxUnrolledL && c->opt_variant != 1;
+  HIPCHK(c, compiled ? kAttr[c->lmax](c->last_needv, c->opt_rule != 0, &a) : shp_attr_Lrt(c->last_needv, false, &a));
+  out->lmax = c->lmax;
+  out->compiled_order = compiled ? 1 : 0;
+  out->vgprs = a.numRegs;
+  out->scratch_bytes = (int)a.localSizeBytes;
+  out->lds_bytes_per_wave = c->last_lds_bytes;
+  out->ring_rows = c->last_ring_rows;
+  // gfx950: 512 VGPRs per SIMD lane in blocks of 8, at most 8 waves per SIMD, 160 KiB LDS per CU of 4 SIMDs
+  const int vg = ((a.numRegs + 7) / 8) * 8;
+  int w = vg > 0 ? 512 / vg : 8;
+  if (w > 8) w = 8;
+  const int by_lds = (160 * 1024) / c->last_lds_bytes;  // one wave per workgroup: workgroups per CU
+  out->waves_per_simd_vgpr = w;
+  out->waves_per_cu_lds = by_lds;
+  const int cu = (4 * w < by_lds) ? 4 * w : by_lds;
+  out->waves_per_cu = cu;
   return SHPAIR_OK;
 }
 

@@ -77,6 +77,8 @@ struct shpair_ctx {
   unsigned long long* h_counters = nullptr;  // pinned 2
 
   int opt_force_volume = 0, opt_timing = 0, opt_count = 0, opt_variant = 0, opt_ring_rows = 0, opt_wpb = 0, opt_rule = 0;
+  int last_lds_bytes = 0, last_ring_rows = 0;  // of the last launch (shpair_get_kernel_info)
+  bool last_needv = false;
   double* pair_out = nullptr;
   double *eatom_dev = nullptr, *vatom_dev = nullptr;    // shpair_set_peratom_output
   double *eatom_host = nullptr, *vatom_host = nullptr;  // shpair_set_peratom_host

@@ -28,6 +28,11 @@ class Stats(C.Structure):
                 ("kernel_ms", C.c_double), ("total_ms", C.c_double)]
 
 
+class KernelInfo(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("lmax", "compiled_order", "vgprs", "scratch_bytes", "lds_bytes_per_wave", "ring_rows",
+                                       "waves_per_simd_vgpr", "waves_per_cu_lds", "waves_per_cu")]
+
+
 class StepArrays(C.Structure):
     """shstep_arrays of include/shstep.h."""
     _fields_ = [("nlocal", C.c_int), ("nmax", C.c_int),
@@ -62,6 +67,7 @@ SYMBOLS = {
                                         C.c_void_p, C.c_void_p]),
     "shpair_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
     "shpair_get_stats": (C.c_int, [C.c_void_p, C.POINTER(Stats)]),
+    "shpair_get_kernel_info": (C.c_int, [C.c_void_p, C.POINTER(KernelInfo)]),
     "shpair_set_pair_output": (C.c_int, [C.c_void_p, C.c_void_p]),
     "shpair_set_peratom_output": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "shpair_set_peratom_host": (C.c_int, [C.c_void_p, _dp, _dp]),
@@ -292,6 +298,12 @@ class ShPair:
         self._chk(self._lib.shpair_get_stats(self._h, C.byref(s)))
         return dict(n_candidates=s.n_candidates, n_contact=s.n_contact, n_touching=s.n_touching,
                     kernel_ms=s.kernel_ms, total_ms=s.total_ms)
+
+    def kernel_info(self):
+        """Registers, LDS and resident waves of the pair kernel the last compute launched."""
+        k = KernelInfo()
+        self._chk(self._lib.shpair_get_kernel_info(self._h, C.byref(k)))
+        return {n: getattr(k, n) for n, _ in KernelInfo._fields_}
 
     def own_stream(self):
         """The context's own hipStream_t as an int (None-safe for compute_device(stream=...))."""

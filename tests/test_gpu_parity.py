@@ -679,3 +679,23 @@ def test_peratom_energy_and_virial(oracle, newton):
     assert np.abs(vd.cpu().numpy() - 2 * o["vatom"]).max() < TOL * vs
     sp.set_peratom_output(None, None)
     sp.close()
+
+
+def test_kernel_info_reports_the_launched_footprint(oracle):
+    case = make_case(60, 6, 1, seed=46, rmax_fn=oracle.shape_rmax)
+    K, E = coeff_tables(1, 900.0, 1.25)
+    sp = make_ctx(case, 16, K, E)
+    from shpair.capi import ShPairError
+    with pytest.raises(ShPairError):
+        sp.kernel_info()                         # nothing launched yet
+    b = case["bed"]
+    sp.compute(60, b["x"], b["quat"], b["type"], b["shtype"])
+    k = sp.kernel_info()
+    assert k["lmax"] == 6 and k["compiled_order"] == 1 and 64 <= k["vgprs"] <= 96 and k["scratch_bytes"] == 0
+    assert 4096 < k["lds_bytes_per_wave"] <= 8192 and k["ring_rows"] == 16
+    assert k["waves_per_simd_vgpr"] == 5 and k["waves_per_cu"] == 20
+    sp.set_option("rule", 1)
+    sp.compute(60, b["x"], b["quat"], b["type"], b["shtype"])
+    kw = sp.kernel_info()
+    assert kw["lds_bytes_per_wave"] > k["lds_bytes_per_wave"] and kw["waves_per_cu"] in (18, 19)
+    sp.close()
