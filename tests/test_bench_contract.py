@@ -27,7 +27,7 @@ def test_single_gpu_line_has_the_contract_fields():
     assert r.returncode == 0, r.stderr[-2000:]
     d = _last_json(r.stdout)
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
-              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "timestep"):
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "timestep", "occupancy"):
         assert k in d, k
     assert d["n_gpus"] == 1 and d["steps"] == 5 and d["warmup"] == 1 and d["dtype"] == "f64" and d["vs_baseline"] is None
     assert d["unit"] == "contact-pairs/s" and d["value"] > 1e7 and d["higher_is_better"] is True
@@ -37,6 +37,7 @@ def test_single_gpu_line_has_the_contract_fields():
     assert abs(d["value"] * d["ms_per_step"] * 1e-3 - d["config"]["contact_pairs_all_ranks"]) < 1e-6 * d["config"]["contact_pairs_all_ranks"]
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["unit"] == d["unit"]
+    assert d["occupancy"]["waves_per_cu"] >= 16 and d["occupancy"]["scratch_bytes"] == 0
     ts = d["timestep"]
     assert ts["timesteps_per_s"] > 0 and ts["steps"] == 10 and ts["particles"] > 15000
 
