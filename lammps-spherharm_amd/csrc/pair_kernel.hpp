@@ -421,13 +421,15 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, WEIGHTED ? SHP_WMIN_WA
     if (rho >= Ri + Rj) return;  // SPEC §2.1, wave-uniform
     centre_in_bj = rho < Rj;
 
-    // SPEC §2.2 cap
+    // SPEC §2.2 cap.  The branch conditions are exact; the value only places the nodes, so Newton-refined
+    // reciprocals / roots (1-2 ulp) do instead of the IEEE sequences (both branches are evaluated: ~40 instructions)
+    const double irho = rcp_nr(rho);
+    const double pj = rho2 - Rj * Rj;
     if (rho <= Rj) cosa = -1.0;
-    else if (rho2 - Rj * Rj <= Ri * Ri) cosa = sqrt(rho2 - Rj * Rj) / rho;
-    else cosa = (rho2 + Ri * Ri - Rj * Rj) / (2.0 * rho * Ri);
+    else if (pj <= Ri * Ri) cosa = sqrt_nr(fmax(pj, 0.0)) * irho;
+    else cosa = (pj + Ri * Ri) * (0.5 * irho * rcp_nr(Ri));
 
     // SPEC §2.3 frame (space)
-    const double irho = rcp_nr(rho);
     const double c0 = d0 * irho, c1 = d1 * irho, c2 = d2 * irho;
     const double sg = copysign(1.0, c2);
     const double aa = -rcp_nr(sg + c2);
