@@ -599,7 +599,12 @@ int shpair_compute(shpair_ctx* c, int nlocal, int nghost, const double* x, const
   }
   hipStream_t st = c->stream;
   // per-atom tallies of the host form: staged like the forces (shpair_set_peratom_host)
-  double *const keep_e = c->eatom_dev, *const keep_v = c->vatom_dev;
+  // the staged arrays stand in for the device-form pointers for the duration of this call, whatever way it ends
+  struct Restore {
+    shpair_ctx* c;
+    double *e, *v;
+    ~Restore() { c->eatom_dev = e; c->vatom_dev = v; }
+  } restore{c, c->eatom_dev, c->vatom_dev};
   const bool pe = c->eatom_host != nullptr, pv = c->vatom_host != nullptr;
   std::vector<double> h_pa;
   if (pe || pv) {
@@ -621,8 +626,6 @@ int shpair_compute(shpair_ctx* c, int nlocal, int nghost, const double* x, const
   HIPCHK(c, hipMemsetAsync(c->d_ev.p, 0, 7 * sizeof(double), st));
   const int rc = shpair_compute_device(c, nlocal, nghost, c->d_x.p, c->d_quat.p, c->d_type.p, c->d_shtype.p,
                                        newton_pair, eflag, vflag, c->d_f.p, c->d_torque.p, c->d_ev.p, st);
-  c->eatom_dev = keep_e;
-  c->vatom_dev = keep_v;
   if (rc) return rc;
   if (pe) HIPCHK(c, hipMemcpyAsync(h_pa.data(), c->d_eatom.p, nall * sizeof(double), hipMemcpyDeviceToHost, st));
   if (pv) HIPCHK(c, hipMemcpyAsync(h_pa.data() + nall, c->d_vatom.p, 6 * nall * sizeof(double), hipMemcpyDeviceToHost, st));
