@@ -71,6 +71,9 @@ def parse():
     ap.add_argument("--rule", default="sharp", choices=["sharp", "weighted"],
                     help="cap rule: sharp inside test (docs/SPEC.md §2.5, the headline) or covered-fraction weights (§2.8)")
     ap.add_argument("--ts-steps", type=int, default=40, help="steps of the whole-timestep leg (N = 1 only; 0 = skip)")
+    ap.add_argument("--multi-ts-steps", type=int, default=0,
+                    help="N > 1 only, off by default: whole timesteps with atom migration and rebuilds through "
+                         "shpair.mrun.MultiRankRun on a periodic bed of `particles` per rank (weak scaling)")
     ap.add_argument("--cpu-threads", type=int, default=16, help="OpenMP threads of the cpu_baseline leg "
                     "(16 = the host-core share of one GPU on the bench box)")
     return ap.parse_args()
@@ -247,6 +250,9 @@ def main():
             verify_err = float(max(np.abs(fg - fr_).max(), np.abs(tg - tr_).max()) / sc)
             assert verify_err < 1e-9, f"decomposed forces differ from single-domain forces: {verify_err}"
 
+    mts = None
+    if world > 1 and args.multi_ts_steps > 0:
+        mts = multi_rank_timestep_leg(args, shp, local_rank, dist, rank, world, grid, rehearsal)
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
         value = contact_all * args.steps / elapsed
@@ -297,6 +303,8 @@ def main():
         }
         if world == 1 and args.ts_steps > 0:
             out["timestep"] = timestep_leg(args, shp, local_rank)
+        if mts is not None:
+            out["timestep_multi_rank"] = mts
         if world == 1 and args.cpu_seconds > 0:
             out["cpu_baseline"] = cpu_baseline(args, shp, rmax, gbed, il, of, jl)
         print(json.dumps(out), flush=True)
@@ -356,6 +364,54 @@ def timestep_leg(args, shp, device):
            "periodic": [1, 1, 1], "energy": {"contact": pe, "ke_trans": kt, "ke_rot": kr},
            "what": "initial_integrate + rebuild test + forward + clear + pair compute + reverse + final_integrate, "
                    "all arrays resident in HBM (shpair.run.DeviceRun over include/shpair.h + include/shstep.h)"}
+    sp.close()
+    return out
+
+
+def multi_rank_timestep_leg(args, shp, device, dist, rank, world, grid, rehearsal):
+    """Whole timesteps on N ranks with everything LAMMPS does around the pair style when atoms move: migration,
+    ghosts, list rebuilds (shpair.mrun.MultiRankRun).  Periodic bed of `particles` per rank; every rank calls this."""
+    import torch
+    from shpair import ShPair, bed
+    from shpair.mrun import MultiRankRun
+    sp = ShPair(device)
+    sp.settings(args.nq)
+    sp.set_ntypes(1, args.nshapes)
+    for s, a in enumerate(shp):
+        sp.set_shape(s, args.lmax, a)
+    sp.coeff("*", "*", 1000.0, args.exponent)
+    sp.set_option("rule", 1 if args.rule == "weighted" else 0)
+    pts, lo, hi = bed.periodic_hcp(args.particles * world, 1.9, (1, 1, 1))
+    rng = np.random.default_rng(bed.SEED0 + 7)
+    n = pts.shape[0]
+    pts = pts + rng.uniform(-0.04, 0.04, pts.shape)
+    quat = bed.random_quaternions(n, rng)
+    shtype = rng.integers(0, args.nshapes, n).astype(np.int32) if args.nshapes > 1 else np.zeros(n, np.int32)
+    blen = (hi - lo) / np.array(grid)
+    c = np.minimum(((np.mod(pts - lo, hi - lo)) / blen).astype(int), np.array(grid) - 1)
+    mine = ((c[:, 0] * grid[1] + c[:, 1]) * grid[2] + c[:, 2]) == rank
+    run = MultiRankRun(sp, dist, rank, world, grid, lo, hi, (1, 1, 1), 0.1, pts[mine], quat[mine], shtype[mine],
+                       np.arange(n, dtype=np.int32)[mine], dt=1.0e-3, device=f"cuda:{device}", staged=rehearsal)
+    run.run(5)
+    b0 = run.builds
+    torch.cuda.synchronize()
+    dist.barrier()
+    t0 = time.perf_counter()
+    run.run(args.multi_ts_steps)
+    torch.cuda.synchronize()
+    dist.barrier()
+    el = time.perf_counter() - t0
+    tot = torch.tensor([el, float(run.n), float(run.nghost), float(run.migrated)], dtype=torch.float64,
+                       device="cpu" if rehearsal else f"cuda:{device}")
+    mx = tot.clone()
+    dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+    sm = tot.clone()
+    dist.all_reduce(sm, op=dist.ReduceOp.SUM)
+    out = {"timesteps_per_s": args.multi_ts_steps / float(mx[0]), "ms_per_step": 1e3 * float(mx[0]) / args.multi_ts_steps,
+           "steps": args.multi_ts_steps, "particles_all_ranks": int(sm[1]), "ghosts_all_ranks": int(sm[2]),
+           "migrated_atoms": int(sm[3]), "rebuilds": run.builds - b0, "proc_grid": list(grid), "dt": 1.0e-3, "skin": 0.1,
+           "what": "initial_integrate + rebuild test (all-reduce) + [migration, ghosts, list build] + forward + pair compute "
+                   "+ reverse + final_integrate on every rank (shpair.mrun.MultiRankRun)"}
     sp.close()
     return out
 

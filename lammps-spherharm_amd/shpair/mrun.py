@@ -227,6 +227,25 @@ class MultiRankRun:
         self.nghost = off - n
         self.plan = plan
         self._send_order, self._recv_order, self._by_code = sends, recvs, by_code
+        # fused gather / scatter lists: one index_select (+ one row-wise shift) and one index_add per array and step,
+        # whatever the number of directions; the messages are slices of the gathered buffer
+        z = torch.zeros(0, dtype=torch.int64, device=self.dev)
+        self._send_all = torch.cat([plan[k]["send_idx"] for k in sends]) if sends else z
+        self._send_shift = (torch.cat([plan[k]["shift"].expand(plan[k]["send_idx"].numel(), 3) for k in sends])
+                            if sends else torch.zeros(0, 3, dtype=torch.float64, device=self.dev))
+        self._send_slices, o = {}, 0
+        for k in sends:
+            m = plan[k]["send_idx"].numel()
+            self._send_slices[k] = (o, o + m)
+            o += m
+        selfs = [k for k, p in enumerate(plan) if p["peer"] == self.rank]
+        self._self_src = torch.cat([plan[k]["send_idx"] for k in selfs]) if selfs else z
+        self._self_dst = (torch.cat([torch.arange(*plan[by_code[26 - plan[k]["code"]]]["recv"], device=self.dev) for k in selfs])
+                          if selfs else z)
+        self._self_shift = (torch.cat([plan[k]["shift"].expand(plan[k]["send_idx"].numel(), 3) for k in selfs])
+                            if selfs else torch.zeros(0, 3, dtype=torch.float64, device=self.dev))
+        self._rf = torch.empty(self._send_all.numel(), 3, dtype=torch.float64, device=self.dev)
+        self._rt = torch.empty_like(self._rf)
         # static per-ghost data, then positions
         self._exchange_rows([self.tag, self.sh, self.ty], shift=False)
         self.forward()
@@ -235,21 +254,23 @@ class MultiRankRun:
         self.builds += 1
 
     def _exchange_rows(self, arrays, shift):
-        """owners' rows of `arrays` -> the ghost rows, all directions in one batched group per array set."""
+        """owners' rows of `arrays` -> the ghost rows: one gather per array, one batched group for all directions."""
         plan = self.plan
-        bufs = {}
-        for k in self._send_order:
-            p = plan[k]
-            bufs[k] = [a[p["send_idx"]] + (p["shift"] if (shift and a is self.x) else 0) if a is self.x else a[p["send_idx"]]
-                       for a in arrays]
-        sends = [(plan[k]["peer"], b) for k in self._send_order for b in bufs[k]]
+        bufs = []
+        for a in arrays:
+            g = a.index_select(0, self._send_all)
+            if shift and a is self.x:
+                g += self._send_shift
+            bufs.append(g)
+        sends = [(plan[k]["peer"], b[self._send_slices[k][0]:self._send_slices[k][1]]) for k in self._send_order for b in bufs]
         recvs = [(plan[k]["peer"], a[plan[k]["recv"][0]:plan[k]["recv"][1]]) for k in self._recv_order for a in arrays]
         self._p2p(sends, recvs)
-        for k, p in enumerate(plan):
-            if p["peer"] == self.rank:
-                a0, a1 = plan[self._by_code[26 - p["code"]]]["recv"]
-                for a in arrays:
-                    a[a0:a1] = (a[p["send_idx"]] + p["shift"]) if (shift and a is self.x) else a[p["send_idx"]]
+        if self._self_src.numel():                      # own periodic images
+            for a in arrays:
+                g = a.index_select(0, self._self_src)
+                if shift and a is self.x:
+                    g += self._self_shift
+                a[self._self_dst] = g
 
     # ---- per step ------------------------------------------------------------------------------------------
     def forward(self):
@@ -257,21 +278,18 @@ class MultiRankRun:
 
     def reverse(self):
         plan = self.plan
-        # ghost rows travel back: what was received in direction c goes to that peer, which adds it to its send list
+        # ghost rows travel back: what came in through a direction returns to that peer, which adds it to the rows it
+        # sent.  The peer sends in ITS receive order (peer, 26 - code ascending) = our send order seen from there.
         sends = [(plan[k]["peer"], a[plan[k]["recv"][0]:plan[k]["recv"][1]]) for k in self._recv_order for a in (self.f, self.tq)]
-        bufs = {k: [torch.empty(plan[k]["send_idx"].numel(), 3, dtype=torch.float64, device=self.dev) for _ in range(2)]
-                for k in self._send_order}
-        recvs = [(plan[k]["peer"], b) for k in self._send_order for b in bufs[k]]
-        # order: the peer sends in ITS recv order (peer, 26 - code ascending) = our send order seen from there
+        recvs = [(plan[k]["peer"], b[self._send_slices[k][0]:self._send_slices[k][1]]) for k in self._send_order
+                 for b in (self._rf, self._rt)]
         self._p2p(sends, recvs)
-        for k in self._send_order:
-            self.f.index_add_(0, plan[k]["send_idx"], bufs[k][0])
-            self.tq.index_add_(0, plan[k]["send_idx"], bufs[k][1])
-        for k, p in enumerate(plan):
-            if p["peer"] == self.rank:
-                a0, a1 = plan[self._by_code[26 - p["code"]]]["recv"]
-                self.f.index_add_(0, p["send_idx"], self.f[a0:a1].clone())
-                self.tq.index_add_(0, p["send_idx"], self.tq[a0:a1].clone())
+        if self._send_all.numel():
+            self.f.index_add_(0, self._send_all, self._rf)
+            self.tq.index_add_(0, self._send_all, self._rt)
+        if self._self_src.numel():
+            self.f.index_add_(0, self._self_src, self.f.index_select(0, self._self_dst))
+            self.tq.index_add_(0, self._self_src, self.tq.index_select(0, self._self_dst))
 
     def force(self, eflag=False):
         sp, n = self.sp, self.n
