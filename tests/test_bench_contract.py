@@ -46,13 +46,16 @@ def test_two_rank_rehearsal_reproduces_single_domain_forces():
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
                         "127.0.0.1", "--master-port", "29541", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo",
-                        "--verify", "--particles", "8000", "--steps", "3", "--warmup", "1", "--ramp", "0", "--cpu-seconds", "0"],
+                        "--verify", "--particles", "8000", "--steps", "3", "--warmup", "1", "--ramp", "0", "--cpu-seconds", "0",
+                        "--multi-ts-steps", "6"],
                        capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
     assert r.returncode == 0, r.stderr[-3000:]
     d = _last_json(r.stdout)
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["backend"] == "gloo-rehearsal"
     assert d["verify_rel_err"] is not None and d["verify_rel_err"] < 1e-12
     assert d["config"]["ghost_atoms_rank0"] > 0 and d["config"]["contact_pairs_all_ranks"] > d["config"]["contact_pairs_rank0"]
+    m = d["timestep_multi_rank"]                   # the optional leg with migration and rebuilds (shpair.mrun)
+    assert m["steps"] == 6 and m["timesteps_per_s"] > 0 and m["particles_all_ranks"] > 15000 and m["ghosts_all_ranks"] > 0
 
 
 def test_halo_exchange_over_real_rccl_with_the_rank_as_its_own_peer():
