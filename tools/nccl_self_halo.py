@@ -37,6 +37,26 @@ fe, te = f0[:nlocal].clone(), t0[:nlocal].clone()
 fe.index_add_(0, torch.from_numpy(send).to(dev), f0[nlocal:])
 te.index_add_(0, torch.from_numpy(send).to(dev), t0[nlocal:])
 assert torch.allclose(f[:nlocal], fe, atol=1e-14) and torch.allclose(t[:nlocal], te, atol=1e-14)
+# the primitives of shpair/mrun.py (MultiRankRun) on RCCL: counts and variable-size rows by all_to_all_single,
+# one-element int64 messages and row slices of int32 / float64 arrays in one batched point-to-point group
+cnt = torch.tensor([37], dtype=torch.int64, device=dev)
+got = torch.zeros_like(cnt)
+dist.all_to_all_single(got, cnt)
+assert got.item() == 37
+rows = torch.randn(37, 16, dtype=torch.float64, device=dev)
+back = torch.empty(37, 16, dtype=torch.float64, device=dev)
+dist.all_to_all_single(back, rows, output_split_sizes=[37], input_split_sizes=[37])
+assert torch.equal(back, rows)
+ns = torch.tensor([5, 9], dtype=torch.int64, device=dev)
+nr = torch.zeros_like(ns)
+ti = torch.arange(40, dtype=torch.int32, device=dev)
+ri = torch.zeros(40, dtype=torch.int32, device=dev)
+ops = [dist.P2POp(dist.irecv, nr[0:1], 0), dist.P2POp(dist.irecv, nr[1:2], 0), dist.P2POp(dist.irecv, ri[10:25], 0),
+       dist.P2POp(dist.isend, ns[0:1], 0), dist.P2POp(dist.isend, ns[1:2], 0), dist.P2POp(dist.isend, ti[3:18].contiguous(), 0)]
+for w in dist.batch_isend_irecv(ops):
+    w.wait()
+torch.cuda.synchronize()
+assert nr.tolist() == [5, 9] and torch.equal(ri[10:25], ti[3:18])
 tot = torch.tensor([1.0, 2.0], dtype=torch.float64, device=dev)
 dist.all_reduce(tot, op=dist.ReduceOp.MAX)
 dist.barrier()
