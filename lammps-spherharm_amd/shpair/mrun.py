@@ -24,7 +24,7 @@ host (`staged=True`).  torch only owns memory and moves bytes; all arithmetic is
 import numpy as np
 import torch
 
-_PACK = 3 + 4 + 3 + 3 + 3  # x, quat, v, angmom, (tag, shtype, type) as doubles
+_PACK = 3 + 4 + 3 + 3 + 4  # x, quat, v, angmom, (tag, shtype, type, mask) as doubles
 
 
 def _dir_code(dx, dy, dz):
@@ -33,7 +33,7 @@ def _dir_code(dx, dy, dz):
 
 class MultiRankRun:
     def __init__(self, sp, dist, rank, world, grid, lo, hi, periodic, skin, x, quat, shtype, tag, type_=None, v=None,
-                 angmom=None, dt=1e-3, gravity=(0.0, 0.0, 0.0), gamma_t=0.0, gamma_r=0.0, device="cuda:0", staged=False,
+                 angmom=None, mask=None, groupbit=1, dt=1e-3, gravity=(0.0, 0.0, 0.0), gamma_t=0.0, gamma_r=0.0, device="cuda:0", staged=False,
                  capacity_factor=3.0):
         self.sp, self.dist, self.rank, self.world, self.staged = sp, dist, rank, world, staged
         self.grid = tuple(int(g) for g in grid)
@@ -80,7 +80,8 @@ class MultiRankRun:
             if src is not None and n:
                 dst[:n] = torch.from_numpy(np.ascontiguousarray(src, dtype=dt_)).to(self.dev)
         put(self.x, x, np.float64); put(self.q, quat, np.float64); put(self.v, v, np.float64); put(self.L, angmom, np.float64)
-        put(self.tag, tag, np.int32); put(self.sh, shtype, np.int32); put(self.ty, type_, np.int32)
+        put(self.tag, tag, np.int32); put(self.sh, shtype, np.int32); put(self.ty, type_, np.int32); put(self.mask, mask, np.int32)
+        self.groupbit = int(groupbit)
         self.n = n
         self.nghost = 0
         self.builds = 0
@@ -154,12 +155,12 @@ class MultiRankRun:
             send_counts = torch.bincount(own[order], minlength=self.world).cpu().tolist() if order.numel() else [0] * self.world
             recv_counts = self._all_to_all_counts(send_counts)
             rows = torch.cat([self.x[order], self.q[order], self.v[order], self.L[order],
-                              torch.stack([self.tag[order], self.sh[order], self.ty[order]], 1).to(torch.float64)], 1) \
+                              torch.stack([self.tag[order], self.sh[order], self.ty[order], self.mask[order]], 1).to(torch.float64)], 1) \
                 if order.numel() else torch.zeros(0, _PACK, dtype=torch.float64, device=self.dev)
             got = self._all_to_all_rows(rows, send_counts, recv_counts)
             keep = torch.nonzero(stay).flatten()
             nk = keep.numel()
-            for a in (self.x, self.q, self.v, self.L, self.tag, self.sh, self.ty):
+            for a in (self.x, self.q, self.v, self.L, self.tag, self.sh, self.ty, self.mask):
                 a[:nk] = a[keep]
             ng = got.shape[0]
             if nk + ng > self.nmax:
@@ -169,10 +170,11 @@ class MultiRankRun:
                 self.q[nk:nk + ng] = got[:, 3:7]
                 self.v[nk:nk + ng] = got[:, 7:10]
                 self.L[nk:nk + ng] = got[:, 10:13]
-                meta = got[:, 13:16].round().to(torch.int32)
+                meta = got[:, 13:17].round().to(torch.int32)
                 self.tag[nk:nk + ng] = meta[:, 0]
                 self.sh[nk:nk + ng] = meta[:, 1]
                 self.ty[nk:nk + ng] = meta[:, 2]
+                self.mask[nk:nk + ng] = meta[:, 3]
             self.migrated += int(order.numel())
             n = self.n = nk + ng
         # 2. ghosts, direction by direction
@@ -303,12 +305,14 @@ class MultiRankRun:
         self.reverse()
         if self.body and n:
             sp.post_force_device(n, self.g, self.gamma_t, self.gamma_r, self.v.data_ptr(), self.q.data_ptr(), self.L.data_ptr(),
-                                 self.sh.data_ptr(), self.mask.data_ptr(), self.f.data_ptr(), self.tq.data_ptr())
+                                 self.sh.data_ptr(), self.mask.data_ptr(), self.f.data_ptr(), self.tq.data_ptr(),
+                                 groupbit=self.groupbit)
 
     def _nve(self, phase):
         if self.n:
             self.sp.nve_device(phase, self.n, self.dt, self.x.data_ptr(), self.v.data_ptr(), self.q.data_ptr(), self.L.data_ptr(),
-                               self.f.data_ptr(), self.tq.data_ptr(), self.sh.data_ptr(), self.mask.data_ptr())
+                               self.f.data_ptr(), self.tq.data_ptr(), self.sh.data_ptr(), self.mask.data_ptr(),
+                               groupbit=self.groupbit)
 
     def step(self, eflag=False):
         self._nve(0)

@@ -44,6 +44,8 @@ def main():
     sht = rng.integers(0, 2, n).astype(np.int32)
     v0 = 2.0 * rng.normal(size=(n, 3))           # fast enough that atoms cross brick boundaries within the run
     tag = np.arange(n, dtype=np.int32)
+    mask = np.where(tag % 11 == 0, 2, 1).astype(np.int32)      # every 11th particle is frozen (another group)
+    v0[mask == 2] = 0.0
     # this rank's atoms (after a periodic wrap, as rebuild() would do)
     xw = x.copy()
     for d in range(3):
@@ -55,7 +57,7 @@ def main():
     mine = owner == rank
     sp = ctx(lmax, shp, nq, rule)
     run = MultiRankRun(sp, dist, rank, world, grid, lo, hi, periodic, skin, x[mine], quat[mine], sht[mine], tag[mine], v=v0[mine],
-                       dt=dt, gravity=(0.0, 0.0, -0.5 if not periodic[2] else 0.0), gamma_t=0.05, gamma_r=0.02, staged=True)
+                       mask=mask[mine], dt=dt, gravity=(0.0, 0.0, -0.5 if not periodic[2] else 0.0), gamma_t=0.05, gamma_r=0.02, staged=True)
     n0 = run.n
     run.run(nsteps)
     torch.cuda.synchronize()
@@ -67,7 +69,7 @@ def main():
         X = np.concatenate([p[1] for p in parts])[o]; V = np.concatenate([p[2] for p in parts])[o]; Q = np.concatenate([p[3] for p in parts])[o]
         assert np.array_equal(tg[o], np.arange(n)), "atoms lost or duplicated"
         sp1 = ctx(lmax, shp, nq, rule)
-        ref = DeviceRun(sp1, x, quat, sht, lo, hi, periodic, skin, dt=dt, gravity=(0.0, 0.0, -0.5 if not periodic[2] else 0.0),
+        ref = DeviceRun(sp1, x, quat, sht, lo, hi, periodic, skin, mask=mask, dt=dt, gravity=(0.0, 0.0, -0.5 if not periodic[2] else 0.0),
                         gamma_t=0.05, gamma_r=0.02)
         ref.v[:] = torch.from_numpy(v0).to(ref.v.device)
         ref.force()                                  # the damping term of the initial forces needs the velocities
