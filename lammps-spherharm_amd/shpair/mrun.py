@@ -13,9 +13,9 @@ At a rebuild (any rank saw an atom move skin/2):
   3. the half list is built on the device from owned + ghost rows with global ids as tags, so each physical
      pair is evaluated by exactly one rank with the lower id as the integrated particle (docs/SPEC.md §7).
 Every step: forward (x, quat of the send lists -> the peers' ghost rows), pair forces, reverse (ghost forces
-added into their owners), integrate.  Between two ranks the messages of one step travel in ONE batched
-point-to-point group per direction, ordered by the sender's direction code on both sides (RCCL matches
-send/recv between a pair of ranks in issue order).
+added into their owners), integrate.  Per step and direction of travel there is ONE batched point-to-point
+group with one message per peer and array: the rows for all directions that lead to the same peer are
+contiguous in the gathered send buffer and in the ghost rows (both ordered by the sender's direction code).
 
 torch.distributed is the transport: backend `nccl` (= RCCL over xGMI) with device tensors, or — for
 rehearsals on a box with fewer GPUs than ranks and for tests — `gloo` with the buffers staged through the
@@ -34,7 +34,7 @@ def _dir_code(dx, dy, dz):
 class MultiRankRun:
     def __init__(self, sp, dist, rank, world, grid, lo, hi, periodic, skin, x, quat, shtype, tag, type_=None, v=None,
                  angmom=None, mask=None, groupbit=1, dt=1e-3, gravity=(0.0, 0.0, 0.0), gamma_t=0.0, gamma_r=0.0, device="cuda:0", staged=False,
-                 capacity_factor=3.0):
+                 capacity_factor=3.0, check_every=1):
         self.sp, self.dist, self.rank, self.world, self.staged = sp, dist, rank, world, staged
         self.grid = tuple(int(g) for g in grid)
         assert int(np.prod(self.grid)) == world
@@ -82,6 +82,7 @@ class MultiRankRun:
         put(self.x, x, np.float64); put(self.q, quat, np.float64); put(self.v, v, np.float64); put(self.L, angmom, np.float64)
         put(self.tag, tag, np.int32); put(self.sh, shtype, np.int32); put(self.ty, type_, np.int32); put(self.mask, mask, np.int32)
         self.groupbit = int(groupbit)
+        self.check_every = max(1, int(check_every))   # rebuild test (a host sync and an all-reduce) every this many steps
         self.n = n
         self.nghost = 0
         self.builds = 0
@@ -220,9 +221,11 @@ class MultiRankRun:
             if p["peer"] == self.rank:                       # own periodic image: arrives as the opposite direction
                 nrecv[by_code[26 - p["code"]]] = nsend[k]
         nrecv = nrecv.cpu().tolist()
+        # ghost rows: first what the remote peers send, peer by peer in the order they send it (so that the rows of one
+        # peer are contiguous and travel as ONE message per array), then the rank's own periodic images
         off = n
-        for k, p in enumerate(plan):
-            p["recv"] = (off, off + nrecv[k])
+        for k in recvs + [k for k, p in enumerate(plan) if p["peer"] == self.rank]:
+            plan[k]["recv"] = (off, off + nrecv[k])
             off += nrecv[k]
         if off > self.nmax:
             raise MemoryError(f"rank {self.rank}: {n} owned + {off - n} ghost rows exceed the capacity {self.nmax}")
@@ -248,6 +251,13 @@ class MultiRankRun:
                             if selfs else torch.zeros(0, 3, dtype=torch.float64, device=self.dev))
         self._rf = torch.empty(self._send_all.numel(), 3, dtype=torch.float64, device=self.dev)
         self._rt = torch.empty_like(self._rf)
+        # one message per peer and array: [peer, (first, last) row of the gathered send buffer, (first, last) ghost row]
+        self._peer_msgs = []
+        for peer in sorted({plan[k]["peer"] for k in sends}):
+            ks = [k for k in sends if plan[k]["peer"] == peer]
+            kr = [k for k in recvs if plan[k]["peer"] == peer]
+            self._peer_msgs.append((peer, (self._send_slices[ks[0]][0], self._send_slices[ks[-1]][1]),
+                                    (plan[kr[0]]["recv"][0], plan[kr[-1]]["recv"][1])))
         # static per-ghost data, then positions
         self._exchange_rows([self.tag, self.sh, self.ty], shift=False)
         self.forward()
@@ -264,8 +274,8 @@ class MultiRankRun:
             if shift and a is self.x:
                 g += self._send_shift
             bufs.append(g)
-        sends = [(plan[k]["peer"], b[self._send_slices[k][0]:self._send_slices[k][1]]) for k in self._send_order for b in bufs]
-        recvs = [(plan[k]["peer"], a[plan[k]["recv"][0]:plan[k]["recv"][1]]) for k in self._recv_order for a in arrays]
+        sends = [(peer, b[so[0]:so[1]]) for peer, so, _ in self._peer_msgs for b in bufs]
+        recvs = [(peer, a[ro[0]:ro[1]]) for peer, _, ro in self._peer_msgs for a in arrays]
         self._p2p(sends, recvs)
         if self._self_src.numel():                      # own periodic images
             for a in arrays:
@@ -282,9 +292,8 @@ class MultiRankRun:
         plan = self.plan
         # ghost rows travel back: what came in through a direction returns to that peer, which adds it to the rows it
         # sent.  The peer sends in ITS receive order (peer, 26 - code ascending) = our send order seen from there.
-        sends = [(plan[k]["peer"], a[plan[k]["recv"][0]:plan[k]["recv"][1]]) for k in self._recv_order for a in (self.f, self.tq)]
-        recvs = [(plan[k]["peer"], b[self._send_slices[k][0]:self._send_slices[k][1]]) for k in self._send_order
-                 for b in (self._rf, self._rt)]
+        sends = [(peer, a[ro[0]:ro[1]]) for peer, _, ro in self._peer_msgs for a in (self.f, self.tq)]
+        recvs = [(peer, b[so[0]:so[1]]) for peer, so, _ in self._peer_msgs for b in (self._rf, self._rt)]
         self._p2p(sends, recvs)
         if self._send_all.numel():
             self.f.index_add_(0, self._send_all, self._rf)
@@ -316,12 +325,13 @@ class MultiRankRun:
 
     def step(self, eflag=False):
         self._nve(0)
-        moved = self.sp.neighbor_check_device(self.n, self.x.data_ptr()) if self.n else False
-        flag = torch.tensor([1.0 if moved else 0.0], device="cpu" if self.staged else self.dev)
-        if self.world > 1:
-            self.dist.all_reduce(flag, op=self.dist.ReduceOp.MAX)
-        if flag.item() > 0:
-            self.rebuild()
+        if (self.steps + 1) % self.check_every == 0:
+            moved = self.sp.neighbor_check_device(self.n, self.x.data_ptr()) if self.n else False
+            flag = torch.tensor([1.0 if moved else 0.0], device="cpu" if self.staged else self.dev)
+            if self.world > 1:
+                self.dist.all_reduce(flag, op=self.dist.ReduceOp.MAX)
+            if flag.item() > 0:
+                self.rebuild()
         self.force(eflag)
         self._nve(1)
         self.steps += 1
