@@ -92,8 +92,12 @@ constexpr int kMaxWavesPerBlock = 4;
 #ifndef SHP_WMIN_WAVES
 #define SHP_WMIN_WAVES(L) (((L) >= 0 && (L) <= 6) ? 5 : 4)
 #endif
+// Waves per SIMD the register allocator must leave room for.  Up to L = 6 the sharp kernels fit 80 VGPRs (6 waves)
+// with at most one spilled value; interleaved A/B against 5 waves (96 VGPRs): L = 4, n_q = 10 +3 %, L = 5,
+// n_q = 12 +4.5 %, L = 6, n_q = 8 +7 %, L = 6, n_q = 16 +1 % (there LDS, 7.5 KB per wave, already limits a CU to
+// 21 waves).  From L = 7 on, 80 VGPRs would spill 70+ bytes: 5 waves.
 #ifndef SHP_MIN_WAVES
-#define SHP_MIN_WAVES 5  // waves per SIMD the register allocator must leave room for (<= 96 VGPRs); A/B: 5 beats 4 and 6
+#define SHP_MIN_WAVES(L) (((L) >= 0 && (L) <= 6) ? 6 : 5)
 #endif
 
 // docs/SPEC.md §2.6: residual below which the inverse-quadratic extrapolation is accepted
@@ -388,7 +392,7 @@ __device__ __forceinline__ void ring_eval(const double* __restrict__ row, const 
 // covered fraction together with that fraction; phase 2 scales the node's weight by it.  n_q <= 32 (a ring
 // neighbour is at most one slab away) and ring groups of at least two slabs' worth of rings: checked on the host.
 template <int L, bool NEEDV, bool WEIGHTED = false>
-__global__ void __launch_bounds__(64 * kMaxWavesPerBlock, WEIGHTED ? SHP_WMIN_WAVES(L) : SHP_MIN_WAVES) pair_contact_kernel(const PairParams P)
+__global__ void __launch_bounds__(64 * kMaxWavesPerBlock, WEIGHTED ? SHP_WMIN_WAVES(L) : SHP_MIN_WAVES(L)) pair_contact_kernel(const PairParams P)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int lane = threadIdx.x & 63;

@@ -691,9 +691,9 @@ def test_kernel_info_reports_the_launched_footprint(oracle):
     b = case["bed"]
     sp.compute(60, b["x"], b["quat"], b["type"], b["shtype"])
     k = sp.kernel_info()
-    assert k["lmax"] == 6 and k["compiled_order"] == 1 and 64 <= k["vgprs"] <= 96 and k["scratch_bytes"] == 0
+    assert k["lmax"] == 6 and k["compiled_order"] == 1 and 64 <= k["vgprs"] <= 80 and k["scratch_bytes"] == 0
     assert 4096 < k["lds_bytes_per_wave"] <= 8192 and k["ring_rows"] == 16
-    assert k["waves_per_simd_vgpr"] == 5 and k["waves_per_cu"] == 20
+    assert k["waves_per_simd_vgpr"] == 6 and k["waves_per_cu"] == 21        # LDS (7.5 KB per wave) is the limit
     sp.set_option("rule", 1)
     sp.compute(60, b["x"], b["quat"], b["type"], b["shtype"])
     kw = sp.kernel_info()
