@@ -129,16 +129,27 @@ __host__ __device__ inline WaveLdsLayout wave_lds_layout(const int L, const int 
 {
   WaveLdsLayout w;
   const int ns = (L + 1) * (L + 1);
+  // frame | [rotation scratch] | rotated coefficients v0 | ring rows | queue.  The scratch of the coefficient
+  // rotation (the Euler trig tables and the second work vector v1) is dead before the first node is queued.  From
+  // L = 7 on it lies over the queue, which leaves room for more resident ring rows (L = 12, n_q = 32: +3 %); up to
+  // L = 6 it keeps its own place: the wave count is limited elsewhere there (A/B: no gain from 24 instead of 21
+  // waves per CU) and the separate layout compiles without a spill under the 80-VGPR bound.
+  const bool alias = L >= 7;
   w.trig = kFrame;
-  w.v0 = w.trig + 6 * (L + 1);
+  w.v0 = alias ? kFrame : w.trig + 6 * (L + 1);
   w.v1 = w.v0 + ns;
-  w.ring = w.v1 + ns;
+  w.ring = alias ? w.v0 + ns : w.v1 + ns;
   w.ring += w.ring & 1;  // 16-byte aligned rows for ds_read_b128
   w.qri = w.ring + 4 * rows * (L + 1);
   w.qrj = w.qri + kQueue;
   w.qp = w.qrj + kQueue;
   w.qw = w.qp + kQueue / 2;
   w.coef = w.qw + (weighted ? kQueue : 0);
+  if (alias) {
+    w.trig = w.qri;
+    w.v1 = w.trig + 6 * (L + 1);
+    if (w.v1 + ns > w.coef) w.coef = w.v1 + ns;  // large L: the scratch is longer than the queue
+  }
   w.coef += w.coef & 1;
 #ifdef SHP_COEF_LDS
   w.bytes = 8 * (w.coef + sh_chunk_stride(L));
