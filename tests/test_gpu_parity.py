@@ -699,3 +699,27 @@ def test_kernel_info_reports_the_launched_footprint(oracle):
     kw = sp.kernel_info()
     assert kw["lds_bytes_per_wave"] > k["lds_bytes_per_wave"] and kw["waves_per_cu"] in (18, 19)
     sp.close()
+
+
+def test_runtime_order_kernel_with_peratom_tallies_and_info(oracle):
+    """L = 14: the loop kernel (no compiled order) — per-atom tallies, kernel info, and the weighted rule refused."""
+    from shpair.capi import ShPairError
+    case = make_case(80, 14, 1, seed=47, rmax_fn=oracle.shape_rmax)
+    K, E = coeff_tables(1, 900.0, 1.25)
+    sp = make_ctx(case, 10, K, E)
+    b = case["bed"]
+    n = case["n"]
+    ea, va = np.zeros(n), np.zeros((n, 6))
+    sp.set_peratom_host(ea, va)
+    f, tq, eng, vir = sp.compute(n, b["x"], b["quat"], b["type"], b["shtype"], eflag=True, vflag=True)
+    o = oracle_compute(oracle, case, 10, K, E, eflag=True, vflag=True, want_peratom=True, nthreads=8)
+    check(f, tq, o)
+    assert np.abs(ea - o["eatom"]).max() < TOL * o["eatom"].max() and abs(ea.sum() - eng) < 1e-12 * eng
+    assert np.abs(va - o["vatom"]).max() < TOL * np.abs(o["vatom"]).max()
+    k = sp.kernel_info()
+    assert k["lmax"] == 14 and k["compiled_order"] == 0 and k["waves_per_cu"] >= 4
+    sp.set_peratom_host(None, None)
+    sp.set_option("rule", 1)
+    with pytest.raises(ShPairError):
+        sp.compute(n, b["x"], b["quat"], b["type"], b["shtype"])
+    sp.close()
