@@ -169,6 +169,13 @@ int shpair_set_peratom_output(shpair_ctx *ctx, double *eatom_dev, double *vatom_
 /* Host form for shpair_compute(): host arrays of the same shapes, staged through the device. */
 int shpair_set_peratom_host(shpair_ctx *ctx, double *eatom, double *vatom);
 
+/* The box's FP64 ceilings, measured instead of trusted (SURVEY.md §8d asks for a v_fma_f64 microbenchmark):
+ * mode 0 = independent v_fma_f64 chains on every SIMD (the vector peak the pair kernel is priced against),
+ * mode 1 = v_mfma_f64_16x16x4_f64 alone, mode 2 = both side by side on every SIMD (4 waves each).
+ * Runs on the context's device for about target_ms per launch (best of 5) and blocks.  TFLOP/s of the waves
+ * running each loop; either output may be NULL. */
+int shpair_fp64_peak(shpair_ctx *ctx, int mode, double target_ms, double *valu_tflops, double *mfma_tflops);
+
 /* The context's own non-blocking stream (a hipStream_t), used by
  * shpair_compute() for its staging copies and kernels. */
 int shpair_get_stream(shpair_ctx *ctx, void **stream);

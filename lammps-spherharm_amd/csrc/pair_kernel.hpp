@@ -187,6 +187,17 @@ __device__ __forceinline__ double rsqrt_nr(const double x)
   return y;
 }
 
+// The same with ONE Newton step: from v_rsq_f64's 2^-26 the step leaves 3/2 (2^-26)^2 = 3.3e-16 plus its own
+// rounding, i.e. 2-3 ulp.  Used where the root only normalises a direction or feeds a residual that is compared
+// with tolerances of 1e-7 and more (node loops: 4 VALU instructions fewer per radius evaluation).
+__device__ __forceinline__ double rsqrt_nr1(const double x)
+{
+  double y = __builtin_amdgcn_rsq(x);
+  const double h = fma(-x * y, y, 1.0);
+  y = fma(y * 0.5, h, y);
+  return y;
+}
+
 // sqrt(x) for x >= 0 as x * rsqrt(x): a third of the VALU work of the IEEE sqrt() expansion
 // (which rescales, iterates and fixes up special cases), accurate to the last ulp or two.
 __device__ __forceinline__ double sqrt_nr(const double x) { return (x > 0.0) ? x * rsqrt_nr(x) : 0.0; }
@@ -580,7 +591,7 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, WEIGHTED ? SHP_WMIN_WA
         const double s2 = q0 * q0 + q1 * q1 + q2 * q2;
         const bool cand = valid && (s2 < fr[FR_RJ2]);
         const bool szero = !(s2 > 0.0);
-        const double inv = rsqrt_nr(fmax(s2, 1e-300));
+        const double inv = rsqrt_nr1(fmax(s2, 1e-300));
         const double sN = s2 * inv;
         g0 = sN - fr[FR_RJ];  // outside B_j: the stand-in of SPEC §2.8 (>= 0)
         double rj0 = fr[FR_RJ];
@@ -684,7 +695,7 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, WEIGHTED ? SHP_WMIN_WA
       // s == 0 (the node sits on x_j) is inside by definition; clamping s2 keeps that lane
       // finite without a select per component (its direction is then the zero vector)
       const bool szero = !(s2 > 0.0);
-      const double inv = rsqrt_nr(fmax(s2, 1e-300));
+      const double inv = rsqrt_nr1(fmax(s2, 1e-300));
       const double rj0e = sh_eval<L>(rc, cwj, lrt, q0 * inv, q1 * inv, q2 * inv);
       const double rj0 = szero ? fr[FR_RJ] : rj0e;
       // SPEC: inside iff s < r_j (s == 0 is inside); s = s2 / sqrt(s2)
@@ -778,7 +789,7 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, WEIGHTED ? SHP_WMIN_WA
                      y2 = fma(lam, uj2, -fr[FR_DJ + 2]);
         const double ss2 = y0 * y0 + y1 * y1 + y2 * y2;
         const bool z0 = !(ss2 > 0.0);
-        const double iv = rsqrt_nr(fmax(ss2, 1e-300));
+        const double iv = rsqrt_nr1(fmax(ss2, 1e-300));
         const double rj = sh_eval<L>(rc, cwj, lrt, y0 * iv, y1 * iv, y2 * iv);
         const double Rjl = fr[FR_RJ];
         const double gl = z0 ? -Rjl : ss2 * iv - rj;

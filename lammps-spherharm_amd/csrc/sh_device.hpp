@@ -127,45 +127,43 @@ __device__ __forceinline__ void sh_term(const double cr, const double ci, const 
 }
 
 struct ShState {
-  double Cm, Sm;   // E_m = (x + i y)^m
-  double r;
+  double ar, ai;   // the running sum over the blocks done so far, see sh_block_end
   ShAcc a;
 };
 
-// Block m is complete: fold W_m into r, advance E_m.
+// r = sum_m Re[W_m e^m], e = x + i y, is itself a Horner scheme in e:
+//   r = Re[W_0 + e (W_1 + e (W_2 + ... + e W_L))],
+// so the blocks are walked from m = L DOWN to 0 and block m costs one complex multiply-add
+// acc <- acc e + W_m (4 v_fma_f64; 2 for the last, whose imaginary part is not needed) instead of a power
+// recurrence E_{m+1} = E_m e (4) plus the fold r += Re[W_m E_m] (2): 4(L-1)+2 operations instead of 6(L-1)+2.
+// W_L is a constant (degree 0 in z): the chain starts from two wave-uniform values.
 template <int L, int M>
 __device__ __forceinline__ void sh_block_end(const double x, const double y, ShState& t)
 {
   const ShAcc& s = t.a;
-  if constexpr (M == 0) {
-    t.r = s.Wr;
+  if constexpr (M == L) {
+    t.ar = s.Wr;
+    t.ai = s.Wi;   // L == 0: never read
+  } else if constexpr (M > 0) {
+    const double nr = fma(t.ar, x, fma(-t.ai, y, s.Wr));
+    t.ai = fma(t.ar, y, fma(t.ai, x, s.Wi));
+    t.ar = nr;
   } else {
-    t.r = fma(s.Wr, t.Cm, t.r);
-    t.r = fma(-s.Wi, t.Sm, t.r);
-  }
-  if constexpr (M < L) {  // E_{m+1} = E_m (x + i y)
-    if constexpr (M == 0) {
-      t.Cm = x;
-      t.Sm = y;
-    } else {
-      const double c = fma(t.Cm, x, -(t.Sm * y));
-      t.Sm = fma(t.Cm, y, t.Sm * x);
-      t.Cm = c;
-    }
+    t.ar = fma(t.ar, x, fma(-t.ai, y, s.Wr));
   }
 }
 
 // The chunk that starts at position N0 - M of block M, its coefficients already requested in
-// `cur`; requests its successor, computes its terms, recurses.
+// `cur`; requests its successor, computes its terms, recurses.  Blocks in DESCENDING m.
 template <int L, int M, int N0>
 struct ShStep {
   static __device__ __forceinline__ void run(const cdptr cw_in, const sh_d8 cur, const double x, const double y,
                                              const double z, ShState& t)
   {
     constexpr bool block_done = (N0 + kChunk > L);
-    constexpr bool has_next = !block_done || (M + 1 <= L);
-    constexpr int Mn = block_done ? M + 1 : M;
-    constexpr int Nn = block_done ? M + 1 : N0 + kChunk;
+    constexpr bool has_next = !block_done || (M >= 1);
+    constexpr int Mn = block_done ? M - 1 : M;
+    constexpr int Nn = block_done ? M - 1 : N0 + kChunk;
     sh_d8 nxt = cur;
     if constexpr (has_next) nxt = sload_chunk(cw_in, 2 * sh_index(L, Nn, Mn));
     sh_term<L, M, N0 - M>(cur[0], cur[1], z, t.a);
@@ -219,14 +217,13 @@ __device__ __forceinline__ double sh_eval(const double* rc_in, const double* cw_
   double r;
   if constexpr (L >= 0) {
     ShState t;
-    t.Cm = 1.0;
-    t.Sm = 0.0;
-    t.r = 0.0;
+    t.ar = 0.0;
+    t.ai = 0.0;
     const cdptr cwl = launder_uniform(cw_in);
-    const sh_d8 first = sload_chunk(cwl, 0);
+    const sh_d8 first = sload_chunk(cwl, 2 * sh_index(L, L, L));
     __builtin_amdgcn_sched_barrier(0);
-    ShStep<L, 0, 0>::run(cwl, first, x, y, z, t);
-    r = t.r;
+    ShStep<L, L, L>::run(cwl, first, x, y, z, t);
+    r = t.ar;
   } else {
     r = sh_eval_rt(rc_in, cw_in, lrt, x, y, z);
   }

@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "../../include/shpair.h"
+#include "fp64_peak.hpp"
 #include "pair_kernel.hpp"
 #include "shpair_ctx.hpp"
 #include "sh_const.hpp"
@@ -747,6 +748,19 @@ int shpair_debug_set_counters(shpair_ctx* c, unsigned long long* dbg_dev)
 {
   if (!c) return SHPAIR_EINVAL;
   c->dbg = dbg_dev;
+  return SHPAIR_OK;
+}
+
+int shpair_fp64_peak(shpair_ctx* c, int mode, double target_ms, double* valu_tflops, double* mfma_tflops)
+{
+  if (!c) return SHPAIR_EINVAL;
+  if (mode < 0 || mode > 2 || !(target_ms > 0.0) || target_ms > 2000.0)
+    CTX_FAIL(c, SHPAIR_EINVAL, "fp64_peak: mode %d not in 0..2 or target_ms %g not in (0, 2000]", mode, target_ms);
+  HIPCHK(c, hipSetDevice(c->device));
+  Fp64PeakResult r;
+  HIPCHK(c, fp64_peak_run(mode, target_ms, 5, &r, c->stream));
+  if (valu_tflops) *valu_tflops = r.valu_tflops;
+  if (mfma_tflops) *mfma_tflops = r.mfma_tflops;
   return SHPAIR_OK;
 }
 

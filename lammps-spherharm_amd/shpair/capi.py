@@ -71,6 +71,7 @@ SYMBOLS = {
     "shpair_set_pair_output": (C.c_int, [C.c_void_p, C.c_void_p]),
     "shpair_set_peratom_output": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "shpair_set_peratom_host": (C.c_int, [C.c_void_p, _dp, _dp]),
+    "shpair_fp64_peak": (C.c_int, [C.c_void_p, C.c_int, C.c_double, _dp, _dp]),
     "shpair_get_stream": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
     "shpair_synchronize": (C.c_int, [C.c_void_p]),
     # include/shstep.h
@@ -304,6 +305,13 @@ class ShPair:
         k = KernelInfo()
         self._chk(self._lib.shpair_get_kernel_info(self._h, C.byref(k)))
         return {n: getattr(k, n) for n, _ in KernelInfo._fields_}
+
+    def fp64_peak(self, mode=0, target_ms=20.0):
+        """Measured FP64 ceilings of this GPU in TFLOP/s: (valu, mfma) of the waves running each loop
+        (mode 0 v_fma_f64 chains, 1 v_mfma_f64_16x16x4_f64, 2 both side by side)."""
+        a, b = C.c_double(), C.c_double()
+        self._chk(self._lib.shpair_fp64_peak(self._h, int(mode), float(target_ms), C.byref(a), C.byref(b)))
+        return a.value, b.value
 
     def own_stream(self):
         """The context's own hipStream_t as an int (None-safe for compute_device(stream=...))."""
