@@ -1,0 +1,176 @@
+/*
+ * shhalo.h — C ABI of the N > 1 path of `pair_style sh` (BASELINE.json configs[3]): LAMMPS'
+ * spatial domain decomposition around PairSH::compute — Comm::exchange (atom migration), Comm::borders (ghost
+ * selection), Comm::forward_comm (x + quaternion of ghosts) and Comm::reverse_comm (force + torque of ghosts
+ * summed into their owners) — for a host whose atoms are resident in HBM, one rank and one shpair context per
+ * GPU, on RCCL point-to-point over xGMI.  Same library (libshpair.so) and conventions as include/shpair.h
+ * (0 or a negative SHPAIR_E* code; shhalo_last_error() gives the detail).
+ *
+ * Reference citations: the fork's Comm code is stock LAMMPS and ABSENT FROM MOUNT (/root/reference/README.md:1 is
+ * the whole reference), so each entry point names the LAMMPS interface it serves.
+ *
+ * MI355X-first shape: bricks of a px x py x pz grid; every rank talks to each of its <= 26
+ * geometric neighbours (7 distinct peers on a 2x2x2 node, one per xGMI link) DIRECTLY: per step and direction of
+ * travel ONE ncclGroupStart .. ncclSend/ncclRecv per peer .. ncclGroupEnd on the caller's stream, no host wait,
+ * one pack and one unpack kernel whatever the number of peers — instead of LAMMPS' three staged x/y/z swaps.
+ * The plan (who sends which rows to whom, and where they land) is rebuilt on the device at every reneighbouring;
+ * the same plan logic is exported as pure host functions (shhalo_plan_*) so that it can be tested without a GPU.
+ *
+ * Transports: RCCL (the product; librccl is bound at run time with dlopen, so a single-GPU host does not need
+ * it), and an in-process hub that moves the same messages between the contexts of several host THREADS of one
+ * process with device copies — for rehearsing N ranks on fewer than N GPUs (tests) and for self-periodic
+ * single-rank runs.  Memory: every array handed in must be ordinary device memory (hipMalloc): the force
+ * accumulation uses hardware FP64 atomics, which fine-grained / host-coherent allocations do not support.
+ */
+#ifndef SHHALO_H
+#define SHHALO_H
+
+#include "shpair.h"
+#include "shstep.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SHHALO_UNIQUE_ID_BYTES 128 /* sizeof(ncclUniqueId) */
+
+typedef struct shhalo_ctx shhalo_ctx;
+typedef struct shhalo_hub shhalo_hub;
+
+/* ---- the plan, as pure host functions (no device, no transport) ------------------------------------------ */
+
+/* One rank's view of the brick decomposition.  Direction code of a step s = (sx, sy, sz) in {-1,0,1}^3:
+ * (sz+1)*9 + (sy+1)*3 + (sx+1); 13 is the rank itself. */
+typedef struct shhalo_geometry {
+  int grid[3], coord[3], rank, nranks;
+  int periodic[3];
+  double lo[3], hi[3];   /* the global orthogonal box */
+  double blo[3], bhi[3]; /* this rank's brick [blo, bhi) */
+  double cut;            /* ghost cutoff: 2 max Rmax + skin */
+  int peer[27];          /* rank a direction leads to; -1 for none (open boundary) and for code 13 */
+  double shift[27][3];   /* added to the position of a row sent in that direction (a box length where the hop
+                            crosses a periodic boundary) */
+} shhalo_geometry;
+
+/* Most cubic px >= py >= pz factorisation of nranks (LAMMPS' default processor-grid idea). */
+int shhalo_proc_grid(int nranks, int grid[3]);
+
+/* Rank <-> brick: rank = (ix*py + iy)*pz + iz.  Fails with SHPAIR_EINVAL if a decomposed brick edge is shorter
+ * than `cut` or an undecomposed periodic edge shorter than 2 cut. */
+int shhalo_plan_geometry(const int grid[3], const double lo[3], const double hi[3], const int periodic[3], double cut,
+                         int rank, shhalo_geometry *out);
+
+/* Comm::exchange, decision part: wraps x[n][3] into the periodic box in place and returns the owning rank of every
+ * row (the brick it lies in; coordinates outside an open boundary belong to the outermost brick). */
+int shhalo_plan_owner(const shhalo_geometry *g, int n, double *x, int *owner);
+
+/* Comm::borders, decision part: bit c of mask[i] is set iff owned row i becomes a ghost of the neighbour in
+ * direction code c:  x_d >= bhi_d - cut for s_d = +1,  x_d < blo_d + cut for s_d = -1, and the direction has a peer. */
+int shhalo_plan_ghost_mask(const shhalo_geometry *g, int n, const double *x, unsigned *mask);
+
+/* Message layout from the per-direction counts.  All arrays are indexed by MY direction code (27 entries).
+ * Send rows are ordered by (peer rank, my code); what arrives through my direction c was sent by peer[c] with
+ * ITS code 26 - c, and the ghost rows are ordered by (peer rank, sender's code) — so that the rows exchanged
+ * with one peer are contiguous on both sides and travel as one message.  The rank is its own peer where a
+ * periodic dimension is not decomposed; those blocks are copied locally. */
+typedef struct shhalo_layout {
+  int send_off[27], send_cnt[27]; /* rows of the send buffer */
+  int recv_off[27], recv_cnt[27]; /* ghost rows (relative to nlocal) */
+  int nsend, nghost;
+  int npeers;                     /* distinct REMOTE peers, ascending rank */
+  int peer_rank[26];
+  int peer_send_off[26], peer_send_cnt[26];
+  int peer_recv_off[26], peer_recv_cnt[26];
+} shhalo_layout;
+int shhalo_plan_layout(const shhalo_geometry *g, const int send_cnt[27], const int recv_cnt[27], shhalo_layout *out);
+
+/* ---- contexts and transports ------------------------------------------------------------------------------ */
+
+/* ncclGetUniqueId(): rank 0 calls this and hands the bytes to every rank with whatever the host has
+ * (MPI_Bcast in LAMMPS, a torch.distributed broadcast in bench.py). */
+int shhalo_get_unique_id(unsigned char id[SHHALO_UNIQUE_ID_BYTES]);
+
+/* One context per rank, bound to the rank's shpair context (whose shapes must be set: the ghost cutoff is
+ * 2 max Rmax + skin).  Sets the shpair context's neighbour-build box to the brick plus the ghost shell.
+ * RCCL form: collective over all ranks (ncclCommInitRank). */
+int shhalo_create_rccl(shhalo_ctx **out, shpair_ctx *sp, const unsigned char id[SHHALO_UNIQUE_ID_BYTES], int rank,
+                       int nranks, const int grid[3], const double lo[3], const double hi[3], const int periodic[3],
+                       double skin);
+/* In-process form: the ranks are host threads of one process sharing a hub (created for nranks; each rank
+ * creates its context from its own thread or from one thread before the rank threads start).  nranks = 1 needs
+ * no hub (NULL): every exchange is then a local copy (a self-periodic single rank). */
+int shhalo_hub_create(shhalo_hub **out, int nranks);
+void shhalo_hub_destroy(shhalo_hub *hub);
+int shhalo_create_local(shhalo_ctx **out, shpair_ctx *sp, shhalo_hub *hub, int rank, int nranks, const int grid[3],
+                        const double lo[3], const double hi[3], const int periodic[3], double skin);
+void shhalo_destroy(shhalo_ctx *h);
+const char *shhalo_last_error(const shhalo_ctx *h);
+int shhalo_get_geometry(const shhalo_ctx *h, shhalo_geometry *out);
+
+/* Device pointers of one rank's particles; every array holds nmax rows (owned rows first, then ghosts; v, angmom,
+ * mask are only used for owned rows but must be able to take nmax rows, because owned atoms arrive by migration). */
+typedef struct shhalo_arrays {
+  int nlocal, nmax;
+  double *x, *v, *quat, *angmom, *f, *torque;
+  int *type, *shtype, *mask, *tag;  /* tag: global ids, unique over all ranks */
+} shhalo_arrays;
+
+/* Comm::exchange: wraps the owned rows into the periodic box, sends those that left the brick to their new owner
+ * (one message per peer) and takes in the arrivals; a->nlocal is updated.  Blocks (counts are read back).
+ * Fails with SHPAIR_ESTATE if an atom left the brick AND its 26 neighbours (lost atom), SHPAIR_ENOMEM if nmax is
+ * too small. */
+int shhalo_exchange_device(shhalo_ctx *h, shhalo_arrays *a, void *stream);
+
+/* Comm::borders: selects the ghosts for all 26 directions, exchanges counts, builds the send lists on the device
+ * and fills the ghost rows nlocal .. nlocal+nghost-1 of x, quat, type, shtype, tag.  Blocks.  The plan stays
+ * valid until the next call. */
+int shhalo_borders_device(shhalo_ctx *h, const shhalo_arrays *a, int *nghost, void *stream);
+
+/* Comm::forward_comm: owners' x (+ shift) and quat -> the ghost rows of every neighbour.  Enqueues one pack
+ * kernel, one RCCL group and one unpack kernel on `stream`; does not wait. */
+int shhalo_forward_device(shhalo_ctx *h, double *x_dev, double *quat_dev, void *stream);
+/* Comm::reverse_comm: ghost rows of f and torque -> added into their owners' rows.  Enqueue only. */
+int shhalo_reverse_device(shhalo_ctx *h, double *f_dev, double *torque_dev, void *stream);
+
+/* Neighbor::decide over all ranks: *rebuild = 1 if an owned atom of ANY rank moved more than skin/2 since the
+ * last list build of the bound shpair context (one max-all-reduce of a flag; blocks for the read-back). */
+int shhalo_check_rebuild_device(shhalo_ctx *h, int nlocal, const double *x_dev, int *rebuild, void *stream);
+
+/* Thermo sums: in-place sum over all ranks of n doubles on the device.  Enqueue only. */
+int shhalo_allreduce_sum_device(shhalo_ctx *h, double *data_dev, int n, void *stream);
+
+/* Counters since creation (host values, no synchronisation). */
+typedef struct shhalo_stats {
+  int nranks_transport;        /* what the transport reports (ncclCommCount for RCCL) */
+  int npeers;                  /* distinct remote peers of the current plan */
+  int nsend_rows, nghost_rows; /* current plan */
+  long long rebuilds, migrated_out, migrated_in;
+  long long forward_bytes_per_step, reverse_bytes_per_step; /* bytes this rank sends to remote peers */
+  int transport;               /* 0 local, 1 RCCL */
+  int rccl_version;            /* ncclGetVersion, 0 for the local transport */
+} shhalo_stats;
+int shhalo_get_stats(const shhalo_ctx *h, shhalo_stats *out);
+
+/* Verlet::run over all ranks for nsteps (every rank calls it with the same nsteps and check_every):
+ * initial_integrate -> [every check_every steps: rebuild test over all ranks -> exchange + borders + neighbour
+ * build] -> forward -> clear -> pair compute -> reverse -> post_force (gravity / viscous, if any is non-zero) ->
+ * final_integrate, all on `stream`; the host only waits at the rebuild tests.  On entry the plan, ghosts and list of
+ * the current positions must exist (shhalo_exchange_device + shhalo_borders_device +
+ * shstep_neighbor_build_device with tags) and f, torque must hold their forces (as after Verlet::setup).
+ * a->nlocal and *nghost are updated.  kernel_ms (nullable): sum of the pair-kernel times of the steps (hipEvents
+ * recorded on `stream`).  Blocks until the last step is done. */
+typedef struct shhalo_run_params {
+  double dt;
+  int groupbit;
+  double gravity[3], gamma_t, gamma_r;
+  int check_every;
+  int eflag_last; /* 1: the last step tallies energy / virial into ev_dev (7 doubles, ADDED to) */
+  double *ev_dev;
+} shhalo_run_params;
+int shhalo_run_device(shhalo_ctx *h, shhalo_arrays *a, const shhalo_run_params *p, int nsteps, int *nghost,
+                      int *rebuilds, double *kernel_ms, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SHHALO_H */

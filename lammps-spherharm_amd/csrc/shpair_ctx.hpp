@@ -94,6 +94,8 @@ struct shpair_ctx {
 void shstep_release_state(shpair_ctx* c);   // shstep_api.hip
 void shstep_invalidate_list(shpair_ctx* c);
 int shpair_prepare_tables(shpair_ctx* c);    // shpair_api.hip
+int shstep_exclusive_scan(shpair_ctx* c, const int* in, int* out, int n, void* stream);                           // shstep_api.hip
+int shstep_enqueue_check(shpair_ctx* c, int nlocal, const double* x, int** flag_dev, int* forced, void* stream);  // shstep_api.hip
 
 #define CTX_FAIL(ctx, code, ...)                         \
   do {                                                   \

@@ -489,6 +489,42 @@ int shstep_neighbor_check_device(shpair_ctx* c, int nlocal, const double* x, int
   return SHPAIR_OK;
 }
 
+}  // extern "C"
+
+// Internal (shpair_ctx.hpp): the three-pass exclusive scan, for the plan builder of shhalo_api.hip.  out[n] = total.
+int shstep_exclusive_scan(shpair_ctx* c, const int* in, int* out, int n, void* stream)
+{
+  STEP_PROLOGUE(c);
+  return exclusive_scan(c, s, in, out, n, (hipStream_t)stream);
+}
+
+// Internal (shpair_ctx.hpp), for the multi-rank loop of shhalo_api.hip: enqueues the displacement test of
+// Neighbor::check_distance and hands back the device flag (1 = an owned row moved more than skin/2) instead of reading
+// it, so that the caller can all-reduce it first.  *forced = 1 (nothing enqueued): there is no list for these rows.
+int shstep_enqueue_check(shpair_ctx* c, int nlocal, const double* x, int** flag_dev, int* forced, void* stream)
+{
+  STEP_PROLOGUE(c);
+  if (!flag_dev || !forced) CTX_FAIL(c, SHPAIR_EINVAL, "null output pointer");
+  HIPCHK(c, s->d_flags.ensure(4));
+  *flag_dev = s->d_flags.p + 1;
+  *forced = 0;
+  hipStream_t st = (hipStream_t)stream;
+  HIPCHK(c, hipMemsetAsync(s->d_flags.p + 1, 0, sizeof(int), st));
+  if (s->l_nlocal < 0 || nlocal != s->l_nlocal) {
+    *forced = 1;
+    return SHPAIR_OK;
+  }
+  if (nlocal == 0) return SHPAIR_OK;
+  if (!x) CTX_FAIL(c, SHPAIR_EINVAL, "null array pointer");
+  const double trig = 0.5 * s->skin;
+  hipLaunchKernelGGL(check_distance_kernel, dim3(nblk(nlocal, kStepBlock)), dim3(kStepBlock), 0, st, nlocal, x,
+                     (const double*)s->d_xhold.p, trig * trig, s->d_flags.p + 1);
+  HIPCHK(c, hipGetLastError());
+  return SHPAIR_OK;
+}
+
+extern "C" {
+
 int shstep_copy_neighbors(shpair_ctx* c, int* offsets, int* jlist)
 {
   STEP_PROLOGUE(c);

@@ -42,6 +42,43 @@ class StepArrays(C.Structure):
                 ("gamma_r", C.c_double), ("check_every", C.c_int)]
 
 
+class HaloGeometry(C.Structure):
+    """shhalo_geometry of include/shhalo.h."""
+    _fields_ = [("grid", C.c_int * 3), ("coord", C.c_int * 3), ("rank", C.c_int), ("nranks", C.c_int),
+                ("periodic", C.c_int * 3), ("lo", C.c_double * 3), ("hi", C.c_double * 3), ("blo", C.c_double * 3),
+                ("bhi", C.c_double * 3), ("cut", C.c_double), ("peer", C.c_int * 27), ("shift", (C.c_double * 3) * 27)]
+
+
+class HaloLayout(C.Structure):
+    """shhalo_layout of include/shhalo.h."""
+    _fields_ = [("send_off", C.c_int * 27), ("send_cnt", C.c_int * 27), ("recv_off", C.c_int * 27), ("recv_cnt", C.c_int * 27),
+                ("nsend", C.c_int), ("nghost", C.c_int), ("npeers", C.c_int), ("peer_rank", C.c_int * 26),
+                ("peer_send_off", C.c_int * 26), ("peer_send_cnt", C.c_int * 26), ("peer_recv_off", C.c_int * 26),
+                ("peer_recv_cnt", C.c_int * 26)]
+
+
+class HaloArrays(C.Structure):
+    """shhalo_arrays of include/shhalo.h."""
+    _fields_ = [("nlocal", C.c_int), ("nmax", C.c_int), ("x", C.c_void_p), ("v", C.c_void_p), ("quat", C.c_void_p),
+                ("angmom", C.c_void_p), ("f", C.c_void_p), ("torque", C.c_void_p), ("type", C.c_void_p), ("shtype", C.c_void_p),
+                ("mask", C.c_void_p), ("tag", C.c_void_p)]
+
+
+class HaloStats(C.Structure):
+    _fields_ = [("nranks_transport", C.c_int), ("npeers", C.c_int), ("nsend_rows", C.c_int), ("nghost_rows", C.c_int),
+                ("rebuilds", C.c_longlong), ("migrated_out", C.c_longlong), ("migrated_in", C.c_longlong),
+                ("forward_bytes_per_step", C.c_longlong), ("reverse_bytes_per_step", C.c_longlong), ("transport", C.c_int),
+                ("rccl_version", C.c_int)]
+
+
+class HaloRunParams(C.Structure):
+    _fields_ = [("dt", C.c_double), ("groupbit", C.c_int), ("gravity", C.c_double * 3), ("gamma_t", C.c_double),
+                ("gamma_r", C.c_double), ("check_every", C.c_int), ("eflag_last", C.c_int), ("ev_dev", C.c_void_p)]
+
+
+_up = C.POINTER(C.c_uint)
+_idp = C.c_char_p  # SHHALO_UNIQUE_ID_BYTES raw bytes
+
 # every symbol include/shpair.h declares: name -> (restype, argtypes)
 SYMBOLS = {
     "shpair_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int]),
@@ -92,6 +129,31 @@ SYMBOLS = {
     "shstep_neighbor_check_device": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, _ip, C.c_void_p]),
     "shstep_copy_neighbors": (C.c_int, [C.c_void_p, _ip, _ip]),
     "shstep_run_device": (C.c_int, [C.c_void_p, C.POINTER(StepArrays), C.c_int, C.c_int, _ip, _ip, C.c_void_p]),
+    # include/shhalo.h
+    "shhalo_proc_grid": (C.c_int, [C.c_int, _ip]),
+    "shhalo_plan_geometry": (C.c_int, [_ip, _dp, _dp, _ip, C.c_double, C.c_int, C.POINTER(HaloGeometry)]),
+    "shhalo_plan_owner": (C.c_int, [C.POINTER(HaloGeometry), C.c_int, _dp, _ip]),
+    "shhalo_plan_ghost_mask": (C.c_int, [C.POINTER(HaloGeometry), C.c_int, _dp, _up]),
+    "shhalo_plan_layout": (C.c_int, [C.POINTER(HaloGeometry), _ip, _ip, C.POINTER(HaloLayout)]),
+    "shhalo_get_unique_id": (C.c_int, [C.c_void_p]),
+    "shhalo_create_rccl": (C.c_int, [C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p, C.c_int, C.c_int, _ip, _dp, _dp, _ip,
+                                     C.c_double]),
+    "shhalo_hub_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int]),
+    "shhalo_hub_destroy": (None, [C.c_void_p]),
+    "shhalo_create_local": (C.c_int, [C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p, C.c_int, C.c_int, _ip, _dp, _dp, _ip,
+                                      C.c_double]),
+    "shhalo_destroy": (None, [C.c_void_p]),
+    "shhalo_last_error": (C.c_char_p, [C.c_void_p]),
+    "shhalo_get_geometry": (C.c_int, [C.c_void_p, C.POINTER(HaloGeometry)]),
+    "shhalo_exchange_device": (C.c_int, [C.c_void_p, C.POINTER(HaloArrays), C.c_void_p]),
+    "shhalo_borders_device": (C.c_int, [C.c_void_p, C.POINTER(HaloArrays), _ip, C.c_void_p]),
+    "shhalo_forward_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "shhalo_reverse_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "shhalo_check_rebuild_device": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, _ip, C.c_void_p]),
+    "shhalo_allreduce_sum_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "shhalo_get_stats": (C.c_int, [C.c_void_p, C.POINTER(HaloStats)]),
+    "shhalo_run_device": (C.c_int, [C.c_void_p, C.POINTER(HaloArrays), C.POINTER(HaloRunParams), C.c_int, _ip, _ip, _dp,
+                                    C.c_void_p]),
 }
 
 

@@ -16,10 +16,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def header_symbols():
     names = set()
-    for h in ("shpair.h", "shstep.h"):
+    for h in ("shpair.h", "shstep.h", "shhalo.h"):
         txt = open(os.path.join(ROOT, "include", h)).read()
         txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
-        names |= set(re.findall(r"\b(sh(?:pair|step)_[a-z_]+)\s*\(", txt))
+        names |= set(re.findall(r"\b(sh(?:pair|step|halo)_[a-z0-9_]+)\s*\(", txt))
     return sorted(names)
 
 

@@ -1,0 +1,303 @@
+"""The N > 1 device path of include/shhalo.h on the one GPU of the box: the ranks are host THREADS of this process that
+share an in-process hub (same plan kernels, same pack / unpack kernels, same message pattern as the RCCL transport;
+only the bytes travel by device copies instead of ncclSend/ncclRecv).  One process on the GPU, whatever the rank count.
+
+ * static bed: decomposed HIP forces == single-domain HIP forces (<= 1e-12), device plan == host planner;
+ * moving atoms: migration + rebuilds through the C++ loop (shhalo_run_device) against the single-rank loop;
+ * BASELINE configs[3]: 1 M particles on 2x2x2 ranks, periodic in x and y, gravity: no atom lost, momentum balance,
+   sampled rows equal to the single-domain HIP forces;
+ * RCCL itself with the rank as its own communicator (world size 1) through the same C ABI.
+"""
+import os
+import sys
+import threading
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def _ctx(lmax, shp, nq, kn=400.0, expo=1.25):
+    from shpair import ShPair
+    sp = ShPair(0)
+    sp.settings(nq)
+    sp.set_ntypes(1, len(shp))
+    for s, a in enumerate(shp):
+        sp.set_shape(s, lmax, a)
+    sp.coeff(1, 1, kn, expo)
+    return sp
+
+
+def _bed(n_target, periodic, nshapes=2, jitter=0.15, seed=9):
+    from shpair import bed
+    pts, lo, hi = bed.periodic_hcp(n_target, 1.9, periodic)
+    rng = np.random.default_rng(seed)
+    n = pts.shape[0]
+    x = pts + rng.uniform(-jitter, jitter, pts.shape)
+    quat = bed.random_quaternions(n, rng)
+    sht = rng.integers(0, nshapes, n).astype(np.int32) if nshapes > 1 else np.zeros(n, np.int32)
+    return x, quat, sht, np.arange(n, dtype=np.int32), lo, hi, rng
+
+
+def _run_ranks(world, body):
+    """body(rank) in one thread per rank; re-raises the first failure."""
+    out, errs = [None] * world, []
+
+    def work(r):
+        try:
+            out[r] = body(r)
+        except BaseException as e:  # noqa: BLE001
+            import traceback
+            errs.append((r, repr(e), traceback.format_exc()))
+    th = [threading.Thread(target=work, args=(r,)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errs, errs[0]
+    return out
+
+
+def _distribute(grid, lo, hi, periodic, cut, x):
+    from shpair import mrank
+    g0 = mrank.plan_geometry(grid, lo, hi, periodic, cut, 0)
+    return mrank.plan_owner(g0, x)   # (wrapped x, owner)
+
+
+@pytest.mark.parametrize("grid,periodic", [((1, 1, 1), (1, 1, 1)), ((2, 1, 1), (1, 0, 0)), ((2, 2, 1), (1, 1, 0)), ((2, 2, 2), (1, 1, 1))])
+def test_static_forces_and_plan_match_single_domain(grid, periodic):
+    import torch
+    from shpair import shapes, mrank
+    from shpair.run import DeviceRun
+    import halo_host
+    world = int(np.prod(grid))
+    lmax, nq, skin = 4, 8, 0.2
+    shp = [shapes.random_shape(lmax, 400 + s, amp=0.2) for s in range(2)]
+    x, quat, sht, tag, lo, hi, _ = _bed(3000, periodic)
+    n = x.shape[0]
+    sp0 = _ctx(lmax, shp, nq)
+    cut = 2.0 * max(sp0.rmax(s) for s in range(2)) + skin
+    xw, owner = _distribute(grid, lo, hi, periodic, cut, x)
+    hub = mrank.Hub(world) if world > 1 else None
+    ty = np.ones(n, dtype=np.int32)
+
+    def body(rank):
+        sp = _ctx(lmax, shp, nq)
+        halo = mrank.Halo(sp, rank, world, grid, lo, hi, periodic, skin, hub=hub)
+        mine = owner == rank
+        run = mrank.RankRun(sp, halo, xw[mine], quat[mine], sht[mine], tag[mine], dt=0.0)
+        st = halo.stats()
+        t, _, _, _, f, tq = run.owned()
+        # the device plan against the host planner, row for row
+        hr = halo_host.HostRank(rank, grid, lo, hi, periodic, cut, x, quat, ty, sht, tag)
+        ghosts = (run.tag[run.n:run.n + run.nghost].cpu().numpy(), run.x[run.n:run.n + run.nghost].cpu().numpy())
+        res = dict(tag=t, f=f, tq=tq, nghost=run.nghost, npairs=run.npairs, stats=st, ghosts=ghosts, hr=hr, n=run.n)
+        halo.close()
+        sp.close()
+        return res
+    parts = _run_ranks(world, body)
+    # host planner: counts exchanged in-process
+    for r, p in enumerate(parts):
+        hr = p["hr"]
+        inbox = {q: parts[q]["hr"].count_message(r) for q in range(world) if q != r}
+        hr.set_counts(inbox)
+        assert hr.n == p["n"] and hr.nghost == p["nghost"] and p["stats"]["npeers"] == hr.lay.npeers
+        assert p["stats"]["nsend_rows"] == hr.lay.nsend
+    # ghost rows (tag, x) in the planner's order: rebuild them from the host send lists
+    for r, p in enumerate(parts):
+        hr = p["hr"]
+        exp_tag = np.zeros(hr.nghost, dtype=np.int64)
+        exp_x = np.zeros((hr.nghost, 3))
+        for c in range(27):
+            q = hr.geo.peer[c]
+            if c == 13 or q < 0:
+                continue
+            src = parts[q]["hr"]
+            rows = src.send_list[26 - c]
+            sh = np.array([src.geo.shift[26 - c][d] for d in range(3)])
+            a = hr.lay.recv_off[c]
+            exp_tag[a:a + rows.size] = src.tag[rows]
+            exp_x[a:a + rows.size] = src.x[rows] + sh
+        assert np.array_equal(p["ghosts"][0], exp_tag)
+        assert np.abs(p["ghosts"][1] - exp_x).max() < 1e-13
+    # forces against the single-domain HIP path on the same periodic box
+    ref = DeviceRun(sp0, x, quat, sht, lo, hi, periodic, skin, dt=0.0)
+    torch.cuda.synchronize()
+    fr, tr = ref.f[:n].cpu().numpy(), ref.tq[:n].cpu().numpy()
+    f, tq, seen = np.zeros_like(fr), np.zeros_like(tr), np.zeros(n, int)
+    for p in parts:
+        f[p["tag"]] = p["f"]
+        tq[p["tag"]] = p["tq"]
+        seen[p["tag"]] += 1
+    assert np.all(seen == 1)
+    assert sum(p["npairs"] for p in parts) == ref.npairs
+    fs = np.abs(fr).max()
+    assert fs > 0 and np.abs(f - fr).max() < 1e-12 * fs and np.abs(tq - tr).max() < 1e-12 * fs
+    sp0.close()
+    if hub:
+        hub.close()
+
+
+@pytest.mark.parametrize("grid,periodic", [((2, 1, 1), (1, 1, 1)), ((2, 2, 1), (1, 1, 0)), ((1, 1, 1), (1, 1, 1)), ((2, 2, 2), (1, 1, 0))])
+def test_dynamic_run_matches_single_rank(grid, periodic):
+    """Atoms move fast enough to change owner; the C++ loop of every rank (exchange, borders, rebuilds, forward,
+    reverse) must reproduce the single-rank loop's trajectory."""
+    import torch
+    from shpair import shapes, mrank
+    from shpair.run import DeviceRun
+    world = int(np.prod(grid))
+    lmax, nq, skin, dt, nsteps = 4, 8, 0.2, 2e-3, 120
+    shp = [shapes.random_shape(lmax, 400 + s, amp=0.2) for s in range(2)]
+    x, quat, sht, tag, lo, hi, rng = _bed(1500 if world < 8 else 4000, periodic)
+    n = x.shape[0]
+    v0 = 2.0 * rng.normal(size=(n, 3))
+    mask = np.where(tag % 11 == 0, 2, 1).astype(np.int32)   # every 11th particle is frozen (another group)
+    v0[mask == 2] = 0.0
+    grav = (0.0, 0.0, -0.5 if not periodic[2] else 0.0)
+    sp0 = _ctx(lmax, shp, nq)
+    cut = 2.0 * max(sp0.rmax(s) for s in range(2)) + skin
+    xw, owner = _distribute(grid, lo, hi, periodic, cut, x)
+    hub = mrank.Hub(world) if world > 1 else None
+
+    def body(rank):
+        sp = _ctx(lmax, shp, nq)
+        halo = mrank.Halo(sp, rank, world, grid, lo, hi, periodic, skin, hub=hub)
+        mine = owner == rank
+        run = mrank.RankRun(sp, halo, xw[mine], quat[mine], sht[mine], tag[mine], v=v0[mine], mask=mask[mine], dt=dt, gravity=grav,
+                            gamma_t=0.05, gamma_r=0.02)
+        n0 = run.n
+        run.run(nsteps)
+        t, X, V, Q, _, _ = run.owned()
+        st = halo.stats()
+        res = dict(tag=t, x=X, v=V, q=Q, builds=run.builds, n0=n0, n1=run.n, nghost=run.nghost, stats=st)
+        halo.close()
+        sp.close()
+        return res
+    parts = _run_ranks(world, body)
+    tg = np.concatenate([p["tag"] for p in parts])
+    o = np.argsort(tg)
+    assert np.array_equal(tg[o], np.arange(n)), "atoms lost or duplicated"
+    X = np.concatenate([p["x"] for p in parts])[o]
+    V = np.concatenate([p["v"] for p in parts])[o]
+    Q = np.concatenate([p["q"] for p in parts])[o]
+    ref = DeviceRun(sp0, x, quat, sht, lo, hi, periodic, skin, mask=mask, dt=dt, gravity=grav, gamma_t=0.05, gamma_r=0.02)
+    ref.v[:] = torch.from_numpy(v0).to(ref.v.device)
+    ref.force()
+    ref.run(nsteps)
+    torch.cuda.synchronize()
+    xr, vr, qr = ref.x[:n].cpu().numpy(), ref.v.cpu().numpy(), ref.q[:n].cpu().numpy()
+    dx = X - xr
+    for d in range(3):
+        if periodic[d]:
+            dx[:, d] -= (hi[d] - lo[d]) * np.round(dx[:, d] / (hi[d] - lo[d]))
+    assert np.abs(dx).max() < 1e-7 and np.abs(V - vr).max() < 1e-6 * np.abs(vr).max()
+    assert np.abs(np.abs((Q * qr).sum(1)) - 1).max() < 1e-9
+    builds = [p["builds"] for p in parts]
+    assert min(builds) >= 3 and len(set(builds)) == 1                 # every rank rebuilt, and together
+    if world > 1:
+        assert sum(p["stats"]["migrated_out"] for p in parts) > 0      # atoms changed owner
+        assert sum(p["stats"]["migrated_out"] for p in parts) == sum(p["stats"]["migrated_in"] for p in parts)
+        assert min(p["nghost"] for p in parts) > 0
+    sp0.close()
+    if hub:
+        hub.close()
+
+
+def test_config4_one_million_particles_eight_ranks():
+    """BASELINE configs[3] as a rehearsal: 1 M particles, L_max = 6, 2x2x2 bricks, periodic in x and y, gravity;
+    eight rank threads on the one GPU.  A few steps of the C++ loop, then: no atom lost, the forces of a sample of
+    rows equal the single-domain HIP forces, and contact forces sum to zero."""
+    import torch
+    from shpair import shapes, bed, mrank, ShPair
+    from shpair.run import DeviceRun
+    grid, periodic, world = (2, 2, 2), (1, 1, 0), 8
+    lmax, nq, skin = 6, 16, 0.1
+    shp = [shapes.random_shape(lmax, bed.SEED0 + 2)]
+    x, quat, sht, tag, lo, hi, _ = _bed(1000000, periodic, nshapes=1, jitter=0.04, seed=bed.SEED0 + 7)
+    n = x.shape[0]
+    assert n > 950000
+    sp0 = _ctx(lmax, shp, nq, kn=1000.0)
+    cut = 2.0 * sp0.rmax(0) + skin
+    xw, owner = _distribute(grid, lo, hi, periodic, cut, x)
+    hub = mrank.Hub(world)
+
+    def body(rank):
+        sp = _ctx(lmax, shp, nq, kn=1000.0)
+        halo = mrank.Halo(sp, rank, world, grid, lo, hi, periodic, skin, hub=hub)
+        mine = owner == rank
+        run = mrank.RankRun(sp, halo, xw[mine], quat[mine], sht[mine], tag[mine], dt=1e-3, gravity=(0.0, 0.0, -1.0),
+                            capacity=int(1.6 * mine.sum()) + 1024)
+        st0 = halo.stats()
+        t0, _, _, _, f0, tq0 = run.owned()           # static forces (contacts + gravity) of the initial bed
+        run.run(4)
+        t1 = run.owned()[0]
+        res = dict(tag0=t0, f0=f0, tq0=tq0, tag1=t1, n=run.n, nghost=run.nghost, npairs=run.npairs, stats=st0)
+        halo.close()
+        sp.close()
+        return res
+    parts = _run_ranks(world, body)
+    tg = np.sort(np.concatenate([p["tag1"] for p in parts]))
+    assert np.array_equal(tg, np.arange(n)), "atoms lost or duplicated"
+    assert all(p["stats"]["npeers"] >= 3 for p in parts) and all(p["nghost"] > 10000 for p in parts)
+    # single-domain HIP forces of the same bed
+    ref = DeviceRun(sp0, x, quat, sht, lo, hi, periodic, skin, dt=1e-3, gravity=(0.0, 0.0, -1.0))
+    torch.cuda.synchronize()
+    fr, tr = ref.f[:n].cpu().numpy(), ref.tq[:n].cpu().numpy()
+    assert sum(p["npairs"] for p in parts) == ref.npairs
+    f = np.zeros_like(fr)
+    tq = np.zeros_like(tr)
+    for p in parts:
+        f[p["tag0"]] = p["f0"]
+        tq[p["tag0"]] = p["tq0"]
+    fs = np.abs(fr).max()
+    rows = np.random.default_rng(1).choice(n, 20000, replace=False)
+    assert np.abs(f[rows] - fr[rows]).max() < 1e-12 * fs and np.abs(tq[rows] - tr[rows]).max() < 1e-12 * fs
+    # contact forces cancel pairwise: what is left of the sum is gravity (m g per particle)
+    m = sp0.body(0)[0]
+    tot = f.sum(axis=0)
+    assert abs(tot[0]) < 1e-8 * fs * np.sqrt(n) and abs(tot[1]) < 1e-8 * fs * np.sqrt(n)
+    assert abs(tot[2] + m * n) < 1e-9 * m * n + 1e-8 * fs * np.sqrt(n)
+    sp0.close()
+    hub.close()
+
+
+def test_rccl_self_communicator_through_the_c_abi():
+    """RCCL itself (ncclCommInitRank, grouped ncclSend/ncclRecv, ncclAllReduce) behind shhalo_create_rccl: one rank,
+    which is all a one-GPU box can hold (RCCL refuses two ranks on one device).  Periodic box: every direction leads
+    back to the rank, so the exchange is local copies; the all-reduce and the rebuild decision go through RCCL."""
+    import torch
+    from shpair import shapes, mrank
+    from shpair.run import DeviceRun
+    lmax, nq, skin = 4, 8, 0.2
+    shp = [shapes.random_shape(lmax, 400 + s, amp=0.2) for s in range(2)]
+    periodic = (1, 1, 1)
+    x, quat, sht, tag, lo, hi, _ = _bed(1500, periodic)
+    n = x.shape[0]
+    sp = _ctx(lmax, shp, nq)
+    uid = mrank.unique_id()
+    assert len(uid) == 128
+    halo = mrank.Halo(sp, 0, 1, (1, 1, 1), lo, hi, periodic, skin, unique_id_bytes=uid)
+    st = halo.stats()
+    assert st["transport"] == 1 and st["nranks_transport"] == 1 and st["rccl_version"] > 20000
+    run = mrank.RankRun(sp, halo, x, quat, sht, tag, dt=1e-3)
+    run.run(20)
+    e = torch.tensor([1.5, 2.5, -4.0], dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()
+    halo.allreduce_sum(e.data_ptr(), 3, run.stream)
+    sp.synchronize()
+    assert e.cpu().tolist() == [1.5, 2.5, -4.0]
+    sp1 = _ctx(lmax, shp, nq)
+    ref = DeviceRun(sp1, x, quat, sht, lo, hi, periodic, skin, dt=1e-3)
+    ref.run(20)
+    torch.cuda.synchronize()
+    t, X, V, Q, _, _ = run.owned()
+    dx = X - ref.x[:n].cpu().numpy()
+    for d in range(3):
+        dx[:, d] -= (hi[d] - lo[d]) * np.round(dx[:, d] / (hi[d] - lo[d]))
+    assert np.abs(dx).max() < 1e-9
+    halo.close()
+    sp.close()
+    sp1.close()

@@ -1,17 +1,107 @@
-"""N>1 path on CPU: world_size-2 and -4 `gloo` runs of the domain decomposition and
-halo exchange, with the oracle standing in for the GPU compute (tests may call the
-oracle; the product path never does).  The decomposed result must equal the
-single-domain result atom for atom."""
+"""N > 1 path on CPU (no GPU): the library's pure host planner (include/shhalo.h: shhalo_plan_geometry / owner /
+ghost_mask / layout — the same geometry and layout code, and the same per-row decisions, the device path runs)
+drives a decomposed evaluation of a periodic bed at world sizes 1, 2, 4, 8 (2x2x2 included), with the oracle
+standing in for the pair kernel.  Transport: an in-process mailbox between rank threads, and real `gloo`
+point-to-point between processes at world 2 and 8.  The decomposed forces must equal the single-domain forces atom
+for atom, every pair must be evaluated exactly once, and no ghost row may be left unwritten."""
 import os
+import queue
 import socket
 import sys
+import threading
 
 import numpy as np
 import pytest
 
-from common import make_case, coeff_tables, oracle_compute
+from shpair import bed, mrank, shapes as shp_mod
+
+import halo_host
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _case(O, periodic, n_target=260, seed=5):
+    lmax, nq, skin = 4, 8, 0.15
+    sh = [shp_mod.random_shape(lmax, 300 + s, amp=0.2) for s in range(2)]
+    shapes = [(lmax, a, O.shape_rmax(lmax, a)) for a in sh]
+    pts, lo, hi = bed.periodic_hcp(n_target, 1.9, periodic)
+    rng = np.random.default_rng(seed)
+    n = pts.shape[0]
+    x = pts + rng.uniform(-0.12, 0.12, pts.shape)
+    # a few rows start outside the box: the planner wraps them (Domain::pbc)
+    for d in range(3):
+        if periodic[d]:
+            x[::17, d] += (hi[d] - lo[d])
+    quat = bed.random_quaternions(n, rng)
+    sht = rng.integers(0, 2, n).astype(np.int32)
+    ty = np.ones(n, dtype=np.int32)
+    tag = np.arange(n, dtype=np.int32)
+    cut = 2.0 * max(s[2] for s in shapes) + skin
+    K = np.full((2, 2), 700.0)
+    E = np.full((2, 2), 1.25)
+    return dict(shapes=shapes, nq=nq, skin=skin, lo=lo, hi=hi, periodic=periodic, cut=cut, x=x, quat=quat, ty=ty, sht=sht,
+                tag=tag, K=K, E=E, n=n)
+
+
+def _rank_body(O, c, grid, rank, exchange):
+    hr = halo_host.HostRank(rank, grid, c["lo"], c["hi"], c["periodic"], c["cut"], c["x"], c["quat"], c["ty"], c["sht"], c["tag"])
+    remote = sorted({hr.geo.peer[k] for k in range(27) if k != 13 and hr.geo.peer[k] >= 0 and hr.geo.peer[k] != rank})
+    inbox = {p: np.zeros(27, dtype=np.int64) for p in remote}
+    exchange([(p, hr.count_message(p)) for p in remote], [(p, inbox[p]) for p in remote])
+    hr.set_counts(inbox)
+    f, tq, e, npairs = halo_host.run_rank(hr, O, c["shapes"], c["K"], c["E"], c["nq"], c["skin"], exchange)
+    return dict(tag=hr.tag, f=f, tq=tq, e=e, npairs=npairs, nghost=hr.nghost, npeers=hr.lay.npeers)
+
+
+def _check(c, O, parts):
+    fr, tr, er, npr = halo_host.single_domain_reference(O, c["shapes"], c["K"], c["E"], c["nq"], c["skin"], c["lo"], c["hi"],
+                                                        c["periodic"], c["cut"], c["x"], c["quat"], c["ty"], c["sht"], c["tag"])
+    f = np.zeros_like(fr)
+    tq = np.zeros_like(tr)
+    seen = np.zeros(c["n"], dtype=int)
+    for p in parts:
+        f[p["tag"]] = p["f"]
+        tq[p["tag"]] = p["tq"]
+        seen[p["tag"]] += 1
+    assert np.all(seen == 1), "an atom is owned by no rank or by two"
+    assert sum(p["npairs"] for p in parts) == npr and npr > 0      # every pair evaluated exactly once
+    assert abs(sum(p["e"] for p in parts) - er) < 1e-11 * abs(er)
+    fs = np.abs(fr).max()
+    assert fs > 0
+    assert np.abs(f - fr).max() < 1e-12 * fs and np.abs(tq - tr).max() < 1e-12 * fs
+
+
+@pytest.mark.parametrize("grid,periodic", [((1, 1, 1), (1, 1, 1)), ((2, 1, 1), (1, 0, 0)), ((2, 1, 1), (1, 1, 1)), ((2, 2, 1), (1, 1, 0)),
+                                           ((2, 2, 2), (1, 1, 0)), ((2, 2, 2), (1, 1, 1)), ((3, 1, 1), (1, 1, 0)),
+                                           ((4, 2, 1), (0, 1, 1))])
+def test_decomposed_forces_equal_single_domain_threads(oracle, grid, periodic):
+    world = int(np.prod(grid))
+    c = _case(oracle, periodic, n_target=700 if max(grid) > 2 else 260)
+    boxes = {(a, b): queue.Queue() for a in range(world) for b in range(world)}
+    parts, errs = [None] * world, []
+
+    def work(rank):
+        def exchange(sends, recvs):
+            for p, a in sends:
+                boxes[(rank, p)].put(np.array(a, copy=True))
+            for p, out in recvs:
+                got = boxes[(p, rank)].get(timeout=120)
+                assert got.shape == out.shape, (got.shape, out.shape)
+                out[...] = got
+        try:
+            parts[rank] = _rank_body(oracle, c, grid, rank, exchange)
+        except BaseException as e:  # noqa: BLE001 - reported below
+            errs.append((rank, repr(e)))
+    th = [threading.Thread(target=work, args=(r,)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errs, errs
+    if world == 8:
+        assert all(p["npeers"] == 7 or periodic != (1, 1, 1) for p in parts)   # 2x2x2 periodic: 7 distinct peers each
+    assert all(p["nghost"] > 0 for p in parts)
+    _check(c, oracle, parts)
 
 
 def _free_port():
@@ -20,72 +110,62 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, grid, out_dir):
+def _gloo_worker(rank, world, port, grid, periodic, out_dir):
     for p in (os.path.join(ROOT, "lammps-spherharm_amd"), ROOT, os.path.join(ROOT, "tests")):
         if p not in sys.path:
             sys.path.insert(0, p)
     import torch
     import torch.distributed as dist
     from oracle import oracle as O
-    from shpair.halo import Decomposition, HaloExchange
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        case = make_case(400, 4, 2, seed=21, rmax_fn=O.shape_rmax)
-        K, E = coeff_tables(1, 1000.0, 1.25)
-        b = case["bed"]
-        dec = Decomposition(b["x"], b["shtype"], case["rmax"], grid)
-        view = dec.plan(rank)
-        gid, nlocal = view["gid"], view["nlocal"]
-        il, of, jl = dec.neighbor_list(view, balanced=(world == 4))   # world 4 also covers rows whose i is a ghost
-        halo = HaloExchange(view, torch.device("cpu"), dist)
-        # owners hold the truth; ghosts start as garbage and must be filled by forward()
-        x = torch.from_numpy(b["x"][gid].copy())
-        q = torch.from_numpy(b["quat"][gid].copy())
-        x[nlocal:] = 1e9
-        q[nlocal:] = 0.0
-        halo.forward(x, q)
-        assert torch.equal(x, torch.from_numpy(b["x"][gid])) and torch.equal(q, torch.from_numpy(b["quat"][gid]))
-        o = O.compute([(case["lmax"], a, r) for a, r in zip(case["shapes"], case["rmax"])], K, E, 8, nlocal,
-                      x.numpy(), q.numpy(), b["type"][gid], b["shtype"][gid], il, of, jl, newton_pair=True,
-                      eflag=True)
-        f = torch.from_numpy(o["f"].copy())
-        tq = torch.from_numpy(o["torque"].copy())
-        halo.reverse(f, tq)
-        e = torch.tensor([o["eng_virial"][0], float(o["counts"][0])], dtype=torch.float64)
-        dist.all_reduce(e)
-        np.savez(os.path.join(out_dir, f"r{rank}.npz"), gid=gid[:nlocal], f=f.numpy()[:nlocal],
-                 tq=tq.numpy()[:nlocal], e=e.numpy(), nghost=gid.size - nlocal)
+        c = _case(O, periodic)
+
+        def exchange(sends, recvs):
+            ops, keep = [], []
+            for p, out in recvs:          # same peer order on both sides; one message per peer and direction of travel
+                t = torch.empty(out.shape, dtype=torch.from_numpy(np.zeros(1, out.dtype)).dtype)
+                keep.append((t, out))
+                ops.append(dist.P2POp(dist.irecv, t, p))
+            for p, a in sends:
+                ops.append(dist.P2POp(dist.isend, torch.from_numpy(np.ascontiguousarray(a)).clone(), p))
+            if ops:
+                for w in dist.batch_isend_irecv(ops):
+                    w.wait()
+            for t, out in keep:
+                out[...] = t.numpy()
+        r = _rank_body(O, c, grid, rank, exchange)
+        np.savez(os.path.join(out_dir, f"r{rank}.npz"), **r)
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,grid", [(2, (2, 1, 1)), (4, (2, 2, 1))])
-def test_decomposed_forces_equal_single_domain(oracle, tmp_path, world, grid):
+@pytest.mark.parametrize("grid,periodic", [((2, 1, 1), (1, 1, 0)), ((2, 2, 2), (1, 1, 0))])
+def test_decomposed_forces_equal_single_domain_gloo(oracle, tmp_path, grid, periodic):
     import torch.multiprocessing as mp
-    port = _free_port()
-    mp.spawn(_worker, args=(world, port, grid, str(tmp_path)), nprocs=world, join=True)
-    case = make_case(400, 4, 2, seed=21, rmax_fn=oracle.shape_rmax)
-    K, E = coeff_tables(1, 1000.0, 1.25)
-    ref = oracle_compute(oracle, case, 8, K, E, eflag=True)
-    f = np.zeros_like(ref["f"])
-    tq = np.zeros_like(ref["torque"])
-    seen = np.zeros(case["n"], dtype=int)
-    for r in range(world):
-        d = np.load(tmp_path / f"r{r}.npz")
-        f[d["gid"]] = d["f"]
-        tq[d["gid"]] = d["tq"]
-        seen[d["gid"]] += 1
-        assert d["nghost"] > 0
-        assert abs(d["e"][0] - ref["eng_virial"][0]) < 1e-11 * ref["eng_virial"][0]
-        assert int(d["e"][1]) == ref["counts"][0]  # every global pair evaluated exactly once
-    assert np.all(seen == 1)
-    fs = np.abs(ref["f"]).max()
-    assert np.abs(f - ref["f"]).max() < 1e-12 * fs and np.abs(tq - ref["torque"]).max() < 1e-12 * fs
+    world = int(np.prod(grid))
+    mp.spawn(_gloo_worker, args=(world, _free_port(), grid, periodic, str(tmp_path)), nprocs=world, join=True)
+    c = _case(oracle, periodic)
+    parts = [dict(np.load(tmp_path / f"r{r}.npz")) for r in range(world)]
+    _check(c, oracle, parts)
 
 
-def test_proc_grid():
-    from shpair.halo import proc_grid
-    assert proc_grid(1) == (1, 1, 1) and proc_grid(2) == (2, 1, 1) and proc_grid(4) == (2, 2, 1)
-    assert proc_grid(8) == (2, 2, 2) and proc_grid(6) == (3, 2, 1)
+def test_proc_grid_and_geometry():
+    assert mrank.proc_grid(1) == (1, 1, 1) and mrank.proc_grid(2) == (2, 1, 1) and mrank.proc_grid(4) == (2, 2, 1)
+    assert mrank.proc_grid(8) == (2, 2, 2) and mrank.proc_grid(6) == (3, 2, 1)
+    g = mrank.plan_geometry((2, 2, 2), (0, 0, 0), (10, 10, 10), (1, 1, 0), 2.0, 5)
+    assert tuple(g.coord) == (1, 0, 1) and tuple(g.blo) == (5.0, 0.0, 5.0)
+    peers = {g.peer[c] for c in range(27) if c != 13 and g.peer[c] >= 0}
+    assert peers == {0, 1, 2, 3, 4, 6, 7}                       # 7 distinct peers: one per xGMI link of the node
+    assert g.peer[13 + 9] == -1 and g.peer[13 - 9] == 4          # open in z: nothing above the top brick
+    assert g.shift[14][0] == -10.0 and g.shift[12][0] == 0.0      # +x from the upper brick crosses the periodic face
+    # a brick shorter than the ghost cutoff is refused
+    with pytest.raises(Exception):
+        mrank.plan_geometry((4, 1, 1), (0, 0, 0), (10, 10, 10), (1, 1, 1), 3.0, 0)
+    # ownership: wrapped, clamped at open boundaries
+    x = np.array([[10.5, 0.1, -3.0], [4.999, 9.9, 25.0]])
+    xw, own = mrank.plan_owner(g, x)
+    assert np.allclose(xw, [[0.5, 0.1, -3.0], [4.999, 9.9, 25.0]]) and list(own) == [0, 3]
