@@ -4,21 +4,26 @@
   python bench.py --gpus N --steps K --warmup W
   (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
-A "step" is one pass of the hot path over one synthetic bed resident in HBM,
-inside the two integrator half-steps that surround it in a timestep:
-initial_integrate -> [forward halo exchange, N > 1] -> clear f/torque ->
-shpair_compute_device() -> [reverse halo exchange, N > 1] -> final_integrate.  Workload at N = 1: BASELINE.json
-configs[1] — 100k particles, one L_max = 6 shape, dense packed bed, n_q = 16
-(Q = 512 cap nodes per pair), general force law (exponent 1.25, so the overlap
-volume root finder runs for every touching node).  N > 1: the same bed per
-rank (weak scaling), bricks of the processor grid, RCCL point-to-point halo.
+N = 1 — BASELINE.json configs[1]: 100k particles, one L_max = 6 shape, dense packed bed resident in HBM, n_q = 16
+(Q = 512 cap nodes per pair), general force law (exponent 1.25: the overlap-volume root finder runs for every
+touching node).  A "step" is one pass of the hot path inside the two integrator half-steps that surround it in a
+timestep: initial_integrate -> clear f/torque -> shpair_compute_device() -> final_integrate.
 
-Prints ONE JSON line on rank 0 (fields: module docstring of DESIGN.md §Measurement).
+N > 1 — BASELINE.json configs[3]: 125k particles per GPU (1 M at N = 8) of the same shape in a box periodic in x
+and y on a frozen floor, gravity, bricks of the processor grid, one rank and one shpair context per GPU.  A step is a
+whole timestep of the C++ loop over all ranks (shhalo_run_device, include/shhalo.h): initial_integrate -> rebuild
+test over all ranks [-> atom migration, ghost plan, list build] -> forward halo -> clear -> pair compute -> reverse
+halo -> gravity -> final_integrate; every byte between GPUs travels as ncclSend/ncclRecv issued by libshpair.so
+(RCCL over xGMI).  torch.distributed (gloo) only hands out the ncclUniqueId and reduces the timings.
+`--transport local` rehearses the same N ranks as threads of one process on one GPU (tests).
+
+Prints ONE JSON line on rank 0 (fields: DESIGN.md §7).
 """
 import argparse
 import json
 import os
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -29,7 +34,8 @@ import numpy as np  # noqa: E402
 
 BYTES_PER_PAIR = 236          # algorithmic HBM bytes per contact pair
 HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-F64_VALU_PEAK_TFLOPS = 78.6   # 256 CU x 4 SIMD x 16 lanes/clk x 2 flop x 2.4 GHz (= half the FP32 vector peak)
+F64_VALU_PEAK_TFLOPS = 78.6   # spec: 256 CU x 4 SIMD x 16 lanes/clk x 2 flop x 2.4 GHz; the box's own v_fma_f64 rate
+                              # is measured at run time (shpair_fp64_peak) and printed beside it
 
 
 def flops_per_pair(lmax, nq):
@@ -39,13 +45,18 @@ def flops_per_pair(lmax, nq):
 
 
 def pmc_traffic(args):
-    """HBM traffic per launch measured with rocprofv3 PMC passes for this exact workload, or None."""
+    """(bytes per launch, source) of the HBM-side traffic measured with rocprofv3 PMC passes for this exact workload
+    and kernel variant, or (None, reason).  A static table: counters cannot be read from inside the timed run."""
+    path = os.path.join("profiles", "pmc_traffic.json")
+    key = f"{args.particles}:{args.lmax}:{args.nq}:{args.nshapes}:{args.exponent:g}:{args.rule}"
     try:
-        tab = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-        key = f"{args.particles}:{args.lmax}:{args.nq}:{args.nshapes}:{args.exponent:g}"
-        return tab[key]["traffic_bytes"] if key in tab else None
-    except (OSError, ValueError, KeyError):
-        return None
+        tab = json.load(open(os.path.join(ROOT, path)))
+    except (OSError, ValueError):
+        return None, f"{path} unreadable"
+    if key not in tab:
+        return None, f"no PMC measurement of workload {key} in {path}"
+    e = tab[key]
+    return e["traffic_bytes"], f"{path}[{key}] (static; rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, {e.get('files', '')})"
 
 
 def parse():
@@ -53,121 +64,121 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--particles", type=int, default=100000, help="particles per GPU")
+    ap.add_argument("--particles", type=int, default=0, help="particles per GPU (default: 100000 at N = 1, 125000 at N > 1)")
     ap.add_argument("--lmax", type=int, default=6)
     ap.add_argument("--nq", type=int, default=16)
     ap.add_argument("--nshapes", type=int, default=1)
     ap.add_argument("--exponent", type=float, default=1.25)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg (0 = skip)")
-    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
-                    help="nccl = RCCL over xGMI (the product path). gloo = rehearsal only: every rank uses "
-                         "GPU 0 and the halo buffers are staged through the host")
+    ap.add_argument("--transport", default="rccl", choices=["rccl", "local"],
+                    help="N > 1: rccl = one process per GPU, ncclSend/ncclRecv over xGMI (the product path); local = "
+                         "rehearsal: the N ranks are threads of this one process on GPU 0 (no torch.distributed.run)")
     ap.add_argument("--verify", action="store_true",
-                    help="N > 1: gather the owned forces and compare them with a single-domain compute of the "
-                         "whole bed on rank 0 (small beds only)")
+                    help="N > 1 with --transport local: compare the decomposed forces with a single-domain compute")
     ap.add_argument("--ramp", type=int, default=8, help="extra untimed passes before the W warm-up steps: the first "
                     "~8 launches of a fresh process run up to 25 %% slower while the GPU clock ramps (rocprof per-launch "
                     "durations in profiles/); they are never part of the K timed steps")
     ap.add_argument("--rule", default="sharp", choices=["sharp", "weighted"],
                     help="cap rule: sharp inside test (docs/SPEC.md §2.5, the headline) or covered-fraction weights (§2.8)")
     ap.add_argument("--ts-steps", type=int, default=40, help="steps of the whole-timestep leg (N = 1 only; 0 = skip)")
-    ap.add_argument("--multi-ts-steps", type=int, default=0,
-                    help="N > 1 only, off by default: whole timesteps with atom migration and rebuilds through "
-                         "shpair.mrun.MultiRankRun on a periodic bed of `particles` per rank (weak scaling)")
     ap.add_argument("--cpu-threads", type=int, default=16, help="OpenMP threads of the cpu_baseline leg "
                     "(16 = the host-core share of one GPU on the bench box)")
-    return ap.parse_args()
+    ap.add_argument("--peak-ms", type=float, default=20.0, help="length of the v_fma_f64 peak measurement (0 = skip)")
+    ap.add_argument("--vthermal", type=float, default=0.5, help="N > 1: initial velocity scale of the bed")
+    a = ap.parse_args()
+    if a.particles <= 0:
+        a.particles = 100000 if a.gpus == 1 else 125000
+    return a
 
 
-def main():
-    args = parse()
+def make_ctx(args, shp, device):
+    from shpair import ShPair
+    sp = ShPair(device)
+    sp.settings(args.nq)
+    sp.set_ntypes(1, args.nshapes)
+    for s, a in enumerate(shp):
+        sp.set_shape(s, args.lmax, a)
+    sp.coeff("*", "*", 1000.0, args.exponent)
+    sp.set_option("rule", 1 if args.rule == "weighted" else 0)
+    return sp
+
+
+def roofline_objects(args, sp, n_contact, kernel_ms, world):
+    fpp = flops_per_pair(args.lmax, args.nq)
+    achieved_gbs = BYTES_PER_PAIR * n_contact / (kernel_ms * 1e-3) / 1e9
+    achieved_tf = fpp * n_contact / (kernel_ms * 1e-3) / 1e12
+    traffic, src = pmc_traffic(args) if world == 1 else (None, "N > 1: not measured")
+    peak_meas = None
+    if args.peak_ms > 0:
+        peak_meas = sp.fp64_peak(0, args.peak_ms)[0]
+    roof = {
+        "bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved_gbs / HBM_PEAK_GBS,
+        "traffic": traffic, "traffic_source": src,
+        "kernel": "pair_contact_kernel", "kernel_ms": kernel_ms, "bytes_per_pair": BYTES_PER_PAIR,
+        "pairs_per_launch": int(n_contact), "algorithmic_bytes_per_launch": BYTES_PER_PAIR * int(n_contact),
+        "note": "north_star asks for the HBM fraction; the kernel is FP64-VALU bound (see valu_f64)",
+    }
+    valu = {
+        "bound": "valu_f64", "achieved": achieved_tf, "peak": F64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+        "frac": achieved_tf / F64_VALU_PEAK_TFLOPS, "peak_measured": peak_meas,
+        "frac_of_measured": (achieved_tf / peak_meas) if peak_meas else None, "flop_per_pair": fpp,
+        "note": "algorithmic FLOP (SURVEY §8d formula) / kernel time. peak = spec; peak_measured = independent v_fma_f64 "
+                "chains on every SIMD of this box, run beside the bench (shpair_fp64_peak). No MFMA: measured on MI355X, "
+                "v_mfma_f64 and v_fma_f64 share one FP64 datapath (side by side they add up to the single-pipe rate, "
+                "profiles/r02_a_fp64_peak.json)",
+    }
+    occ = dict(sp.kernel_info(), note="static footprint of pair_contact_kernel as launched: one wave = one pair = one "
+               "workgroup; waves_per_cu = min(4 x VGPR limit, LDS limit) of a gfx950 CU")
+    return roof, valu, occ
+
+
+# ======================================================================================================== N = 1
+def main_single(args):
     import torch
-    from shpair import ShPair, shapes, bed
-    from shpair.halo import Decomposition, HaloExchange, proc_grid
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if rank == 0:
-            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run",
-                  file=sys.stderr)
-        sys.exit(2)
+    from shpair import shapes, bed
     if not torch.cuda.is_available():
         print("bench.py: no GPU visible; the HIP path has no CPU fallback", file=sys.stderr)
         sys.exit(3)
-    rehearsal = args.backend == "gloo"
-    if rehearsal:
-        local_rank = 0
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if rehearsal:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
-        else:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
     lmax, nq, nshapes = args.lmax, args.nq, args.nshapes
     shp = [shapes.random_shape(lmax, bed.SEED0 + 2 + s) for s in range(nshapes)]
-    sp = ShPair(local_rank)
-    sp.settings(nq)
-    sp.set_ntypes(1, nshapes)
-    for s, a in enumerate(shp):
-        sp.set_shape(s, lmax, a)
-    sp.coeff("*", "*", 1000.0, args.exponent)
-    sp.set_option("rule", 1 if args.rule == "weighted" else 0)
+    sp = make_ctx(args, shp, 0)
     rmax = [sp.rmax(s) for s in range(nshapes)]
-
-    # ---- the bed: world x particles, bricks of the processor grid (weak scaling)
-    grid = proc_grid(world)
-    gbed = bed.make_bed(args.particles * world, rmax, nshapes, seed=bed.SEED0 + 2,
-                        aspect=tuple(float(g) for g in grid))
-    halo = None
-    if world == 1:
-        gid = np.arange(args.particles)
-        nlocal = args.particles
-        il, of, jl = bed.half_neighbor_list(gbed["x"], gbed["shtype"], rmax)
-    else:
-        dec = Decomposition(gbed["x"], gbed["shtype"], rmax, grid)
-        view = dec.plan(rank)
-        gid, nlocal = view["gid"], view["nlocal"]
-        il, of, jl = dec.neighbor_list(view)
-        halo = HaloExchange(view, dev, dist, host_staged=rehearsal)
-    nall = gid.size
+    gbed = bed.make_bed(args.particles, rmax, nshapes, seed=bed.SEED0 + 2)
+    nlocal = nall = args.particles
+    il, of, jl = bed.half_neighbor_list(gbed["x"], gbed["shtype"], rmax)
     sp.set_neighbors_csr(il, of, jl)
 
-    x = torch.from_numpy(gbed["x"][gid]).to(dev)
-    q = torch.from_numpy(gbed["quat"][gid]).to(dev)
-    ty = torch.from_numpy(gbed["type"][gid]).to(dev)
-    sh = torch.from_numpy(gbed["shtype"][gid]).to(dev)
+    x = torch.from_numpy(gbed["x"]).to(dev)
+    q = torch.from_numpy(gbed["quat"]).to(dev)
+    ty = torch.from_numpy(gbed["type"]).to(dev)
+    sh = torch.from_numpy(gbed["shtype"]).to(dev)
     f = torch.zeros(nall, 3, dtype=torch.float64, device=dev)
     tq = torch.zeros_like(f)
     stream = torch.cuda.current_stream()
-    # the integrator either side of the hot path (include/shstep.h): owned rows only.  The bed starts at
-    # rest and dt is sized so that nothing moves further than 1e-2 of the neighbour skin during the whole
-    # run: the half list (and the contact-pair count) stay valid without a rebuild.  --verify keeps dt = 0.
+    # the integrator either side of the hot path (include/shstep.h).  The bed starts at rest and dt is sized so that
+    # nothing moves further than 1e-2 of the neighbour skin during the whole run: the half list (and the
+    # contact-pair count) stay valid without a rebuild.
     v = torch.zeros(nlocal, 3, dtype=torch.float64, device=dev)
     angmom = torch.zeros_like(v)
     mask = torch.ones(nlocal, dtype=torch.int32, device=dev)
-    dt = 0.0 if args.verify else min(1.0e-4, 4.0e-3 / (args.steps + args.warmup + args.ramp + 1))
+    dt = min(1.0e-4, 4.0e-3 / (args.steps + args.warmup + args.ramp + 1))
 
     def integrate(phase):
         sp.nve_device(phase, nlocal, dt, x.data_ptr(), v.data_ptr(), q.data_ptr(), angmom.data_ptr(), f.data_ptr(),
                       tq.data_ptr(), sh.data_ptr(), mask.data_ptr(), stream=stream.cuda_stream)
 
-    def step():
+    def step(events=None):
         integrate(0)
-        if halo is not None:
-            halo.forward(x, q)
         f.zero_()
         tq.zero_()
-        sp.compute_device(nlocal, nall - nlocal, x.data_ptr(), q.data_ptr(), ty.data_ptr(), sh.data_ptr(),
-                          f.data_ptr(), tq.data_ptr(), stream=stream.cuda_stream)
-        if halo is not None:
-            halo.reverse(f, tq)
+        if events:
+            events[0].record(stream)   # HIP events on the stream the pair kernel is launched on
+        sp.compute_device(nlocal, 0, x.data_ptr(), q.data_ptr(), ty.data_ptr(), sh.data_ptr(), f.data_ptr(), tq.data_ptr(),
+                          stream=stream.cuda_stream)
+        if events:
+            events[1].record(stream)
         integrate(1)
 
     # ---- untimed: count the contact pairs of this bed (static positions)
@@ -177,157 +188,60 @@ def main():
     st = sp.stats()
     n_contact, n_touching = st["n_contact"], st["n_touching"]
     sp.set_option("count", 0)
-
     for _ in range(args.ramp + args.warmup):
         step()
 
-    # ---- timed region: exactly K steps between barrier + synchronize
+    # ---- timed region: exactly K steps between synchronize
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for k in range(args.steps):
-        integrate(0)
-        if halo is not None:
-            halo.forward(x, q)
-        f.zero_()
-        tq.zero_()
-        ev[k][0].record(stream)   # HIP events on the stream the pair kernel is launched on
-        sp.compute_device(nlocal, nall - nlocal, x.data_ptr(), q.data_ptr(), ty.data_ptr(), sh.data_ptr(),
-                          f.data_ptr(), tq.data_ptr(), stream=stream.cuda_stream)
-        ev[k][1].record(stream)
-        if halo is not None:
-            halo.reverse(f, tq)
-        integrate(1)
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
+        step(ev[k])
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
 
-    tot = torch.tensor([elapsed, float(n_contact), float(n_touching), kernel_ms], dtype=torch.float64,
-                       device="cpu" if rehearsal else dev)
-    if dist is not None:
-        mx = tot.clone()
-        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
-        sm = tot.clone()
-        dist.all_reduce(sm, op=dist.ReduceOp.SUM)
-        elapsed = float(mx[0])
-        contact_all, touching_all = float(sm[1]), float(sm[2])
-    else:
-        contact_all, touching_all = float(n_contact), float(n_touching)
-
-    # sanity: forces are finite and (N = 1) sum to zero
     fh = f[:nlocal].cpu().numpy()
     assert np.all(np.isfinite(fh)) and np.abs(fh).max() > 0
 
-    verify_err = None
-    if args.verify and dist is not None:
-        mine = (gid[:nlocal], f[:nlocal].cpu().numpy(), tq[:nlocal].cpu().numpy())
-        parts = [None] * world if rank == 0 else None
-        dist.gather_object(mine, parts, dst=0)
-        if rank == 0:
-            ntot = args.particles * world
-            fg = np.zeros((ntot, 3))
-            tg = np.zeros((ntot, 3))
-            for g_, f_, t_ in parts:
-                fg[g_] = f_
-                tg[g_] = t_
-            ref = ShPair(local_rank)
-            ref.settings(nq)
-            ref.set_ntypes(1, nshapes)
-            for s_, a_ in enumerate(shp):
-                ref.set_shape(s_, lmax, a_)
-            ref.coeff("*", "*", 1000.0, args.exponent)
-            ril, rof, rjl = bed.half_neighbor_list(gbed["x"], gbed["shtype"], rmax)
-            ref.set_neighbors_csr(ril, rof, rjl)
-            fr_, tr_, _, _ = ref.compute(ntot, gbed["x"], gbed["quat"], gbed["type"], gbed["shtype"])
-            ref.close()
-            sc = np.abs(fr_).max()
-            verify_err = float(max(np.abs(fg - fr_).max(), np.abs(tg - tr_).max()) / sc)
-            assert verify_err < 1e-9, f"decomposed forces differ from single-domain forces: {verify_err}"
-
-    mts = None
-    if world > 1 and args.multi_ts_steps > 0:
-        mts = multi_rank_timestep_leg(args, shp, local_rank, dist, rank, world, grid, rehearsal)
-    if rank == 0:
-        ms_per_step = 1e3 * elapsed / args.steps
-        value = contact_all * args.steps / elapsed
-        achieved_gbs = BYTES_PER_PAIR * n_contact / (kernel_ms * 1e-3) / 1e9
-        fpp = flops_per_pair(lmax, nq)
-        achieved_tf = fpp * n_contact / (kernel_ms * 1e-3) / 1e12
-        out = {
-            "metric": "contact_pairs_per_sec", "value": value, "unit": "contact-pairs/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ramp_passes": args.ramp,
-            "ms_per_step": ms_per_step,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
-            "data": "synthetic",
-            "config": {
-                "workload": f"{args.particles} particles/GPU, {nshapes} SH shape(s) L_max={lmax}, dense packed "
-                            f"bed (jittered HCP, spacing 1.9 mean radii), n_q={nq} (Q={2 * nq * nq} nodes/pair), "
-                            f"pair_coeff kn=1000 exponent={args.exponent} (overlap volume + force + torque), "
-                            "inputs resident in HBM",
-                "particles_per_gpu": args.particles, "lmax": lmax, "nq": nq, "nshapes": nshapes,
-                "exponent": args.exponent, "rule": args.rule, "proc_grid": list(grid),
-                "backend": "rccl" if (world > 1 and not rehearsal) else ("gloo-rehearsal" if world > 1 else "none"),
-                "half_list_pairs_rank0": int(jl.size), "contact_pairs_rank0": int(n_contact),
-                "touching_pairs_rank0": int(n_touching), "contact_pairs_all_ranks": int(contact_all),
-                "ghost_atoms_rank0": int(nall - nlocal),
-            },
-            "timesteps_per_sec": args.steps / elapsed,
-            "timestep_note": "one step = initial_integrate + [forward halo] + clear + pair compute + [reverse halo] + "
-                             f"final_integrate on every rank, dt = {dt:g} from rest, no list rebuild inside the timed "
-                             "steps (see the `timestep` object for whole steps with rebuilds at N = 1)",
-            "verify_rel_err": verify_err,
-            "roofline": {
-                "bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved_gbs / HBM_PEAK_GBS,
-                "traffic": pmc_traffic(args) if world == 1 else None,
-                "kernel": "pair_contact_kernel", "kernel_ms": kernel_ms,
-                "bytes_per_pair": BYTES_PER_PAIR, "pairs_per_launch": int(n_contact),
-                "algorithmic_bytes_per_launch": BYTES_PER_PAIR * int(n_contact),
-                "note": "north_star asks for the HBM fraction; the kernel is FP64-VALU bound (see valu_f64). "
-                        "traffic: bytes/launch from profiles/pmc_traffic.json (rocprofv3 FETCH_SIZE + WRITE_SIZE "
-                        "passes of this workload; uncalibrated access widths, see the file)",
-            },
-            "occupancy": dict(sp.kernel_info(), note="static footprint of pair_contact_kernel as launched: one wave = one pair "
-                              "= one workgroup; waves_per_cu = min(4 x VGPR limit, LDS limit) of a gfx950 CU"),
-            "valu_f64": {
-                "bound": "valu_f64", "achieved": achieved_tf, "peak": F64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": achieved_tf / F64_VALU_PEAK_TFLOPS, "flop_per_pair": fpp,
-                "note": "algorithmic FLOP (SURVEY §8d formula) / kernel time; no MFMA by design",
-            },
-        }
-        if world == 1 and args.ts_steps > 0:
-            out["timestep"] = timestep_leg(args, shp, local_rank)
-        if mts is not None:
-            out["timestep_multi_rank"] = mts
-        if world == 1 and args.cpu_seconds > 0:
-            out["cpu_baseline"] = cpu_baseline(args, shp, rmax, gbed, il, of, jl)
-        print(json.dumps(out), flush=True)
+    roof, valu, occ = roofline_objects(args, sp, n_contact, kernel_ms, 1)
+    out = {
+        "metric": "contact_pairs_per_sec", "value": n_contact * args.steps / elapsed, "unit": "contact-pairs/s",
+        "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ramp_passes": args.ramp,
+        "ms_per_step": 1e3 * elapsed / args.steps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {
+            "workload": f"BASELINE configs[1]: {args.particles} particles/GPU, {nshapes} SH shape(s) L_max={lmax}, dense packed "
+                        f"bed (jittered HCP, spacing 1.9 mean radii), n_q={nq} (Q={2 * nq * nq} nodes/pair), "
+                        f"pair_coeff kn=1000 exponent={args.exponent} (overlap volume + force + torque), "
+                        "inputs resident in HBM",
+            "particles_per_gpu": args.particles, "lmax": lmax, "nq": nq, "nshapes": nshapes,
+            "exponent": args.exponent, "rule": args.rule, "proc_grid": [1, 1, 1], "backend": "none",
+            "half_list_pairs_rank0": int(jl.size), "contact_pairs_rank0": int(n_contact),
+            "touching_pairs_rank0": int(n_touching), "contact_pairs_all_ranks": int(n_contact), "ghost_atoms_rank0": 0,
+        },
+        "timesteps_per_sec": args.steps / elapsed,
+        "timestep_note": "one step = initial_integrate + clear + pair compute + final_integrate, "
+                         f"dt = {dt:g} from rest, no list rebuild inside the timed steps (see the `timestep` object for whole "
+                         "steps with rebuilds)",
+        "roofline": roof, "occupancy": occ, "valu_f64": valu,
+    }
+    if args.ts_steps > 0:
+        out["timestep"] = timestep_leg(args, shp)
+    if args.cpu_seconds > 0:
+        out["cpu_baseline"] = cpu_baseline(args, shp, rmax, gbed, il, of, jl)
+    print(json.dumps(out), flush=True)
     sp.close()
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
 
 
-def timestep_leg(args, shp, device):
+def timestep_leg(args, shp):
     """Whole device-resident timesteps per second (the second half of BASELINE.json's metric): NVE run of
     a fully periodic dense bed of the same shapes — integrate, rebuild test, ghosts, pair forces, reverse,
     integrate — everything through the C ABI (include/shstep.h), nothing on the host but launches."""
     import torch
-    from shpair import ShPair, bed
+    from shpair import bed
     from shpair.run import DeviceRun
-    sp = ShPair(device)
-    sp.settings(args.nq)
-    sp.set_ntypes(1, args.nshapes)
-    for s, a in enumerate(shp):
-        sp.set_shape(s, args.lmax, a)
-    sp.coeff("*", "*", 1000.0, args.exponent)
-    sp.set_option("rule", 1 if args.rule == "weighted" else 0)
+    sp = make_ctx(args, shp, 0)
     pts, lo, hi = bed.periodic_hcp(args.particles, 1.9, (1, 1, 1))
     rng = np.random.default_rng(bed.SEED0 + 7)
     n = pts.shape[0]
@@ -335,7 +249,7 @@ def timestep_leg(args, shp, device):
     quat = bed.random_quaternions(n, rng)
     shtype = rng.integers(0, args.nshapes, n).astype(np.int32) if args.nshapes > 1 else np.zeros(n, np.int32)
     skin, dt = 0.1, 1.0e-3
-    run = DeviceRun(sp, pts, quat, shtype, lo, hi, (1, 1, 1), skin, dt=dt, device=f"cuda:{device}")
+    run = DeviceRun(sp, pts, quat, shtype, lo, hi, (1, 1, 1), skin, dt=dt, device="cuda:0")
     run.run(5)
     sp.set_option("count", 1)
     run.force()
@@ -349,7 +263,6 @@ def timestep_leg(args, shp, device):
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
     rebuilds = run.builds - b0
-    # cost of one rebuild (borders + bins + half list), timed on its own
     torch.cuda.synchronize()
     t1 = time.perf_counter()
     run.rebuild()
@@ -368,52 +281,231 @@ def timestep_leg(args, shp, device):
     return out
 
 
-def multi_rank_timestep_leg(args, shp, device, dist, rank, world, grid, rehearsal):
-    """Whole timesteps on N ranks with everything LAMMPS does around the pair style when atoms move: migration,
-    ghosts, list rebuilds (shpair.mrun.MultiRankRun).  Periodic bed of `particles` per rank; every rank calls this."""
-    import torch
-    from shpair import ShPair, bed
-    from shpair.mrun import MultiRankRun
-    sp = ShPair(device)
-    sp.settings(args.nq)
-    sp.set_ntypes(1, args.nshapes)
-    for s, a in enumerate(shp):
-        sp.set_shape(s, args.lmax, a)
-    sp.coeff("*", "*", 1000.0, args.exponent)
-    sp.set_option("rule", 1 if args.rule == "weighted" else 0)
-    pts, lo, hi = bed.periodic_hcp(args.particles * world, 1.9, (1, 1, 1))
-    rng = np.random.default_rng(bed.SEED0 + 7)
+# ======================================================================================================== N > 1
+def config4_bed(args, world, grid):
+    """BASELINE configs[3] as a synthetic bed: `particles` per rank on an HCP lattice in a box periodic in x and y
+    whose aspect follows the processor grid (equal bricks), one frozen layer as the floor, thermal velocities."""
+    from shpair import bed
+    n_target = args.particles * world
+    dx, dy, dz = 1.9, 1.9 * np.sqrt(3.0) / 2.0, 1.9 * np.sqrt(2.0 / 3.0)
+    s = (n_target * dx * dy * dz / (grid[0] * grid[1] * grid[2])) ** (1.0 / 3.0)   # brick edge
+    nx = max(2, int(round(grid[0] * s / dx)))
+    ny = max(2, 2 * int(round(grid[1] * s / dy / 2)))
+    nz = max(2, 2 * int(round(n_target / (nx * ny) / 2)))
+    k, j, i = np.meshgrid(np.arange(nz), np.arange(ny), np.arange(nx), indexing="ij")
+    # no offset in x and y: lattice planes then coincide with the brick faces, so that the thermal motion carries atoms
+    # across them (migration) from the first rebuild on
+    pts = np.stack([((i + 0.5 * (j % 2) + 0.5 * (k % 2)) * dx).ravel(), ((j + (k % 2) / 3.0) * dy).ravel(),
+                    (k * dz).ravel() + 0.25 * 1.9], axis=1)
+    lo = np.zeros(3)
+    hi = np.array([nx * dx, ny * dy, nz * dz + 1.9])
+    pts[:, 0] = np.mod(pts[:, 0], hi[0])
+    pts[:, 1] = np.mod(pts[:, 1], hi[1])
+    rng = np.random.default_rng(bed.SEED0 + 4)
     n = pts.shape[0]
-    pts = pts + rng.uniform(-0.04, 0.04, pts.shape)
+    x = pts + rng.uniform(-0.04, 0.04, pts.shape)
     quat = bed.random_quaternions(n, rng)
     shtype = rng.integers(0, args.nshapes, n).astype(np.int32) if args.nshapes > 1 else np.zeros(n, np.int32)
-    blen = (hi - lo) / np.array(grid)
-    c = np.minimum(((np.mod(pts - lo, hi - lo)) / blen).astype(int), np.array(grid) - 1)
-    mine = ((c[:, 0] * grid[1] + c[:, 1]) * grid[2] + c[:, 2]) == rank
-    run = MultiRankRun(sp, dist, rank, world, grid, lo, hi, (1, 1, 1), 0.1, pts[mine], quat[mine], shtype[mine],
-                       np.arange(n, dtype=np.int32)[mine], dt=1.0e-3, device=f"cuda:{device}", staged=rehearsal)
-    run.run(5)
-    b0 = run.builds
+    mask = np.where(pts[:, 2] < 0.25 * 1.9 + 0.5 * dz, 2, 1).astype(np.int32)    # the bottom layer is the floor
+    v = args.vthermal * rng.normal(size=(n, 3))
+    v[mask == 2] = 0.0
+    return dict(x=x, quat=quat, shtype=shtype, mask=mask, v=v, tag=np.arange(n, dtype=np.int32), lo=lo, hi=hi,
+                periodic=(1, 1, 0), n=n)
+
+
+class _Collective:
+    """What the ranks need of each other besides the data path: a barrier, max / sum of a few host numbers, one
+    broadcast.  torch.distributed (gloo) between processes, a threading.Barrier between rank threads."""
+
+    def __init__(self, world, dist=None):
+        self.world, self.dist = world, dist
+        if dist is None:
+            self.bar = threading.Barrier(world)
+            self.slots = [None] * world
+
+    def barrier(self):
+        if self.dist is not None:
+            self.dist.barrier()
+        else:
+            self.bar.wait()
+
+    def gather(self, rank, value):
+        """List of every rank's value (on every rank)."""
+        if self.dist is not None:
+            out = [None] * self.world
+            self.dist.all_gather_object(out, value)
+            return out
+        self.slots[rank] = value
+        self.bar.wait()
+        out = list(self.slots)
+        self.bar.wait()
+        return out
+
+
+def multi_rank_body(args, rank, world, device, coll, hub, uid, result):
+    import torch
+    from shpair import shapes, bed, mrank
+    torch.cuda.set_device(device)
+    shp = [shapes.random_shape(args.lmax, bed.SEED0 + 2 + s) for s in range(args.nshapes)]
+    sp = make_ctx(args, shp, device)
+    skin = 0.1
+    grid = mrank.proc_grid(world)
+    cfg = config4_bed(args, world, grid)
+    cut = 2.0 * max(sp.rmax(s) for s in range(args.nshapes)) + skin
+    geo = mrank.plan_geometry(grid, cfg["lo"], cfg["hi"], cfg["periodic"], cut, rank)
+    xw, owner = mrank.plan_owner(geo, cfg["x"])
+    mine = owner == rank
+    halo = mrank.Halo(sp, rank, world, grid, cfg["lo"], cfg["hi"], cfg["periodic"], skin, hub=hub, unique_id_bytes=uid)
+    dt = 2.0e-3
+    run = mrank.RankRun(sp, halo, xw[mine], cfg["quat"][mine], cfg["shtype"][mine], cfg["tag"][mine], v=cfg["v"][mine],
+                        mask=cfg["mask"][mine], dt=dt, gravity=(0.0, 0.0, -1.0), device=f"cuda:{device}",
+                        capacity=int(1.5 * mine.sum()) + 4096)
+    verify_err = None
+    if args.verify:
+        t, _, _, _, f0, tq0 = run.owned()
+        parts = coll.gather(rank, (t, f0, tq0))
+        if rank == 0:
+            from shpair.run import DeviceRun
+            ref_sp = make_ctx(args, shp, device)
+            ref = DeviceRun(ref_sp, cfg["x"], cfg["quat"], cfg["shtype"], cfg["lo"], cfg["hi"], cfg["periodic"], skin, mask=cfg["mask"],
+                            dt=dt, gravity=(0.0, 0.0, -1.0), device=f"cuda:{device}")
+            ref.v[:] = torch.from_numpy(cfg["v"]).to(ref.v.device)
+            ref.force()
+            torch.cuda.synchronize()
+            n = cfg["n"]
+            fr, tr = ref.f[:n].cpu().numpy(), ref.tq[:n].cpu().numpy()
+            fg, tg = np.zeros_like(fr), np.zeros_like(tr)
+            for t_, f_, q_ in parts:
+                fg[t_] = f_
+                tg[t_] = q_
+            verify_err = float(max(np.abs(fg - fr).max(), np.abs(tg - tr).max()) / np.abs(fr).max())
+            assert verify_err < 1e-9, f"decomposed forces differ from single-domain forces: {verify_err}"
+            ref_sp.close()
+
+    def count_contacts():
+        sp.set_option("count", 1)
+        run.force()
+        st = sp.stats()
+        sp.set_option("count", 0)
+        return st["n_contact"], st["n_touching"]
+
+    for _ in range(max(1, (args.ramp + args.warmup) // 4)):   # clock ramp and warm-up, in chunks so that rebuilds happen too
+        run.run(4)
+    c0, t0_ = count_contacts()
+    b0, k0 = run.builds, run.kernel_ms
+    s0 = halo.stats()
+    run.sync()
+    coll.barrier()
     torch.cuda.synchronize()
-    dist.barrier()
     t0 = time.perf_counter()
-    run.run(args.multi_ts_steps)
+    run.run(args.steps, timed=True)
     torch.cuda.synchronize()
-    dist.barrier()
-    el = time.perf_counter() - t0
-    tot = torch.tensor([el, float(run.n), float(run.nghost), float(run.migrated)], dtype=torch.float64,
-                       device="cpu" if rehearsal else f"cuda:{device}")
-    mx = tot.clone()
-    dist.all_reduce(mx, op=dist.ReduceOp.MAX)
-    sm = tot.clone()
-    dist.all_reduce(sm, op=dist.ReduceOp.SUM)
-    out = {"timesteps_per_s": args.multi_ts_steps / float(mx[0]), "ms_per_step": 1e3 * float(mx[0]) / args.multi_ts_steps,
-           "steps": args.multi_ts_steps, "particles_all_ranks": int(sm[1]), "ghosts_all_ranks": int(sm[2]),
-           "migrated_atoms": int(sm[3]), "rebuilds": run.builds - b0, "proc_grid": list(grid), "dt": 1.0e-3, "skin": 0.1,
-           "what": "initial_integrate + rebuild test (all-reduce) + [migration, ghosts, list build] + forward + pair compute "
-                   "+ reverse + final_integrate on every rank (shpair.mrun.MultiRankRun)"}
+    coll.barrier()
+    elapsed = time.perf_counter() - t0
+    c1, t1_ = count_contacts()
+    s1 = halo.stats()
+    n_end = run.n
+    mine_out = dict(elapsed=elapsed, contact=0.5 * (c0 + c1), touching=0.5 * (t0_ + t1_), kernel_ms=(run.kernel_ms - k0) / args.steps,
+                    rebuilds=run.builds - b0, migrated=s1["migrated_out"] - s0["migrated_out"], nlocal=n_end, nghost=run.nghost,
+                    npairs=run.npairs, stats=s1)
+    allr = coll.gather(rank, mine_out)
+    if rank == 0:
+        el = max(r["elapsed"] for r in allr)
+        contact_all = sum(r["contact"] for r in allr)
+        assert sum(r["nlocal"] for r in allr) == cfg["n"], "atoms lost"
+        roof, valu, occ = roofline_objects(args, sp, allr[0]["contact"], allr[0]["kernel_ms"], world)
+        st = allr[0]["stats"]
+        result["line"] = {
+            "metric": "contact_pairs_per_sec", "value": contact_all * args.steps / el, "unit": "contact-pairs/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ramp_passes": args.ramp,
+            "ms_per_step": 1e3 * el / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {
+                "workload": f"BASELINE configs[3]: {args.particles} particles/GPU ({cfg['n']} in all), {args.nshapes} SH shape(s) "
+                            f"L_max={args.lmax}, n_q={args.nq}, exponent={args.exponent}, box periodic in x,y on a frozen floor, gravity, "
+                            f"thermal start (|v| ~ {args.vthermal}), dt={dt}, skin {skin}: whole timesteps with rebuild tests, atom "
+                            "migration, ghost exchange (shhalo_run_device); arrays resident in HBM",
+                "particles_per_gpu": args.particles, "particles_all_ranks": int(cfg["n"]), "lmax": args.lmax, "nq": args.nq,
+                "nshapes": args.nshapes, "exponent": args.exponent, "rule": args.rule, "proc_grid": list(grid),
+                "backend": "rccl" if args.transport == "rccl" else "local-hub-rehearsal (rank threads on one GPU)",
+                "contact_pairs_rank0": int(allr[0]["contact"]), "contact_pairs_all_ranks": int(contact_all),
+                "ghost_atoms_rank0": int(allr[0]["nghost"]), "half_list_pairs_rank0": int(allr[0]["npairs"]),
+            },
+            "timesteps_per_sec": args.steps / el,
+            "halo": {
+                "transport": "rccl" if st["transport"] == 1 else "local",
+                "ranks_reported_by_transport": st["nranks_transport"], "rccl_version": st["rccl_version"],
+                "peers_rank0": st["npeers"], "send_rows_rank0": st["nsend_rows"], "ghost_rows_rank0": st["nghost_rows"],
+                "forward_bytes_per_step_rank0": st["forward_bytes_per_step"], "reverse_bytes_per_step_rank0": st["reverse_bytes_per_step"],
+                "rebuilds_in_timed_steps": [r["rebuilds"] for r in allr], "atoms_migrated_in_timed_steps": int(sum(r["migrated"] for r in allr)),
+                "owned_atoms": [r["nlocal"] for r in allr], "ghost_atoms": [r["nghost"] for r in allr],
+                "what": "per step and direction of travel one pack kernel, one ncclGroupStart..ncclSend/ncclRecv per peer.."
+                        "ncclGroupEnd on the compute stream, one unpack kernel; no host wait except at the rebuild test",
+            },
+            "value_note": "contact pairs of all ranks (mean of the counts before and after the timed steps) x K / max-over-ranks time",
+            "verify_rel_err": verify_err,
+            "roofline": roof, "occupancy": occ, "valu_f64": valu,
+        }
+    coll.barrier()
+    halo.close()
     sp.close()
-    return out
+
+
+def main_multi(args):
+    import torch
+    if not torch.cuda.is_available():
+        print("bench.py: no GPU visible; the HIP path has no CPU fallback", file=sys.stderr)
+        sys.exit(3)
+    world = args.gpus
+    result = {}
+    if args.transport == "local":
+        from shpair import mrank
+        hub = mrank.Hub(world)
+        coll = _Collective(world)
+        errs = []
+
+        def work(r):
+            try:
+                multi_rank_body(args, r, world, 0, coll, hub, None, result)
+            except BaseException as e:  # noqa: BLE001
+                import traceback
+                errs.append(traceback.format_exc())
+                try:
+                    coll.bar.abort()
+                except Exception:  # noqa: BLE001
+                    pass
+        th = [threading.Thread(target=work, args=(r,)) for r in range(world)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        if errs:
+            print(errs[0], file=sys.stderr)
+            sys.exit(1)
+        print(json.dumps(result["line"]), flush=True)
+        hub.close()
+        return
+    wsz = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if wsz != world:
+        if rank == 0:
+            print(f"bench.py: --gpus {world} but WORLD_SIZE={wsz}; launch with torch.distributed.run (or --transport local)",
+                  file=sys.stderr)
+        sys.exit(2)
+    import torch.distributed as dist
+    from shpair import mrank
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    torch.cuda.set_device(local_rank)
+    dist.init_process_group("gloo", rank=rank, world_size=world)   # control plane only: id broadcast, barriers, timings
+    box = [mrank.unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0)
+    coll = _Collective(world, dist)
+    multi_rank_body(args, rank, world, local_rank, coll, None, box[0], result)
+    if rank == 0:
+        print(json.dumps(result["line"]), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
 
 
 def cpu_baseline(args, shp, rmax, gbed, il, of, jl):
@@ -439,7 +531,6 @@ def cpu_baseline(args, shp, rmax, gbed, il, of, jl):
     per_row = max(c_probe / probe_rows, 1e-9)
     nrows = int(min(len(il), max(probe_rows, args.cpu_seconds * rate / per_row)))
     t_main, c_main = run(nrows, nthreads)
-    # one thread, on a sample sized for about a fifth of the budget (a plain LAMMPS rank is one core)
     rows1 = int(min(len(il), max(200, 0.2 * args.cpu_seconds * (rate / nthreads) / per_row)))
     t_one, c_one = run(rows1, 1)
     return {"value": c_main / t_main, "unit": "contact-pairs/s", "cores": nthreads, "kind": "port",
@@ -450,4 +541,8 @@ def cpu_baseline(args, shp, rmax, gbed, il, of, jl):
 
 
 if __name__ == "__main__":
-    main()
+    _args = parse()
+    if _args.gpus == 1:
+        main_single(_args)
+    else:
+        main_multi(_args)
