@@ -50,6 +50,8 @@ struct PairParams {
   const double* rc;     // recurrence constants a'_nm for lmax, m-major (ring tables; run-time-order kernel)
   const double* coef;   // nshapes x cstride doubles: monomial table (compiled orders) or cw (run-time order)
   const double* rmax;   // nshapes
+  int nshapes;
+  int* err;             // device error bits (kPairErr*), raised instead of an out-of-bounds table read
   int cstride;
   int lmax;
   // pair coefficients, (ntypes+1)^2 row-major
@@ -87,6 +89,8 @@ struct PairParams {
 };
 
 constexpr int kMaxWavesPerBlock = 4;
+constexpr int kPairErrShape = 1;  // a shape index outside [0, nshapes) reached the kernel: the pair was skipped
+constexpr int kPairErrType = 2;   // an atom type outside [1, ntypes]
 // The same for the WEIGHTED variant (three-slab window): 5 fits without spills up to L = 6 (A/B at L = 6:
 // n_q = 16 5.29 -> 5.12 ms, n_q = 8 2.45 -> 2.27 ms); from L = 7 it would spill 25-30 VGPRs, so 4 there.
 #ifndef SHP_WMIN_WAVES
@@ -436,6 +440,10 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, WEIGHTED ? SHP_WMIN_WA
   const int i = P.pair_i[w];
   const int j = P.pair_j[w];
   const int si = P.shtype[i], sj = P.shtype[j];
+  if ((unsigned)si >= (unsigned)P.nshapes || (unsigned)sj >= (unsigned)P.nshapes) {  // wave-uniform
+    if (lane == 0) atomicOr(P.err, kPairErrShape);
+    return;
+  }
   const double Ri = P.rmax[si], Rj = P.rmax[sj];
   double rho2, rho, cosa;
   bool centre_in_bj;  // rho < Rj
@@ -893,6 +901,10 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, WEIGHTED ? SHP_WMIN_WA
 
   // SPEC §2.7 force law
   const int ti = P.type[i], tj = P.type[j];
+  if (ti < 1 || ti > P.ntypes || tj < 1 || tj > P.ntypes) {
+    atomicOr(P.err, kPairErrType);
+    return;
+  }
   const double knij = P.kn[ti * (P.ntypes + 1) + tj];
   const double mij = P.expo[ti * (P.ntypes + 1) + tj];
   const double vm1 = (mij == 1.0) ? 1.0 : pow_quarter(aV, mij - 1.0);  // V^(m-1)

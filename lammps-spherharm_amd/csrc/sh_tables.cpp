@@ -312,6 +312,82 @@ double default_rmax(int lmax, const double* anm)
   return 1.01 * best;
 }
 
+// The largest radius of the shape: the sample grid of default_rmax(), then a derivative-free local search on the
+// sphere (shrinking tangent-plane pattern) from the best nodes.  Used to REFUSE a bounding radius that is too small;
+// the default itself stays 1.01 x the sampled maximum (docs/SPEC.md §1).
+double refined_max_radius(int lmax, const double* anm)
+{
+  const int nt = 6 * (lmax + 1) + 2, np = 2 * nt;
+  std::vector<double> t, w;
+  gauss_legendre(nt, t, w);
+  struct Node {
+    double r, u[3];
+  };
+  std::vector<Node> best;
+  const size_t keep = 12;
+  for (int a = 0; a < nt; ++a) {
+    const double ct = t[a], st = std::sqrt(1.0 - ct * ct);
+    for (int b = 0; b < np; ++b) {
+      const double ph = 2.0 * (double)kPi * b / np;
+      Node n;
+      n.u[0] = st * std::cos(ph);
+      n.u[1] = st * std::sin(ph);
+      n.u[2] = ct;
+      n.r = host_radius(lmax, anm, n.u);
+      if (best.size() < keep) {
+        best.push_back(n);
+      } else {
+        size_t lo = 0;
+        for (size_t k = 1; k < keep; ++k)
+          if (best[k].r < best[lo].r) lo = k;
+        if (n.r > best[lo].r) best[lo] = n;
+      }
+    }
+  }
+  double rmax = 0.0;
+  for (Node n : best) {
+    double h = 2.0 * (double)kPi / np;  // one grid cell
+    for (int it = 0; it < 60 && h > 1e-9; ++it) {
+      // tangent basis at n.u
+      const int k = std::fabs(n.u[0]) < 0.6 ? 0 : 1;
+      double e[3] = {0.0, 0.0, 0.0};
+      e[k] = 1.0;
+      const double d = e[0] * n.u[0] + e[1] * n.u[1] + e[2] * n.u[2];
+      double a1[3], a2[3];
+      double na = 0.0;
+      for (int q = 0; q < 3; ++q) {
+        a1[q] = e[q] - d * n.u[q];
+        na += a1[q] * a1[q];
+      }
+      na = std::sqrt(na);
+      for (int q = 0; q < 3; ++q) a1[q] /= na;
+      a2[0] = n.u[1] * a1[2] - n.u[2] * a1[1];
+      a2[1] = n.u[2] * a1[0] - n.u[0] * a1[2];
+      a2[2] = n.u[0] * a1[1] - n.u[1] * a1[0];
+      bool moved = false;
+      for (int dir = 0; dir < 8; ++dir) {
+        const double c = std::cos(dir * (double)kPi / 4.0), sn = std::sin(dir * (double)kPi / 4.0);
+        double v[3], nv = 0.0;
+        for (int q = 0; q < 3; ++q) {
+          v[q] = n.u[q] + h * (c * a1[q] + sn * a2[q]);
+          nv += v[q] * v[q];
+        }
+        nv = std::sqrt(nv);
+        for (int q = 0; q < 3; ++q) v[q] /= nv;
+        const double r = host_radius(lmax, anm, v);
+        if (r > n.r) {
+          n.r = r;
+          for (int q = 0; q < 3; ++q) n.u[q] = v[q];
+          moved = true;
+        }
+      }
+      if (!moved) h *= 0.5;
+    }
+    if (n.r > rmax) rmax = n.r;
+  }
+  return rmax;
+}
+
 // docs/SPEC.md §5. Azimuth nodes start at phi = 0 (any offset is exact for these integrands).
 void mass_props(int lmax, const double* anm, double out[10])
 {

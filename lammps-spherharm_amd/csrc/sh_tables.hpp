@@ -51,6 +51,7 @@ double host_radius(int lmax, const double* anm, const double u[3]);
 
 // Default bounding radius: 1.01 x max over the (6(L+1)+2) x 2(6(L+1)+2) grid.
 double default_rmax(int lmax, const double* anm);
+double refined_max_radius(int lmax, const double* anm);  // largest radius incl. between the samples (local search)
 
 // Rigid-body properties at unit density (docs/SPEC.md §5): V, c[3], J_c (xx,yy,zz,xy,xz,yz).
 void mass_props(int lmax, const double* anm, double out[10]);

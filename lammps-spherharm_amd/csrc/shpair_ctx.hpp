@@ -68,9 +68,19 @@ struct shpair_ctx {
   // staging for the host-pointer entry point
   shp::DevBuf<double> d_x, d_quat, d_f, d_torque, d_ev;
   shp::DevBuf<int> d_type, d_shtype;
-  double *h_ft = nullptr;  // pinned: f then torque
-  size_t h_ft_cap = 0;
   double *h_ev = nullptr;  // pinned 7
+
+  // neighbour lists installed so far
+  unsigned long long list_gen = 0;
+  // flattened LAMMPS list on its way to the device (pinned), and its device copy (expanded by expand_csr_kernel)
+  int* h_list = nullptr;
+  size_t h_list_cap = 0;
+  shp::DevBuf<int> d_list;
+  // device error bits raised by the pair kernel (pair_kernel.hpp kPairErr*), read at the blocking calls
+  shp::DevBuf<int> d_err;
+  int* h_err = nullptr;  // pinned
+  // last output pointers that passed the device-memory check of shpair_compute_device
+  const void* ok_ptr[3] = {nullptr, nullptr, nullptr};
 
   shp::DevBuf<unsigned long long> d_counters;
   shp::DevBuf<unsigned char> d_flags;
@@ -94,6 +104,7 @@ struct shpair_ctx {
 void shstep_release_state(shpair_ctx* c);   // shstep_api.hip
 void shstep_invalidate_list(shpair_ctx* c);
 int shpair_prepare_tables(shpair_ctx* c);    // shpair_api.hip
+int shpair_check_device_errors(shpair_ctx* c, void* stream);  // shpair_api.hip: reads + clears the kernel's error bits (blocks)
 int shstep_exclusive_scan(shpair_ctx* c, const int* in, int* out, int n, void* stream);                           // shstep_api.hip
 int shstep_enqueue_check(shpair_ctx* c, int nlocal, const double* x, int** flag_dev, int* forced, void* stream);  // shstep_api.hip
 

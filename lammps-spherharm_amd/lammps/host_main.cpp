@@ -8,6 +8,9 @@
 //            per atom: x y z qw qx qy qz type shtype
 //            inum ; per row: i n j1 .. jn
 // usage: lammps_host <bed> <out> <nq> <kn> <exponent> <shape files...>
+// With LAMMPS_HOST_GHOST_OWNERS=<file of nghost owner rows> the quaternions are registered as a CUSTOM per-atom
+// array (fix property/atom d2_quat 4 ghost yes) instead of an atom-style array and the stub Comm forwards owners'
+// values to the ghosts when the pair style asks for it: the bed file may then hold stale ghost orientations.
 // With LAMMPS_HOST_NSTEPS=<n> and LAMMPS_HOST_DT=<dt> in the environment it then runs n velocity-Verlet
 // steps with FixNVESH (fix nve/sh) from rest, the way Verlet::run orders them, and writes
 // x v quat angmom of the owned atoms to <out>.traj (ghost-free beds only: nghost = 0).
@@ -69,7 +72,21 @@ int main(int argc, char **argv)
   atom->f = f;
   atom->torque = tq;
   atom->type = type.data();
-  atom->extractable["quat"] = (void *) quat;        // as atom_style spherharm would expose them
+  double **darr[1] = {quat};
+  if (const char *gof = getenv("LAMMPS_HOST_GHOST_OWNERS")) {
+    FILE *gp = fopen(gof, "r");
+    if (!gp) return 3;
+    lmp.comm->ghost_owner.resize(nghost);
+    for (int g = 0; g < nghost; g++)
+      if (fscanf(gp, "%d", &lmp.comm->ghost_owner[g]) != 1) return 3;
+    fclose(gp);
+    atom->custom_names.push_back("quat");
+    atom->custom_flag.push_back(1);
+    atom->custom_cols.push_back(4);
+    atom->darray = darr;
+  } else {
+    atom->extractable["quat"] = (void *) quat;        // as atom_style spherharm would expose them
+  }
   atom->extractable["shtype"] = (void *) shtype.data();
   lmp.force->newton_pair = newton;
 
@@ -112,7 +129,7 @@ int main(int argc, char **argv)
 
   fp = fopen(argv[2], "w");
   if (!fp) return 4;
-  fprintf(fp, "%.17g %.17g %.17g\n", cut, e1, pair.eng_vdwl);
+  fprintf(fp, "%.17g %.17g %.17g %d\n", cut, e1, pair.eng_vdwl, lmp.comm->forward_calls);
   fprintf(fp, "%.17g %.17g %.17g %.17g %.17g %.17g\n", pair.virial[0], pair.virial[1], pair.virial[2],
           pair.virial[3], pair.virial[4], pair.virial[5]);
   for (int i = 0; i < nall; i++)

@@ -43,8 +43,14 @@ using namespace LAMMPS_NS;
 
 PairSH::PairSH(LAMMPS *lmp) :
     Pair(lmp), ctx(nullptr), nq(16), device(-1), rule(0), nshapes(0), kn(nullptr), exponent(nullptr), maxrad(0.0),
-    last_neigh_build(-1)
+    last_neigh_build(-1), quat_comm(nullptr), quat_is_custom(0)
 {
+  // Orientations kept in a custom per-atom array (fix property/atom d2_quat 4 ghost yes) reach the ghost atoms only at
+  // Comm::borders(), i.e. at reneighbourings, while the integrator turns the owners every step: the pair style
+  // forwards them itself (Comm::forward_comm(this), 4 doubles per ghost) at the top of compute().  An atom style
+  // that carries the quaternion (atom->extract("quat")) is expected to pack it in its own pack_comm, as LAMMPS'
+  // aspherical atom styles do.
+  comm_forward = 4;
   single_enable = 0;
   restartinfo = 0;
   no_virial_fdotr_compute = 1;    // the virial comes back from the device, tallied per pair
@@ -105,10 +111,15 @@ void PairSH::settings(int narg, char **arg)
     // one rank per GPU: default device = rank within the node
     int dev = device;
     if (dev < 0) {
-      const char *lr = getenv("OMPI_COMM_WORLD_LOCAL_RANK");
-      if (!lr) lr = getenv("MV2_COMM_WORLD_LOCAL_RANK");
-      if (!lr) lr = getenv("SLURM_LOCALID");
-      dev = lr ? atoi(lr) : 0;
+      // the rank within the node, from whichever launcher started the run: Open MPI, MVAPICH2, MPICH / Hydra (what
+      // this image ships), Intel MPI, PALS, Slurm, Flux
+      static const char *const vars[] = {"OMPI_COMM_WORLD_LOCAL_RANK", "MV2_COMM_WORLD_LOCAL_RANK", "MPI_LOCALRANKID",
+                                         "PMI_LOCAL_RANK", "PALS_LOCAL_RANKID", "SLURM_LOCALID", "FLUX_TASK_LOCAL_ID",
+                                         "LOCAL_RANK"};
+      const char *lr = nullptr;
+      for (const char *v : vars)
+        if ((lr = getenv(v)) != nullptr && *lr) break;
+      dev = (lr && *lr) ? atoi(lr) : 0;
     }
     const int rc = shpair_create(&ctx, dev);
     if (rc != SHPAIR_OK) {
@@ -285,8 +296,20 @@ void PairSH::compute(int eflag, int vflag)
   // per-atom orientation and shape index
   int flag = 0, cols = 0, idx;
   double **quat = (double **) atom->extract("quat");
-  if (!quat && (idx = atom->find_custom("quat", flag, cols)) >= 0 && flag == 1 && cols == 4) quat = atom->darray[idx];
+  quat_is_custom = 0;
+  if (!quat && (idx = atom->find_custom("quat", flag, cols)) >= 0 && flag == 1 && cols == 4) {
+    quat = atom->darray[idx];
+    quat_is_custom = 1;
+  }
   if (!quat) error->one(FLERR, "pair sh: per-atom quaternions disappeared");
+  if (quat_is_custom && atom->nghost > 0) {
+    quat_comm = quat;
+#ifdef SHPAIR_LAMMPS_OLD_API
+    comm->forward_comm_pair(this);
+#else
+    comm->forward_comm(this);
+#endif
+  }
   int *shtype = (int *) atom->extract("shtype");
   if (!shtype && (idx = atom->find_custom("shtype", flag, cols)) >= 0 && flag == 0 && cols == 0) shtype = atom->ivector[idx];
   if (!shtype) error->one(FLERR, "pair sh: per-atom shape index disappeared");
@@ -306,6 +329,35 @@ void PairSH::compute(int eflag, int vflag)
   if (eflag_global) eng_vdwl += eng;
   if (vflag_global)
     for (int a = 0; a < 6; a++) virial[a] += vir[a];
+}
+
+/* ----------------------------------------------------------------------
+   forward communication of the orientations (see the constructor)
+------------------------------------------------------------------------- */
+
+int PairSH::pack_forward_comm(int n, int *list, double *buf, int /*pbc_flag*/, int * /*pbc*/)
+{
+  int m = 0;
+  for (int i = 0; i < n; i++) {
+    const double *q = quat_comm[list[i]];
+    buf[m++] = q[0];
+    buf[m++] = q[1];
+    buf[m++] = q[2];
+    buf[m++] = q[3];
+  }
+  return m;
+}
+
+void PairSH::unpack_forward_comm(int n, int first, double *buf)
+{
+  int m = 0;
+  for (int i = first; i < first + n; i++) {
+    double *q = quat_comm[i];
+    q[0] = buf[m++];
+    q[1] = buf[m++];
+    q[2] = buf[m++];
+    q[3] = buf[m++];
+  }
 }
 
 void *PairSH::extract(const char *str, int &dim)

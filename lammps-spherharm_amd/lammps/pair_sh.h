@@ -41,6 +41,8 @@ class PairSH : public Pair {
   void init_style() override;
   double init_one(int, int) override;
   void *extract(const char *, int &) override;
+  int pack_forward_comm(int, int *, double *, int, int *) override;
+  void unpack_forward_comm(int, int, double *) override;
 
  protected:
   struct shpair_ctx *ctx;
@@ -52,6 +54,8 @@ class PairSH : public Pair {
   double **kn, **exponent;              // [ntypes+1][ntypes+1], as pair_coeff sets them
   double maxrad;                        // largest bounding radius over all shapes
   bigint last_neigh_build;              // neighbor->lastcall of the list already uploaded
+  double **quat_comm;                   // the array forward communication packs from / unpacks into
+  int quat_is_custom;                   // orientation comes from fix property/atom: ghosts must be refreshed here
 
   void allocate();
   void load_shapes();

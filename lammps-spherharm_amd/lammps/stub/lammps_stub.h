@@ -110,9 +110,16 @@ class Neighbor {
   void request(void *, int) { nrequest++; }
 };
 
+// Comm::forward_comm(Pair *) as LAMMPS does it for a pair style with comm_forward > 0: pack the owners' values of the
+// send list, unpack them into the ghost rows.  Here one swap whose send list is the owner of every ghost.
 class Comm {
  public:
   int me = 0, nprocs = 1;
+  std::vector<int> ghost_owner;   // test scaffold: owner row of ghost nlocal + g
+  class Atom *atom_for_comm = nullptr;
+  int forward_calls = 0;
+  inline void forward_comm(class Pair *pair);
+  inline void forward_comm_pair(class Pair *pair) { forward_comm(pair); }   // pre-2020 name
 };
 class Update {
  public:
@@ -129,6 +136,7 @@ class LAMMPS {
   Neighbor *neighbor = new Neighbor;
   Comm *comm = new Comm;
   Update *update = new Update;
+  LAMMPS() { comm->atom_for_comm = atom; }
 };
 
 class Pointers {
@@ -184,6 +192,9 @@ class Pair : protected Pointers {
   virtual void init_style() {}
   virtual double init_one(int, int) { return 0.0; }
   virtual void *extract(const char *, int &) { return nullptr; }
+  int comm_forward = 0;    // doubles per atom in forward communication
+  virtual int pack_forward_comm(int, int *, double *, int, int *) { return 0; }
+  virtual void unpack_forward_comm(int, int, double *) {}
   void ev_init(int eflag, int vflag)
   {
     // LAMMPS bit convention: 1 = global, 2 = per-atom
@@ -216,6 +227,21 @@ class Pair : protected Pointers {
     for (double &v : virial) v = 0.0;
   }
 };
+
+inline void Comm::forward_comm(Pair *pair)
+{
+  ++forward_calls;
+  const int ng = (int) ghost_owner.size();
+  if (ng == 0 || pair->comm_forward <= 0) return;
+  std::vector<double> buf((size_t) ng * pair->comm_forward);
+  int pbc[6] = {0, 0, 0, 0, 0, 0};
+  const int n = pair->pack_forward_comm(ng, ghost_owner.data(), buf.data(), 0, pbc);
+  if (n != ng * pair->comm_forward) {
+    fprintf(stderr, "stub Comm: pack_forward_comm returned %d, expected %d\n", n, ng * pair->comm_forward);
+    exit(1);
+  }
+  pair->unpack_forward_comm(ng, atom_for_comm ? atom_for_comm->nlocal : 0, buf.data());
+}
 
 namespace FixConst {
 enum { INITIAL_INTEGRATE = 1 << 0, POST_FORCE = 1 << 4, FINAL_INTEGRATE = 1 << 5 };

@@ -76,7 +76,8 @@ def test_pairsh_adapter_matches_oracle(tmp_path, oracle, newton, expo):
                        env=env, timeout=300)
     assert r.returncode == 0, r.stderr
     lines = open(out).read().split("\n")
-    cut, e1, e2 = (float(v) for v in lines[0].split())
+    cut, e1, e2 = (float(v) for v in lines[0].split()[:3])
+    assert int(lines[0].split()[3]) == 0      # quat from the atom style: the pair style does not forward it itself
     vir = np.array([float(v) for v in lines[1].split()])
     ft = np.array([[float(v) for v in ln.split()] for ln in lines[2:] if ln.strip()])
     K, E = coeff_tables(1, 750.0, expo)
@@ -91,6 +92,51 @@ def test_pairsh_adapter_matches_oracle(tmp_path, oracle, newton, expo):
     pa = np.loadtxt(str(out) + ".peratom")
     assert np.abs(pa[:, 0] - o["eatom"]).max() < 1e-9 * o["eatom"].max()
     assert np.abs(pa[:, 1:] - o["vatom"]).max() < 1e-9 * np.abs(o["vatom"]).max()
+
+
+@pytest.mark.gpu
+def test_pairsh_forwards_custom_quaternions_to_ghosts(tmp_path, oracle):
+    """Orientations kept by `fix property/atom d2_quat 4 ghost yes` reach ghosts only at reneighbourings in stock
+    LAMMPS, while the integrator turns the owners every step.  PairSH forwards them itself (comm_forward = 4,
+    pack/unpack_forward_comm, Comm::forward_comm(this) at the top of compute): the bed handed to the host has STALE
+    ghost orientations, the forces must be those of the owners' current ones."""
+    build_host()
+    case = make_case(260, 6, 2, seed=35, rmax_fn=oracle.shape_rmax)
+    n, nlocal = case["n"], 200
+    b = case["bed"]
+    rng = np.random.default_rng(3)
+    owners = rng.integers(0, nlocal, n - nlocal).astype(np.int32)
+    truth = dict(case)
+    tb = {k: (v.copy() if hasattr(v, "copy") else v) for k, v in b.items()}
+    tb["quat"][nlocal:] = tb["quat"][owners]           # what the ghosts' orientations must be
+    tb["shtype"][nlocal:] = tb["shtype"][owners]
+    truth["bed"] = tb
+    # rows of the half list: owned i only (newton on: ghost forces are computed too)
+    truth["ilist"] = case["ilist"][:nlocal]
+    truth["jlist"] = case["jlist"][:case["offsets"][nlocal]]
+    truth["offsets"] = case["offsets"][:nlocal + 1]
+    stale = dict(truth)
+    sb = {k: (v.copy() if hasattr(v, "copy") else v) for k, v in tb.items()}
+    sb["quat"][nlocal:] = np.array([1.0, 0.0, 0.0, 0.0])   # as after borders(), before the owners were turned
+    stale["bed"] = sb
+    bedf, shapes = write_inputs(tmp_path, stale, nlocal, True, False)
+    gof = tmp_path / "ghost_owners.txt"
+    np.savetxt(gof, owners, fmt="%d")
+    out = tmp_path / "out.txt"
+    env = dict(os.environ, LAMMPS_HOST_GHOST_OWNERS=str(gof))
+    r = subprocess.run([HOST, bedf, str(out), "12", "750.0", "1.25", *shapes], capture_output=True, text=True, env=env,
+                       timeout=300)
+    assert r.returncode == 0, r.stderr
+    lines = open(out).read().split("\n")
+    assert int(lines[0].split()[3]) == 2                 # one forward per compute() call
+    ft = np.array([[float(v) for v in ln.split()] for ln in lines[2:] if ln.strip()])
+    K, E = coeff_tables(1, 750.0, 1.25)
+    o = oracle_compute(oracle, truth, 12, K, E, nlocal=nlocal, newton_pair=True)
+    o_stale = oracle_compute(oracle, stale, 12, K, E, nlocal=nlocal, newton_pair=True)
+    fs = np.abs(o["f"]).max()
+    assert np.abs(o_stale["f"] - o["f"]).max() > 1e-3 * fs       # the stale orientations would have been visibly wrong
+    assert np.abs(ft[:, :3] - o["f"]).max() < 1e-9 * fs
+    assert np.abs(ft[:, 3:] - o["torque"]).max() < 1e-9 * max(fs, np.abs(o["torque"]).max())
 
 
 @pytest.mark.gpu
