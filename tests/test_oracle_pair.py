@@ -248,3 +248,64 @@ def test_pair_against_independent_numpy_implementation(oracle):
         assert nin == diag[0] and nin > 20
         assert abs(o[0] - V) < 1e-6 * V   # deep overlap (V = 12 % of a particle); shallow contacts: ~2e-8
         assert diag[2] / diag[0] < 4.0    # evaluations per inside node
+
+
+def _rotate_pair(Q, xi, qi, xj, qj):
+    """The whole pair turned by the rotation quaternion Q about x_i."""
+    w, x, y, z = Q
+    R = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)],
+                  [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+                  [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
+    return R, xi, qmul(Q, qi), xi + R @ (xj - xi), qmul(Q, qj)
+
+
+def test_rotation_about_the_pair_axis_by_a_node_spacing_is_exact(oracle):
+    """Whole-pair rotation covariance, as far as the discrete rule has it: the cap nodes sit at n_psi
+    equally spaced azimuths about the pair axis, so a rigid rotation of both bodies about that axis by a multiple of
+    2 pi / n_psi maps the node set onto itself.  V is then unchanged and S_n, T_n turn with the bodies to rounding.
+    (For a general rotation the frame (e1, e2) of SPEC §2.3 does not turn with the pair, the nodes land elsewhere on
+    the surfaces and the sums differ by the quadrature error: next test.)"""
+    lmax, nq = 6, 12
+    a, b = shapes.random_shape(lmax, 21, amp=0.3), shapes.random_shape(lmax, 22, amp=0.3)
+    ra, rb = oracle.shape_rmax(lmax, a), oracle.shape_rmax(lmax, b)
+    rng = np.random.default_rng(4)
+    for trial in range(6):
+        qi = rng.normal(size=4); qi /= np.linalg.norm(qi)
+        qj = rng.normal(size=4); qj /= np.linalg.norm(qj)
+        c = rng.normal(size=3); c /= np.linalg.norm(c)
+        xi = rng.normal(size=3)
+        xj = xi + rng.uniform(1.3, 1.9) * c
+        _, o1, _ = oracle.pair(lmax, a, ra, lmax, b, rb, xi, qi, xj, qj, nq)
+        assert o1[0] > 0
+        k = 1 + trial
+        Q = rot_quat(c, 2 * np.pi * k / (2 * nq))
+        R, xi2, qi2, xj2, qj2 = _rotate_pair(Q, xi, qi, xj, qj)
+        assert np.abs(xj2 - xj).max() < 1e-14          # the axis is fixed
+        _, o2, _ = oracle.pair(lmax, a, ra, lmax, b, rb, xi2, qi2, xj, qj2, nq)
+        sc = np.abs(o1).max()
+        assert abs(o2[0] - o1[0]) < 1e-12 * sc
+        assert np.abs(o2[1:4] - R @ o1[1:4]).max() < 1e-12 * sc and np.abs(o2[4:7] - R @ o1[4:7]).max() < 1e-12 * sc
+
+
+def test_general_rotation_is_covariant_to_quadrature_accuracy(oracle):
+    lmax = 5
+    a, b = shapes.random_shape(lmax, 31, amp=0.25), shapes.random_shape(lmax, 32, amp=0.25)
+    ra, rb = oracle.shape_rmax(lmax, a), oracle.shape_rmax(lmax, b)
+    rng = np.random.default_rng(8)
+    dev = {}
+    for nq in (8, 48):
+        worst = 0.0
+        for _ in range(5):
+            qi = rng.normal(size=4); qi /= np.linalg.norm(qi)
+            qj = rng.normal(size=4); qj /= np.linalg.norm(qj)
+            c = rng.normal(size=3); c /= np.linalg.norm(c)
+            xi = rng.normal(size=3)
+            xj = xi + 1.6 * c
+            Q = rng.normal(size=4); Q /= np.linalg.norm(Q)
+            R, xi2, qi2, xj2, qj2 = _rotate_pair(Q, xi, qi, xj, qj)
+            _, o1, _ = oracle.pair(lmax, a, ra, lmax, b, rb, xi, qi, xj, qj, nq)
+            _, o2, _ = oracle.pair(lmax, a, ra, lmax, b, rb, xi2, qi2, xj2, qj2, nq)
+            s = np.linalg.norm(o1[1:4])
+            worst = max(worst, np.linalg.norm(o2[1:4] - R @ o1[1:4]) / s, abs(o2[0] - o1[0]) / o1[0])
+        dev[nq] = worst
+    assert dev[48] < 2e-2 and dev[48] < 0.5 * dev[8], dev

@@ -97,3 +97,32 @@ def test_ellipsoid_projection_is_close_to_the_ellipsoid():
     anm = shapes.ellipsoid(1.0, 0.8, 0.6, lmax=8)
     r = shapes.sh_radius_np(8, anm, np.eye(3))
     assert np.allclose(r, [1.0, 0.8, 0.6], atol=0.02)
+
+
+@pytest.mark.parametrize("lmax", [4, 12, 20])
+def test_single_harmonics_against_mpmath_at_50_digits(oracle, lmax):
+    """spot values of Y_nm (hence of the Legendre recurrence with its normalisation and
+    Condon-Shortley phase) against mpmath at 50 digits, every (n, m) of the order, directions including near-polar
+    ones; the library's host helper (shpair_shape_radius) is held to the same values."""
+    import mpmath
+    from shpair import capi
+    mpmath.mp.dps = 50
+    rng = np.random.default_rng(7 + lmax)
+    dirs = [(np.arccos(rng.uniform(-1, 1)), rng.uniform(0, 2 * np.pi)) for _ in range(3)] + [(1e-3, 0.7), (np.pi - 2e-3, 4.1)]
+    nt = shapes.nterms(lmax)
+    worst = 0.0
+    for n in range(lmax + 1):
+        for m in range(n + 1):
+            k = n * (n + 1) // 2 + m
+            for part in ((0, 1) if m > 0 else (0,)):          # a_nm = 1, then a_nm = i
+                anm = np.zeros((nt, 2))
+                anm[k, part] = 1.0
+                for th, ph in dirs:
+                    y = mpmath.spherharm(n, m, mpmath.mpf(float(th)), mpmath.mpf(float(ph)))
+                    a = mpmath.mpc(1, 0) if part == 0 else mpmath.mpc(0, 1)
+                    ref = float(((1 if m == 0 else 2) * a * y).real)
+                    u = [np.sin(th) * np.cos(ph), np.sin(th) * np.sin(ph), np.cos(th)]
+                    worst = max(worst, abs(oracle.sh_eval(lmax, anm.ravel(), u) - ref),
+                                abs(capi.shape_radius(lmax, anm.ravel(), u) - ref))
+    # |Y_nm| <= sqrt((2n+1)/4pi) ~ 1.8 at n = 20; the direction itself is rounded to double first
+    assert worst < 2e-13, worst
