@@ -38,7 +38,7 @@ def test_single_gpu_line_has_the_contract_fields():
     assert 60.0 < vf["peak_measured"] < 80.0 and abs(vf["frac_of_measured"] - vf["achieved"] / vf["peak_measured"]) < 1e-12
     assert abs(d["value"] * d["ms_per_step"] * 1e-3 - d["config"]["contact_pairs_all_ranks"]) < 1e-6 * d["config"]["contact_pairs_all_ranks"]
     cb = d["cpu_baseline"]
-    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["unit"] == d["unit"]
+    assert cb["kind"] == "port" and "tuned" in cb["variant"] and cb["max_rel_dev_from_oracle"] < 1e-11 and cb["cores"] >= 1 and cb["value"] > 0 and cb["unit"] == d["unit"]
     assert d["occupancy"]["waves_per_cu"] >= 16 and d["occupancy"]["scratch_bytes"] == 0
     ts = d["timestep"]
     assert ts["timesteps_per_s"] > 0 and ts["steps"] == 10 and ts["particles"] > 15000
