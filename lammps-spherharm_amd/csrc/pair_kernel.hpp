@@ -64,6 +64,11 @@ struct PairParams {
   const int* xcol;       // ... and absolute column indices
   const int* xinfo;      // (lmax+1)^2: l | (m + l) << 8
   const double* gscale;  // (lmax+1)^2 ring-recurrence scale g_lm
+  // per-pair records written by pair_setup_kernel (pair_setup.hpp), read here instead of redoing the scalar set-up on
+  // 64 lanes: rec[kRecStride * w] = the pair frame FR_* and the Euler cos/sin; rec_i[4 w] = status, shape i, shape j,
+  // [rho < R_j]
+  const double* rec;
+  const int* rec_i;
   int wave_lds_bytes;    // dynamic LDS per wave (wave_lds_layout)
   int ring_rows;         // quadrature rings whose tables are resident at a time (<= nq)
   int waves_per_block;
@@ -75,9 +80,9 @@ struct PairParams {
   int rule;             // 0: sharp inside test (SPEC §2.5); 1: covered-fraction weights (SPEC §2.8)
   double* eatom;        // nullable: per-atom energy  [nall], LAMMPS eatom (ev_tally_xyz halves)
   double* vatom;        // nullable: per-atom virial  [nall][6] (xx,yy,zz,xy,xz,yz)
-  const double* trig;   // (cos m psi_l, sin m psi_l) at trig[(m - 2) * trig_stride + 2 l], m = 2..lmax: for one m the
-                        // lanes of a wave read consecutive 16-byte entries (4 cache lines per load, not 20)
-  int trig_stride;      // 4 nq doubles between consecutive m
+  const double* trig;   // (cos, sin)(m psi_l), m = 2..lmax; trig_lmajor(lmax): at trig[l * trig_stride + 2 (m - 2)],
+                        // else at trig[(m - 2) * trig_stride + 2 l]
+  int trig_stride;      // doubles between consecutive azimuths (l-major: 2 (lmax - 1)) / orders (m-major: 4 nq)
   int nq;
   // outputs / flags
   double* ev;           // 7 doubles or null
@@ -91,17 +96,19 @@ struct PairParams {
 constexpr int kMaxWavesPerBlock = 4;
 constexpr int kPairErrShape = 1;  // a shape index outside [0, nshapes) reached the kernel: the pair was skipped
 constexpr int kPairErrType = 2;   // an atom type outside [1, ntypes]
-// The same for the WEIGHTED variant (three-slab window): 5 fits without spills up to L = 6 (A/B at L = 6:
-// n_q = 16 5.29 -> 5.12 ms, n_q = 8 2.45 -> 2.27 ms); from L = 7 it would spill 25-30 VGPRs, so 4 there.
+// Waves per SIMD the register allocator must leave room for, chosen per kernel so that NO kernel spills a vector
+// register or touches scratch (tests/test_kernel_resources.py reads the code objects):
+//   forces-only kernels (no root finder) fit 80 VGPRs = 6 waves up to L = 6;
+//   kernels with the volume path fit 80 VGPRs at L = 0, 1 and 6 and need 96 (5 waves) in between (at 80 they would
+//   spill 1-7 registers; round 1 shipped those with 8-32 bytes of scratch) and from L = 7 on;
+//   the weighted variant (three-slab window) fits 96 VGPRs up to L = 6 except at L = 3 (128: 4 waves), 128 beyond.
+// Interleaved A/B of 6 against 5 waves where both compile clean (round 1): L = 6, n_q = 16 +1 %, n_q = 8 +7 %.
 #ifndef SHP_WMIN_WAVES
-#define SHP_WMIN_WAVES(L) (((L) >= 0 && (L) <= 6) ? 5 : 4)
+#define SHP_WMIN_WAVES(L) (((L) >= 0 && (L) <= 6 && (L) != 3) ? 5 : 4)
 #endif
-// Waves per SIMD the register allocator must leave room for.  Up to L = 6 the sharp kernels fit 80 VGPRs (6 waves)
-// with at most one spilled value; interleaved A/B against 5 waves (96 VGPRs): L = 4, n_q = 10 +3 %, L = 5,
-// n_q = 12 +4.5 %, L = 6, n_q = 8 +7 %, L = 6, n_q = 16 +1 % (there LDS, 7.5 KB per wave, already limits a CU to
-// 21 waves).  From L = 7 on, 80 VGPRs would spill 70+ bytes: 5 waves.
 #ifndef SHP_MIN_WAVES
-#define SHP_MIN_WAVES(L) (((L) >= 0 && (L) <= 6) ? 6 : 5)
+#define SHP_MIN_WAVES(L, NEEDV) \
+  ((NEEDV) ? (((L) == 0 || (L) == 1 || (L) == 6) ? 6 : 5) : (((L) >= 0 && (L) <= 6) ? 6 : 5))
 #endif
 
 // docs/SPEC.md §2.6: residual below which the inverse-quadratic extrapolation is accepted
@@ -118,11 +125,14 @@ constexpr int kPairErrType = 2;   // an atom type outside [1, ntypes]
 //                        leaves the CU enough waves, else the cap is processed in ring groups.
 //   qri[kQueue], qrj[kQueue], qp[kQueue] (int)   queue of inside nodes
 constexpr int kQueue = 128;  // entries; a slab adds <= 64 to a queue holding < 64
-constexpr int kFrame = 32;
+constexpr int kFrame = 40;
+constexpr int kRecStride = 40;   // doubles per pair record: the first kRecUsed are copied into the frame
+constexpr int kRecUsed = 37;
 // per-pair scalars live in the frame too: as VALU results they would sit in VGPR pairs for
 // the whole kernel (wave-uniform FP64 values cannot be SGPRs without readfirstlane)
 enum { FR_BJ1 = 0, FR_BJ2 = 3, FR_BJC = 6, FR_DJ = 9, FR_E1 = 12, FR_E2 = 15, FR_C = 18, FR_D = 21,
-       FR_RJ = 24, FR_RJ2 = 25, FR_RHO2 = 26, FR_HW = 27, FR_HM = 28, FR_WSC = 29 };
+       FR_RJ = 24, FR_RJ2 = 25, FR_RHO2 = 26, FR_HW = 27, FR_HM = 28, FR_WSC = 29,
+       FR_EULER = 30 /* cos, sin of alpha, beta, gamma */, FR_RHO = 36 };
 
 struct WaveLdsLayout {
   int trig, v0, v1, ring, qri, qrj, qp, bytes;  // offsets in doubles (qp: in doubles too), total bytes
@@ -241,51 +251,23 @@ __device__ __forceinline__ double pow_quarter(const double v, const double e)
 // axis of a vanishing tilt.
 template <int L>
 __device__ __forceinline__ void cap_frame_rotate(const PairParams& P, double* __restrict__ lw, const WaveLdsLayout& W,
-                                                 const int LL, const int si, const int lane, const double* b1,
-                                                 const double* b2, const double* bc)
+                                                 const int LL, const int si, const int lane)
 {
   const int ns = (LL + 1) * (LL + 1);
   double* trig = lw + W.trig;
   double* v0 = lw + W.v0;
   double* v1 = lw + W.v1;
-  // Euler angles: lanes 0,1,2 tabulate cos/sin(m angle) for alpha, beta, gamma
-  {
-    // sin(beta) from the x,y components of the pole, NOT sqrt(1 - cos^2): near the poles the
-    // latter is quantised at 1e-8 and rotates by a wrong tilt (4.8e-9 in r at L = 6, caught by
-    // tests/test_host_tables.py)
-    const double cb = bc[2];
-    const double sb2 = bc[0] * bc[0] + bc[1] * bc[1];
-    double sb = 0.0, ca = 1.0, sa = 0.0;
-    if (sb2 > 1e-280) {  // below: exactly polar (and v_rsq_f64 would meet a denormal)
-      const double n = rsqrt_nr(sb2);
-      sb = sb2 * n;
-      ca = bc[0] * n;
-      sa = bc[1] * n;
-    }
-    double cg, sg;
-    if (cb >= 0.0) {
-      const double iv = rcp_nr(1.0 + cb);
-      const double cs = (b1[0] + b2[1]) * iv, ss = (b1[1] - b2[0]) * iv;  // alpha + gamma
-      cg = cs * ca + ss * sa;
-      sg = ss * ca - cs * sa;
-    } else {
-      const double iv = rcp_nr(1.0 - cb);
-      const double cd = -(b1[0] - b2[1]) * iv, sd = -(b1[1] + b2[0]) * iv;  // alpha - gamma
-      cg = ca * cd + sa * sd;
-      sg = sa * cd - ca * sd;
-    }
-    if (lane < 3) {
-      const double c1 = lane == 0 ? ca : (lane == 1 ? cb : cg);
-      const double s1 = lane == 0 ? sa : (lane == 1 ? sb : sg);
-      double* t = trig + 2 * (LL + 1) * lane;
-      double cm = 1.0, sm = 0.0;
-      for (int m = 0; m <= LL; ++m) {
-        t[2 * m] = cm;
-        t[2 * m + 1] = sm;
-        const double c = fma(cm, c1, -(sm * s1)), s = fma(cm, s1, sm * c1);
-        cm = c;
-        sm = s;
-      }
+  // Euler angles (computed per pair by pair_setup_kernel): lanes 0,1,2 tabulate cos/sin(m angle) for alpha, beta, gamma
+  if (lane < 3) {
+    const double c1 = lw[FR_EULER + 2 * lane], s1 = lw[FR_EULER + 2 * lane + 1];
+    double* t = trig + 2 * (LL + 1) * lane;
+    double cm = 1.0, sm = 0.0;
+    for (int m = 0; m <= LL; ++m) {
+      t[2 * m] = cm;
+      t[2 * m + 1] = sm;
+      const double c = fma(cm, c1, -(sm * s1)), s = fma(cm, s1, sm * c1);
+      cm = c;
+      sm = s;
     }
   }
   wave_lds_sync();
@@ -375,6 +357,12 @@ __device__ __forceinline__ void cap_frame_rings(const PairParams& P, double* __r
   wave_lds_sync();
 }
 
+// Layout of the cos/sin(m psi_l) table (host: upload_quadrature).  Up to L = 6 l-major: the orders of one azimuth are
+// adjacent, a lane reads them with immediate offsets from one address (m-major costs a 64-bit address computation per
+// order, ~10 VALU per slab).  Above, m-major: a lane's orders would span 16 (L - 1) > 128 bytes and every wave load
+// would touch one cache line per lane (A/B at L = 12, n_q = 32: l-major +1.8 %), and at L = 7 the l-major form costs a spilled register.
+__host__ __device__ constexpr bool trig_lmajor(int L) { return L >= 2 && L <= 6; }
+
 // r_i (and its mu / psi derivatives) at ring row `row`, azimuth (c1, s1) = (cos psi, sin psi)
 template <int L, bool GRAD>
 __device__ __forceinline__ void ring_eval(const double* __restrict__ row, const int LL, const double c1, const double s1,
@@ -392,8 +380,8 @@ __device__ __forceinline__ void ring_eval(const double* __restrict__ row, const 
 #pragma unroll
   for (int m = 1; m <= lim; ++m) {
     if (L >= 2 && m >= 2) {
-      cm = tr[(m - 2) * tstride];
-      sm = tr[(m - 2) * tstride + 1];
+      cm = tr[trig_lmajor(L) ? 2 * (m - 2) : (m - 2) * tstride];
+      sm = tr[(trig_lmajor(L) ? 2 * (m - 2) : (m - 2) * tstride) + 1];
     }
     const double A = row[4 * m], B = row[4 * m + 1];
     r = fma(A, cm, r);
@@ -418,7 +406,7 @@ __device__ __forceinline__ void ring_eval(const double* __restrict__ row, const 
 // covered fraction together with that fraction; phase 2 scales the node's weight by it.  n_q <= 32 (a ring
 // neighbour is at most one slab away) and ring groups of at least two slabs' worth of rings: checked on the host.
 template <int L, bool NEEDV, bool WEIGHTED = false>
-__global__ void __launch_bounds__(64 * kMaxWavesPerBlock, WEIGHTED ? SHP_WMIN_WAVES(L) : SHP_MIN_WAVES(L)) pair_contact_kernel(const PairParams P)
+__global__ void __launch_bounds__(64 * kMaxWavesPerBlock, WEIGHTED ? SHP_WMIN_WAVES(L) : SHP_MIN_WAVES(L, NEEDV)) pair_contact_kernel(const PairParams P)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int lane = threadIdx.x & 63;
@@ -437,79 +425,25 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, WEIGHTED ? SHP_WMIN_WA
 #define SHP_LDS() ((double*)(smem_raw + launder_u32(wave_off)))
   double* lw = SHP_LDS();
 
+  // the pair's record (pair_setup.hpp): scalar loads of the four ints, one coalesced vector load of the frame
+  const int* rid = P.rec_i + 4 * (size_t)w;
+  const int status = rid[0];
+  if (status == 0) return;   // bounding spheres apart (SPEC §2.1) or a shape index outside the table; wave-uniform
+  const int si = rid[1], sj = rid[2];
+  const bool centre_in_bj = rid[3] != 0;  // rho < Rj
+  if (lane < kRecUsed) lw[lane] = P.rec[(size_t)kRecStride * w + lane];
+  wave_lds_sync();
   const int i = P.pair_i[w];
   const int j = P.pair_j[w];
-  const int si = P.shtype[i], sj = P.shtype[j];
-  if ((unsigned)si >= (unsigned)P.nshapes || (unsigned)sj >= (unsigned)P.nshapes) {  // wave-uniform
-    if (lane == 0) atomicOr(P.err, kPairErrShape);
-    return;
-  }
-  const double Ri = P.rmax[si], Rj = P.rmax[sj];
-  double rho2, rho, cosa;
-  bool centre_in_bj;  // rho < Rj
-  {
-    const double d0 = P.x[3 * j] - P.x[3 * i], d1 = P.x[3 * j + 1] - P.x[3 * i + 1],
-                 d2 = P.x[3 * j + 2] - P.x[3 * i + 2];
-    rho2 = d0 * d0 + d1 * d1 + d2 * d2;
-    rho = sqrt(rho2);  // IEEE: decides the pair (SPEC §2.1) exactly as the oracle does
-    if (rho >= Ri + Rj) return;  // SPEC §2.1, wave-uniform
-    centre_in_bj = rho < Rj;
-
-    // SPEC §2.2 cap.  The branch conditions are exact; the value only places the nodes, so Newton-refined
-    // reciprocals / roots (1-2 ulp) do instead of the IEEE sequences (both branches are evaluated: ~40 instructions)
-    const double irho = rcp_nr(rho);
-    const double pj = rho2 - Rj * Rj;
-    if (rho <= Rj) cosa = -1.0;
-    else if (pj <= Ri * Ri) cosa = sqrt_nr(fmax(pj, 0.0)) * irho;
-    else cosa = (pj + Ri * Ri) * (0.5 * irho * rcp_nr(Ri));
-
-    // SPEC §2.3 frame (space)
-    const double c0 = d0 * irho, c1 = d1 * irho, c2 = d2 * irho;
-    const double sg = copysign(1.0, c2);
-    const double aa = -rcp_nr(sg + c2);
-    const double bb = c0 * c1 * aa;
-    const double e10 = 1.0 + sg * c0 * c0 * aa, e11 = sg * bb, e12 = -sg * c0;
-    const double e20 = bb, e21 = sg + c1 * c1 * aa, e22 = -c1;
-
-    double Rmi[9], Rmj[9];
-    quat_to_mat(P.quat[4 * i], P.quat[4 * i + 1], P.quat[4 * i + 2], P.quat[4 * i + 3], Rmi);
-    quat_to_mat(P.quat[4 * j], P.quat[4 * j + 1], P.quat[4 * j + 2], P.quat[4 * j + 3], Rmj);
-
-    // the cap axes in i's body frame (columns of M) and in j's body frame, d in j's frame
-    double b1[3], b2[3], bc[3];
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-      b1[a] = Rmi[a] * e10 + Rmi[3 + a] * e11 + Rmi[6 + a] * e12;
-      b2[a] = Rmi[a] * e20 + Rmi[3 + a] * e21 + Rmi[6 + a] * e22;
-      bc[a] = Rmi[a] * c0 + Rmi[3 + a] * c1 + Rmi[6 + a] * c2;
-    }
-    if (lane == 0) {
-#pragma unroll
-      for (int a = 0; a < 3; ++a) {
-        lw[FR_BJ1 + a] = Rmj[a] * e10 + Rmj[3 + a] * e11 + Rmj[6 + a] * e12;
-        lw[FR_BJ2 + a] = Rmj[a] * e20 + Rmj[3 + a] * e21 + Rmj[6 + a] * e22;
-        lw[FR_BJC + a] = Rmj[a] * c0 + Rmj[3 + a] * c1 + Rmj[6 + a] * c2;
-        lw[FR_DJ + a] = Rmj[a] * d0 + Rmj[3 + a] * d1 + Rmj[6 + a] * d2;
-      }
-      lw[FR_E1] = e10; lw[FR_E1 + 1] = e11; lw[FR_E1 + 2] = e12;
-      lw[FR_E2] = e20; lw[FR_E2 + 1] = e21; lw[FR_E2 + 2] = e22;
-      lw[FR_C] = c0; lw[FR_C + 1] = c1; lw[FR_C + 2] = c2;
-      lw[FR_D] = d0; lw[FR_D + 1] = d1; lw[FR_D + 2] = d2;
-      lw[FR_RJ] = Rj; lw[FR_RJ2] = Rj * Rj; lw[FR_RHO2] = rho2;
-      const double hw0 = 0.5 * (1.0 - cosa);
-      lw[FR_HW] = hw0; lw[FR_HM] = 0.5 * (1.0 + cosa);
-      lw[FR_WSC] = hw0 * (6.283185307179586476925286766559 / (double)(2 * nq));  // hw dpsi
-    }
 #if defined(SHP_ABL) && SHP_ABL == 1   // timing-only build: stop after the pair prologue
-    asm volatile("" ::"v"(b1[0] + b2[1] + bc[2]));
-    return;
+  asm volatile("" ::"v"(lw[lane & 31]));
+  return;
 #endif
-    cap_frame_rotate<L>(P, lw, W, LL, si, lane, b1, b2, bc);
+  cap_frame_rotate<L>(P, lw, W, LL, si, lane);
 #if defined(SHP_ABL) && SHP_ABL == 4   // timing-only build: stop after the coefficient rotation
-    asm volatile("" ::"v"(lw[W.v0 + lane]));
-    return;
+  asm volatile("" ::"v"(lw[W.v0 + lane]));
+  return;
 #endif
-  }
 
   const double* rc = P.rc;
 #ifndef SHP_COEF_LDS
@@ -530,6 +464,7 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, WEIGHTED ? SHP_WMIN_WA
   // SPEC §2.6: centre of i inside j (only possible when rho < Rj)
   bool centre_inside = false;
   if (NEEDV && centre_in_bj) {
+    const double rho = fr[FR_RHO];
     const double ir = rcp_nr(rho);
     const double rj = sh_eval<L>(rc, cwj, lrt, -fr[FR_DJ] * ir, -fr[FR_DJ + 1] * ir, -fr[FR_DJ + 2] * ir);
     centre_inside = (rho - rj <= 0.0);
@@ -589,7 +524,7 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, WEIGHTED ? SHP_WMIN_WA
         const double mu = row[1], sig = row[3];
         const double c1 = P.cpsi[l], s1 = P.spsi[l];
         double ri, t0, t1;
-        ring_eval<L, false>(row, LL, c1, s1, P.trig + 2 * l, P.trig_stride, ri, t0, t1);
+        ring_eval<L, false>(row, LL, c1, s1, P.trig + (trig_lmajor(L) ? (size_t)P.trig_stride * l : (size_t)(2 * l)), P.trig_stride, ri, t0, t1);
         const double a1 = sig * c1, a2 = sig * s1;
         const double uj0 = fma(a1, fr[FR_BJ1], fma(a2, fr[FR_BJ2], mu * fr[FR_BJC]));
         const double uj1 = fma(a1, fr[FR_BJ1 + 1], fma(a2, fr[FR_BJ2 + 1], mu * fr[FR_BJC + 1]));
@@ -683,7 +618,7 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, WEIGHTED ? SHP_WMIN_WA
       const double mu = row[1], sig = row[3];
       const double c1 = P.cpsi[l], s1 = P.spsi[l];
       double ri, t0, t1;
-      ring_eval<L, false>(row, LL, c1, s1, P.trig + 2 * l, P.trig_stride, ri, t0, t1);
+      ring_eval<L, false>(row, LL, c1, s1, P.trig + (trig_lmajor(L) ? (size_t)P.trig_stride * l : (size_t)(2 * l)), P.trig_stride, ri, t0, t1);
       // the surface point seen from x_j, in j's body frame
       const double a1 = sig * c1, a2 = sig * s1;
       const double uj0 = fma(a1, fr[FR_BJ1], fma(a2, fr[FR_BJ2], mu * fr[FR_BJC]));
@@ -850,7 +785,7 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, WEIGHTED ? SHP_WMIN_WA
     //   u = (sigma c, sigma s, mu), gamma^ = (mu c, mu s, -sigma), psi^ = (-s, c, 0)
     fr = SHP_LDS();
     double r2, rmu, rpsi;
-    ring_eval<L, true>(fr + W.ring + (k - k0) * rowlen, LL, c1, s1, P.trig + 2 * l, P.trig_stride, r2, rmu, rpsi);
+    ring_eval<L, true>(fr + W.ring + (k - k0) * rowlen, LL, c1, s1, P.trig + (trig_lmajor(L) ? (size_t)P.trig_stride * l : (size_t)(2 * l)), P.trig_stride, r2, rmu, rpsi);
     const double rad = ri * fma(ri, sig, rmu * sig * mu);   // r (r sigma + sigma mu r_mu): multiplies (c, s)
     const double tan_ = ri * rpsi / sig;                   // (r / sigma) r_psi
     const double A0 = fma(rad, c1, tan_ * s1);

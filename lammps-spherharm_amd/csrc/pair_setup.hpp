@@ -1,0 +1,126 @@
+// pair_setup.hpp — per-pair scalar set-up of the contact kernel, ONE LANE PER PAIR.
+//
+// Everything the contact kernel needs that depends on the pair as a whole (docs/SPEC.md §2.1-2.3: bounding-sphere
+// reject, cap angle, the frame (e1, e2, c), the cap axes and the separation in j's body frame, the Euler angles of
+// the cap frame in i's body frame) is wave-uniform there: computed in the contact kernel it costs ~300 FP64
+// instructions per pair ISSUED ON 64 LANES for one lane's worth of work (no scalar FP64 unit on gfx950).  Here the
+// same arithmetic runs with one pair per lane — 1/64 of the vector issue — and leaves a 320-byte record per pair that
+// the contact kernel picks up with one coalesced load (pair_kernel.hpp).  HBM bound: 56 B gathered per atom of the
+// pair, 336 B written per pair.
+// Included by shpair_api.hip only (the kernel is not a template: one definition per library).
+#pragma once
+#include "pair_kernel.hpp"
+
+namespace shp {
+
+constexpr int kSetupBlock = 256;
+
+__global__ __launch_bounds__(kSetupBlock) void pair_setup_kernel(const PairParams P, double* __restrict__ rec,
+                                                                  int* __restrict__ rec_i)
+{
+  const int w = blockIdx.x * kSetupBlock + threadIdx.x;
+  if (w >= P.npairs) return;
+  int* ri = rec_i + 4 * (size_t)w;
+  const int i = P.pair_i[w], j = P.pair_j[w];
+  const int si = P.shtype[i], sj = P.shtype[j];
+  ri[1] = si;
+  ri[2] = sj;
+  if ((unsigned)si >= (unsigned)P.nshapes || (unsigned)sj >= (unsigned)P.nshapes) {
+    atomicOr(P.err, kPairErrShape);
+    ri[0] = 0;
+    ri[3] = 0;
+    return;
+  }
+  const double Ri = P.rmax[si], Rj = P.rmax[sj];
+  const double d0 = P.x[3 * j] - P.x[3 * i], d1 = P.x[3 * j + 1] - P.x[3 * i + 1], d2 = P.x[3 * j + 2] - P.x[3 * i + 2];
+  const double rho2 = d0 * d0 + d1 * d1 + d2 * d2;
+  const double rho = sqrt(rho2);  // IEEE: decides the pair (SPEC §2.1) exactly as the oracle does
+  if (rho >= Ri + Rj) {
+    ri[0] = 0;
+    ri[3] = 0;
+    return;
+  }
+  ri[0] = 1;
+  ri[3] = rho < Rj ? 1 : 0;
+
+  // SPEC §2.2 cap.  The branch conditions are exact; the value only places the nodes, so Newton-refined
+  // reciprocals / roots (1-2 ulp) do instead of the IEEE sequences
+  const double irho = rcp_nr(rho);
+  const double pj = rho2 - Rj * Rj;
+  double cosa;
+  if (rho <= Rj) cosa = -1.0;
+  else if (pj <= Ri * Ri) cosa = sqrt_nr(fmax(pj, 0.0)) * irho;
+  else cosa = (pj + Ri * Ri) * (0.5 * irho * rcp_nr(Ri));
+
+  // SPEC §2.3 frame (space)
+  const double c0 = d0 * irho, c1 = d1 * irho, c2 = d2 * irho;
+  const double sg = copysign(1.0, c2);
+  const double aa = -rcp_nr(sg + c2);
+  const double bb = c0 * c1 * aa;
+  const double e10 = 1.0 + sg * c0 * c0 * aa, e11 = sg * bb, e12 = -sg * c0;
+  const double e20 = bb, e21 = sg + c1 * c1 * aa, e22 = -c1;
+
+  double Rmi[9], Rmj[9];
+  quat_to_mat(P.quat[4 * i], P.quat[4 * i + 1], P.quat[4 * i + 2], P.quat[4 * i + 3], Rmi);
+  quat_to_mat(P.quat[4 * j], P.quat[4 * j + 1], P.quat[4 * j + 2], P.quat[4 * j + 3], Rmj);
+
+  double* o = rec + (size_t)kRecStride * w;
+  // the cap axes in i's body frame (columns of M) and in j's body frame, d in j's frame
+  double b1[3], b2[3], bc[3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    b1[a] = Rmi[a] * e10 + Rmi[3 + a] * e11 + Rmi[6 + a] * e12;
+    b2[a] = Rmi[a] * e20 + Rmi[3 + a] * e21 + Rmi[6 + a] * e22;
+    bc[a] = Rmi[a] * c0 + Rmi[3 + a] * c1 + Rmi[6 + a] * c2;
+    o[FR_BJ1 + a] = Rmj[a] * e10 + Rmj[3 + a] * e11 + Rmj[6 + a] * e12;
+    o[FR_BJ2 + a] = Rmj[a] * e20 + Rmj[3 + a] * e21 + Rmj[6 + a] * e22;
+    o[FR_BJC + a] = Rmj[a] * c0 + Rmj[3 + a] * c1 + Rmj[6 + a] * c2;
+    o[FR_DJ + a] = Rmj[a] * d0 + Rmj[3 + a] * d1 + Rmj[6 + a] * d2;
+  }
+  o[FR_E1] = e10; o[FR_E1 + 1] = e11; o[FR_E1 + 2] = e12;
+  o[FR_E2] = e20; o[FR_E2 + 1] = e21; o[FR_E2 + 2] = e22;
+  o[FR_C] = c0; o[FR_C + 1] = c1; o[FR_C + 2] = c2;
+  o[FR_D] = d0; o[FR_D + 1] = d1; o[FR_D + 2] = d2;
+  o[FR_RJ] = Rj; o[FR_RJ2] = Rj * Rj; o[FR_RHO2] = rho2;
+  const double hw0 = 0.5 * (1.0 - cosa);
+  o[FR_HW] = hw0; o[FR_HM] = 0.5 * (1.0 + cosa);
+  o[FR_WSC] = hw0 * (6.283185307179586476925286766559 / (double)(2 * P.nq));  // hw dpsi
+  o[FR_RHO] = rho;
+
+  // Euler angles of M = [b1 b2 bc] = Rz(alpha) Ry(beta) Rz(gamma) (pair_kernel.hpp cap_frame_rotate):
+  // sin(beta) from the x,y components of the pole, NOT sqrt(1 - cos^2): near the poles the latter is quantised at
+  // 1e-8 and rotates by a wrong tilt (4.8e-9 in r at L = 6, caught by tests/test_host_tables.py); gamma from the
+  // WELL CONDITIONED sum (cos beta >= 0) or difference of the two angles
+  const double cb = bc[2];
+  const double sb2 = bc[0] * bc[0] + bc[1] * bc[1];
+  double sb = 0.0, ca = 1.0, sa = 0.0;
+  if (sb2 > 1e-280) {  // below: exactly polar (and v_rsq_f64 would meet a denormal)
+    const double n = rsqrt_nr(sb2);
+    sb = sb2 * n;
+    ca = bc[0] * n;
+    sa = bc[1] * n;
+  }
+  double cg, sgm;
+  if (cb >= 0.0) {
+    const double iv = rcp_nr(1.0 + cb);
+    const double cs = (b1[0] + b2[1]) * iv, ss = (b1[1] - b2[0]) * iv;  // alpha + gamma
+    cg = cs * ca + ss * sa;
+    sgm = ss * ca - cs * sa;
+  } else {
+    const double iv = rcp_nr(1.0 - cb);
+    const double cd = -(b1[0] - b2[1]) * iv, sd = -(b1[1] + b2[0]) * iv;  // alpha - gamma
+    cg = ca * cd + sa * sd;
+    sgm = sa * cd - ca * sd;
+  }
+  o[FR_EULER] = ca; o[FR_EULER + 1] = sa;
+  o[FR_EULER + 2] = cb; o[FR_EULER + 3] = sb;
+  o[FR_EULER + 4] = cg; o[FR_EULER + 5] = sgm;
+}
+
+inline void launch_pair_setup(const PairParams& P, double* rec, int* rec_i, hipStream_t st)
+{
+  if (P.npairs <= 0) return;
+  hipLaunchKernelGGL(pair_setup_kernel, dim3((P.npairs + kSetupBlock - 1) / kSetupBlock), dim3(kSetupBlock), 0, st, P, rec, rec_i);
+}
+
+}  // namespace shp

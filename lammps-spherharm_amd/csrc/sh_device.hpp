@@ -95,6 +95,20 @@ __device__ __forceinline__ double horner_step(const double w, const double z, co
 #endif
 }
 
+// w + c with the wave-uniform c as the SGPR operand of one v_add_f64.  Without it the compiler contracts the first
+// two Horner steps (c0 z) + c1 into an FMA whose addend must be a VGPR, and copies c1 there first: two v_mov_b32 and a
+// v_fmac_f64 instead of a v_mul_f64 and a v_add_f64 (26 v_mov_b32 per radius evaluation at L = 6).
+__device__ __forceinline__ double sgpr_add(const double w, const double c)
+{
+#ifndef SHP_COEF_LDS
+  double o;
+  asm("v_add_f64 %0, %1, %2" : "=v"(o) : "v"(w), "s"(c));
+  return o;
+#else
+  return w + c;
+#endif
+}
+
 // Compiled orders evaluate W_m(z) in MONOMIAL form by Horner (coefficients in descending powers,
 // built on the host in long double, sh_tables.cpp: build_monomial): one v_fma_f64 per coefficient
 // and accumulator instead of the recurrence's mul + fma + fmac, and no recurrence constants at
@@ -118,8 +132,8 @@ __device__ __forceinline__ void sh_term(const double cr, const double ci, const 
       s.Wi = ci;
     }
   } else if constexpr (K == 1) {
-    s.Wr = s.Wr + cr;                       // c0 z + c1
-    if constexpr (M > 0) s.Wi = s.Wi + ci;
+    s.Wr = sgpr_add(s.Wr, cr);              // c0 z + c1
+    if constexpr (M > 0) s.Wi = sgpr_add(s.Wi, ci);
   } else {
     s.Wr = horner_step(s.Wr, z, cr);
     if constexpr (M > 0) s.Wi = horner_step(s.Wi, z, ci);

@@ -17,6 +17,7 @@
 #include "../../include/shpair.h"
 #include "fp64_peak.hpp"
 #include "pair_kernel.hpp"
+#include "pair_setup.hpp"
 #include "shpair_ctx.hpp"
 #include "sh_const.hpp"
 #include "sh_tables.hpp"
@@ -128,7 +129,7 @@ void shpair_destroy(shpair_ctx* c)
   c->d_creal.release(); c->d_xval.release(); c->d_gscale.release(); c->d_xcol.release(); c->d_xinfo.release();
   c->d_x.release(); c->d_quat.release(); c->d_f.release(); c->d_torque.release(); c->d_ev.release();
   c->d_type.release(); c->d_shtype.release(); c->d_counters.release(); c->d_flags.release();
-  c->d_eatom.release(); c->d_vatom.release(); c->d_list.release(); c->d_err.release();
+  c->d_eatom.release(); c->d_vatom.release(); c->d_list.release(); c->d_err.release(); c->d_rec.release(); c->d_rec_i.release();
   if (c->h_list) (void)hipHostFree(c->h_list);
   if (c->h_err) (void)hipHostFree(c->h_err);
   if (c->h_ev) (void)hipHostFree(c->h_ev);
@@ -267,6 +268,8 @@ static int upload_staged_list(shpair_ctx* c, int inum, size_t tot, int max_index
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipStreamSynchronize(c->stream));
   }
+  HIPCHK(c, c->d_rec.ensure((tot ? tot : 1) * kRecStride));
+  HIPCHK(c, c->d_rec_i.ensure((tot ? tot : 1) * 4));
   c->npairs = (int)tot;
   c->max_atom_index = max_index;
   c->have_neighbors = true;
@@ -368,6 +371,8 @@ int shpair_set_neighbors_device(shpair_ctx* c, int inum, const int* ilist, const
                        offsets, jlist, inum, c->d_pair_i.p, c->d_pair_j.p);
     HIPCHK(c, hipGetLastError());
   }
+  HIPCHK(c, c->d_rec.ensure((size_t)(npairs ? npairs : 1) * kRecStride));
+  HIPCHK(c, c->d_rec_i.ensure((size_t)(npairs ? npairs : 1) * 4));
   c->npairs = npairs;
   c->max_atom_index = max_atom_index;
   c->have_neighbors = true;
@@ -464,8 +469,10 @@ static int upload_quadrature(shpair_ctx* c)
     q[2 * nq + l] = std::cos(psi);
     q[2 * nq + npsi + l] = std::sin(psi);
     for (int m = 2; m <= c->lmax; ++m) {
-      q[2 * nq + 2 * npsi + ((size_t)(m - 2) * npsi + l) * 2] = std::cos(m * psi);
-      q[2 * nq + 2 * npsi + ((size_t)(m - 2) * npsi + l) * 2 + 1] = std::sin(m * psi);
+      // layout: pair_kernel.hpp trig_lmajor()
+      const size_t e = trig_lmajor(c->lmax) ? ((size_t)l * nm + (m - 2)) : ((size_t)(m - 2) * npsi + l);
+      q[2 * nq + 2 * npsi + 2 * e] = std::cos(m * psi);
+      q[2 * nq + 2 * npsi + 2 * e + 1] = std::sin(m * psi);
     }
   }
   HIPCHK(c, hipDeviceSynchronize());  // as in upload_tables
@@ -570,7 +577,7 @@ int shpair_compute_device(shpair_ctx* c, int nlocal, int nghost, const double* x
   P.vatom = c->vatom_dev;
   P.nq = nq;
   P.trig = c->d_quad.p + 6 * nq;
-  P.trig_stride = 4 * nq;
+  P.trig_stride = trig_lmajor(c->lmax) ? 2 * (c->lmax - 1) : 4 * nq;
   P.creal = c->d_creal.p; P.xval = c->d_xval.p; P.xcol = c->d_xcol.p; P.xinfo = c->d_xinfo.p; P.gscale = c->d_gscale.p;
   {
     // Resident ring rows: all nq if a wave then needs <= 8 KB of LDS (five 4-wave workgroups per CU,
@@ -634,7 +641,14 @@ int shpair_compute_device(shpair_ctx* c, int nlocal, int nghost, const double* x
   }
   const bool needv = c->opt_force_volume || eflag || c->any_nonunit_exponent || c->eatom_dev != nullptr;
   c->last_needv = needv;
+  // per-pair records (pair_setup.hpp); the buffers are sized when a list is installed, so nothing is allocated here
+  // unless a caller swapped the list behind the context's back
+  HIPCHK(c, c->d_rec.ensure((size_t)c->npairs * kRecStride));
+  HIPCHK(c, c->d_rec_i.ensure((size_t)c->npairs * 4));
+  P.rec = c->d_rec.p;
+  P.rec_i = c->d_rec_i.p;
   if (c->opt_timing) HIPCHK(c, hipEventRecord(c->ev0, st));
+  launch_pair_setup(P, c->d_rec.p, c->d_rec_i.p, st);
   if (c->lmax <= kMaxUnrolledL && c->opt_variant != 1) {
     P.coef = c->d_coefm.p;  // compiled orders read the monomial (Horner) table
     kLaunch[c->lmax](P, needv, st);

@@ -61,6 +61,8 @@ struct shpair_ctx {
   shp::DevBuf<double> d_rc, d_coef, d_coefm, d_rmax, d_kn, d_expo, d_quad, d_creal, d_xval, d_gscale;
   shp::DevBuf<int> d_xcol, d_xinfo;
   shp::DevBuf<int> d_pair_i, d_pair_j;
+  shp::DevBuf<double> d_rec;  // per-pair records of pair_setup.hpp, kRecStride doubles per list slot
+  shp::DevBuf<int> d_rec_i;   // 4 ints per list slot
   int npairs = 0;
   int max_atom_index = -1;  // largest i or j in the uploaded list
   bool have_neighbors = false;

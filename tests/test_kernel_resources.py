@@ -1,0 +1,56 @@
+"""Static resources of every kernel in libshpair.so, read from the gfx950 code objects (no GPU needed): no kernel
+may spill a vector register or execute a scratch access — a spilled VGPR turns a register read into a memory round
+trip inside the node loops.  (the volume-path kernels of L = 1..5 shipped with 8-32 bytes of scratch.)"""
+import importlib.util
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _meta():
+    spec = importlib.util.spec_from_file_location("kernel_meta", os.path.join(ROOT, "tools", "kernel_meta.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def test_no_kernel_spills_vector_registers_or_touches_scratch():
+    M = _meta()
+    lib = os.path.join(ROOT, "lammps-spherharm_amd", "shpair", "libshpair.so")
+    ks = M.kernels(lib)
+    scr = M.scratch_instruction_counts(lib)
+    pair = [k for k in ks if "pair_contact_kernel" in k["symbol"]]
+    # one instantiation per compiled order (0..12) and run-time order, x {forces only, volume path} + weighted (0..12)
+    assert len(pair) == 13 * 3 + 2, len(pair)
+    assert len(ks) >= len(pair) + 20           # the integrator / list / halo kernels
+    nominal = []
+    for k in ks:
+        assert k["vgpr_spills"] == 0, k
+        assert scr.get(k["symbol"], 0) == 0, (k["symbol"], "executes scratch accesses")
+        if k["scratch_bytes"]:
+            nominal.append((k["symbol"], k["scratch_bytes"]))
+    # A frame the compiler reserves without ever addressing it (no scratch instruction in the ISA, checked above) is
+    # tolerated for one known instantiation: the forces-only L = 7 kernel (20 bytes; not removable by flags or wave bounds).
+    assert all(re.search(r"pair_contact_kernelILi7ELb0ELb0", s) for s, _ in nominal), nominal
+    # the headline kernel: 80 VGPRs -> 6 waves per SIMD
+    head = [k for k in pair if "ILi6ELb1ELb0E" in k["symbol"]][0]
+    assert head["vgprs"] <= 80 and head["scratch_bytes"] == 0
+
+
+def test_register_budgets_match_the_wave_targets():
+    M = _meta()
+    ks = M.kernels(os.path.join(ROOT, "lammps-spherharm_amd", "shpair", "libshpair.so"))
+    for k in ks:
+        m = re.search(r"pair_contact_kernelILi(n?\\d+)ELb([01])ELb([01])E", k["symbol"])
+        if not m or m.group(1).startswith("n"):
+            continue
+        L, needv, weighted = int(m.group(1)), m.group(2) == "1", m.group(3) == "1"
+        if weighted:
+            waves = 5 if (L <= 6 and L != 3) else 4
+        elif needv:
+            waves = 6 if L in (0, 1, 6) else 5
+        else:
+            waves = 6 if L <= 6 else 5
+        alloc = (k["vgprs"] + 7) // 8 * 8
+        assert 512 // alloc >= waves, (k["symbol"], k["vgprs"], waves)

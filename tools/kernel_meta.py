@@ -34,6 +34,36 @@ def code_object_notes(lib):
     return "\n".join(out)
 
 
+def scratch_instruction_counts(lib):
+    """{mangled kernel name: number of scratch_* / private buffer instructions in its disassembly}."""
+    counts = {}
+    with tempfile.TemporaryDirectory() as td:
+        fat = os.path.join(td, "fat.bin")
+        subprocess.check_call([os.path.join(LLVM, "llvm-objcopy"), "-O", "binary", "--only-section=.hip_fatbin", lib, fat])
+        blob = open(fat, "rb").read()
+        magic = b"__CLANG_OFFLOAD_BUNDLE__"
+        starts = [m.start() for m in re.finditer(re.escape(magic), blob)]
+        for k, a in enumerate(starts):
+            b = starts[k + 1] if k + 1 < len(starts) else len(blob)
+            one, co = os.path.join(td, f"b{k}.bin"), os.path.join(td, f"co{k}.hsaco")
+            open(one, "wb").write(blob[a:b])
+            subprocess.check_call([os.path.join(LLVM, "clang-offload-bundler"), "--unbundle", "--type=o", f"--input={one}",
+                                   "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--output={co}"],
+                                  stderr=subprocess.DEVNULL)
+            if not os.path.getsize(co):
+                continue
+            dis = subprocess.check_output([os.path.join(LLVM, "llvm-objdump"), "-d", "--no-show-raw-insn", co], text=True)
+            cur = None
+            for ln in dis.splitlines():
+                m = re.match(r"^[0-9a-f]+ <([^>]+)>:", ln)
+                if m:
+                    cur = m.group(1)
+                    counts.setdefault(cur, 0)
+                elif cur and re.search(r"\bscratch_(load|store)|buffer_(load|store)_\w+ .*\boffen\b.*\bs\[0:3\]", ln):
+                    counts[cur] += 1
+    return counts
+
+
 def kernels(lib):
     txt = code_object_notes(lib)
     out = []
@@ -46,7 +76,7 @@ def kernels(lib):
             dem = subprocess.check_output([os.path.join(LLVM, "llvm-cxxfilt"), name], text=True).strip()
         except (OSError, subprocess.CalledProcessError):
             dem = name
-        out.append(dict(name=dem, vgprs=g("vgpr_count"), sgprs=g("sgpr_count"), vgpr_spills=g("vgpr_spill_count"),
+        out.append(dict(name=dem, symbol=name, vgprs=g("vgpr_count"), sgprs=g("sgpr_count"), vgpr_spills=g("vgpr_spill_count"),
                         sgpr_spills=g("sgpr_spill_count"), scratch_bytes=g("private_segment_fixed_size"),
                         static_lds=g("group_segment_fixed_size")))
     return out
