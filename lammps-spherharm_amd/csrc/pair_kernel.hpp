@@ -123,7 +123,7 @@ constexpr int kPairErrType = 2;   // an atom type outside [1, ntypes]
 //   ring[rows][L+1][4]   A_km, B_km, dA/dmu, dB/dmu of `rows` consecutive rings; the two B slots
 //                        of m = 0 (identically zero) carry mu_k and sigma_k.  rows = nq when that
 //                        leaves the CU enough waves, else the cap is processed in ring groups.
-//   qri[kQueue], qrj[kQueue], qp[kQueue] (int)   queue of inside nodes
+//   qri[kQueue], qrj[kQueue], qp[kQueue] (16-bit)   queue of inside nodes
 constexpr int kQueue = 128;  // entries; a slab adds <= 64 to a queue holding < 64
 constexpr int kFrame = 40;
 constexpr int kRecStride = 40;   // doubles per pair record: the first kRecUsed are copied into the frame
@@ -134,6 +134,9 @@ enum { FR_BJ1 = 0, FR_BJ2 = 3, FR_BJC = 6, FR_DJ = 9, FR_E1 = 12, FR_E2 = 15, FR
        FR_RJ = 24, FR_RJ2 = 25, FR_RHO2 = 26, FR_HW = 27, FR_HM = 28, FR_WSC = 29,
        FR_EULER = 30 /* cos, sin of alpha, beta, gamma */, FR_RHO = 36 };
 
+#ifndef SHP_ALIAS_FROM_L
+#define SHP_ALIAS_FROM_L 7
+#endif
 struct WaveLdsLayout {
   int trig, v0, v1, ring, qri, qrj, qp, bytes;  // offsets in doubles (qp: in doubles too), total bytes
   int qw;                                        // weighted rule only: the queued nodes' weights
@@ -148,7 +151,7 @@ __host__ __device__ inline WaveLdsLayout wave_lds_layout(const int L, const int 
   // L = 7 on it lies over the queue, which leaves room for more resident ring rows (L = 12, n_q = 32: +3 %); up to
   // L = 6 it keeps its own place: the wave count is limited elsewhere there (A/B: no gain from 24 instead of 21
   // waves per CU) and the separate layout compiles without a spill under the 80-VGPR bound.
-  const bool alias = L >= 7;
+  const bool alias = SHP_ALIAS_FROM_L <= L;
   w.trig = kFrame;
   w.v0 = alias ? kFrame : w.trig + 6 * (L + 1);
   w.v1 = w.v0 + ns;
@@ -157,7 +160,7 @@ __host__ __device__ inline WaveLdsLayout wave_lds_layout(const int L, const int 
   w.qri = w.ring + 4 * rows * (L + 1);
   w.qrj = w.qri + kQueue;
   w.qp = w.qrj + kQueue;
-  w.qw = w.qp + kQueue / 2;
+  w.qw = w.qp + kQueue / 4;
   w.coef = w.qw + (weighted ? kQueue : 0);
   if (alias) {
     w.trig = w.qri;
@@ -592,7 +595,7 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, WEIGHTED ? SHP_WMIN_WA
             const int pos = (qhead + qcount + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32),
                                                      __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u))) & (kQueue - 1);
             double* lq = (double*)fr;
-            ((int*)(lq + W.qp))[pos] = p1;
+            ((unsigned short*)(lq + W.qp))[pos] = (unsigned short)p1;
             lq[W.qri + pos] = wri1;
             lq[W.qrj + pos] = wrj1;
             lq[W.qw + pos] = (wg1 < 0.0) ? wt : -wt;  // the sign carries [g~ < 0] to phase 2 (no second opinion there)
@@ -652,7 +655,7 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, WEIGHTED ? SHP_WMIN_WA
         const int pos = (qhead + qcount + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32),
                                                  __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u))) & (kQueue - 1);
         double* lq = (double*)fr;
-        ((int*)(lq + W.qp))[pos] = p;
+        ((unsigned short*)(lq + W.qp))[pos] = (unsigned short)p;
         lq[W.qri + pos] = ri;
         lq[W.qrj + pos] = rj0;
       }
@@ -679,7 +682,7 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, WEIGHTED ? SHP_WMIN_WA
     if (lane == 0) atomicAdd(&P.dbg[4], 1ULL);
     if (active) atomicAdd(&P.dbg[7], 1ULL);
 #endif
-    const int p = ((const int*)(fr + W.qp))[e];
+    const int p = ((const unsigned short*)(fr + W.qp))[e];   // Q = 2 nq^2 <= 2^15
     const double ri = fr[W.qri + e];
     const int k = (int)(((unsigned)p * magic) >> 24);
     const int l = p - k * npsi;
