@@ -6,21 +6,38 @@
 // instructions per pair ISSUED ON 64 LANES for one lane's worth of work (no scalar FP64 unit on gfx950).  Here the
 // same arithmetic runs with one pair per lane — 1/64 of the vector issue — and leaves a 320-byte record per pair that
 // the contact kernel picks up with one coalesced load (pair_kernel.hpp).  HBM bound: 56 B gathered per atom of the
-// pair, 336 B written per pair.
+// pair, 336 B written per pair.  The records of a workgroup are staged in LDS and leave as full 512-byte wave stores
+// (written lane by lane they are 8-byte stores 320 bytes apart: 1.4x the bytes at the memory side, measured).
 // Included by shpair_api.hip only (the kernel is not a template: one definition per library).
 #pragma once
 #include "pair_kernel.hpp"
 
 namespace shp {
 
-constexpr int kSetupBlock = 256;
+constexpr int kSetupBlock = 64;
+constexpr int kSetupPad = kRecStride + 1;   // LDS row stride: odd, so that the lanes' rows start in different banks
+
+__device__ __forceinline__ void pair_setup_one(const PairParams& P, const int w, double* __restrict__ o, int* __restrict__ ri);
 
 __global__ __launch_bounds__(kSetupBlock) void pair_setup_kernel(const PairParams P, double* __restrict__ rec,
                                                                   int* __restrict__ rec_i)
 {
-  const int w = blockIdx.x * kSetupBlock + threadIdx.x;
-  if (w >= P.npairs) return;
-  int* ri = rec_i + 4 * (size_t)w;
+  __shared__ double srec[kSetupBlock * kSetupPad];
+  const int base = blockIdx.x * kSetupBlock;
+  const int w = base + threadIdx.x;
+  if (w < P.npairs) pair_setup_one(P, w, srec + threadIdx.x * kSetupPad, rec_i + 4 * (size_t)w);
+  __syncthreads();
+  // the workgroup's records, contiguous in memory: 64 x kRecStride doubles as wave-wide stores
+  const int nrec = (P.npairs - base < kSetupBlock) ? P.npairs - base : kSetupBlock;
+  double* out = rec + (size_t)kRecStride * base;
+  for (int t = threadIdx.x; t < nrec * kRecStride; t += kSetupBlock) {
+    const int r = t / kRecStride, k = t - r * kRecStride;
+    out[t] = srec[r * kSetupPad + k];
+  }
+}
+
+__device__ __forceinline__ void pair_setup_one(const PairParams& P, const int w, double* __restrict__ o, int* __restrict__ ri)
+{
   const int i = P.pair_i[w], j = P.pair_j[w];
   const int si = P.shtype[i], sj = P.shtype[j];
   ri[1] = si;
@@ -64,7 +81,6 @@ __global__ __launch_bounds__(kSetupBlock) void pair_setup_kernel(const PairParam
   quat_to_mat(P.quat[4 * i], P.quat[4 * i + 1], P.quat[4 * i + 2], P.quat[4 * i + 3], Rmi);
   quat_to_mat(P.quat[4 * j], P.quat[4 * j + 1], P.quat[4 * j + 2], P.quat[4 * j + 3], Rmj);
 
-  double* o = rec + (size_t)kRecStride * w;
   // the cap axes in i's body frame (columns of M) and in j's body frame, d in j's frame
   double b1[3], b2[3], bc[3];
 #pragma unroll
