@@ -85,6 +85,8 @@ def parse():
                     "(16 = the host-core share of one GPU on the bench box)")
     ap.add_argument("--peak-ms", type=float, default=20.0, help="length of the v_fma_f64 peak measurement (0 = skip)")
     ap.add_argument("--vthermal", type=float, default=0.5, help="N > 1: initial velocity scale of the bed")
+    ap.add_argument("--one-device", action="store_true", help="N > 1 with --transport rccl: every rank uses GPU 0 (only to probe "
+                    "what RCCL does with several ranks on one device; RCCL normally refuses)")
     a = ap.parse_args()
     if a.particles <= 0:
         a.particles = 100000 if a.gpus == 1 else 125000
@@ -496,6 +498,8 @@ def main_multi(args):
     import torch.distributed as dist
     from shpair import mrank
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if args.one_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist.init_process_group("gloo", rank=rank, world_size=world)   # control plane only: id broadcast, barriers, timings
     box = [mrank.unique_id() if rank == 0 else None]

@@ -301,3 +301,56 @@ def test_rccl_self_communicator_through_the_c_abi():
     halo.close()
     sp.close()
     sp1.close()
+
+
+def test_failure_modes_are_loud():
+    """Bricks shorter than the ghost cutoff, a capacity that cannot take the ghosts, and an atom that left its brick
+    and all neighbouring bricks between two exchanges must come back as error codes, never as silent garbage."""
+    import torch
+    from shpair import shapes, mrank, ShPairError
+    lmax, nq, skin = 4, 8, 0.2
+    shp = [shapes.random_shape(lmax, 400 + s, amp=0.2) for s in range(2)]
+    periodic = (1, 1, 1)
+    x, quat, sht, tag, lo, hi, _ = _bed(1500, periodic)
+    sp = _ctx(lmax, shp, nq)
+    with pytest.raises(ShPairError) as e:                      # 8 bricks along x: shorter than 2 Rmax + skin
+        mrank.Halo(sp, 0, 8, (8, 1, 1), lo, hi, periodic, skin, hub=mrank.Hub(8))
+    assert e.value.code == -1 and "ghost cutoff" in str(e.value)
+    halo = mrank.Halo(sp, 0, 1, (1, 1, 1), lo, hi, periodic, skin)
+    with pytest.raises(ShPairError) as e:                      # room for the owned rows but not for their periodic images
+        mrank.RankRun(sp, halo, x, quat, sht, tag, dt=1e-3, capacity=x.shape[0] + 10)
+    assert e.value.code == -5 and "capacity" in str(e.value)
+    halo.close()
+    sp.close()
+    # a lost atom: 4 x 1 x 1 ranks, periodic in x — rank 2 is not a neighbour of rank 0
+    world, grid, per = 4, (4, 1, 1), (1, 1, 0)
+    x, quat, sht, tag, lo, hi, _ = _bed(4000, per)
+    sp0 = _ctx(lmax, shp, nq)
+    cut = 2.0 * max(sp0.rmax(s) for s in range(2)) + skin
+    sp0.close()
+    xw, owner = _distribute(grid, lo, hi, per, cut, x)
+    hub = mrank.Hub(world)
+
+    def body(rank):
+        sp = _ctx(lmax, shp, nq)
+        halo = mrank.Halo(sp, rank, world, grid, lo, hi, per, skin, hub=hub)
+        mine = owner == rank
+        run = mrank.RankRun(sp, halo, xw[mine], quat[mine], sht[mine], tag[mine], dt=1e-3)
+        n0 = run.n
+        if rank == 0:                                   # teleport one atom into the brick of rank 2
+            run.x[0, 0] = float(lo[0] + 0.625 * (hi[0] - lo[0]))
+            torch.cuda.synchronize()
+        msg = None
+        try:
+            halo.exchange(run.a, run.stream)            # Comm::exchange only: the count messages still pair up
+            run.sync()
+        except ShPairError as err:
+            msg = (err.code, str(err))
+        res = (msg, n0, run.n)
+        halo.close()
+        sp.close()
+        return res
+    out = _run_ranks(world, body)
+    hub.close()
+    assert out[0][0] is not None and out[0][0][0] == -4 and "lost atom" in out[0][0][1]
+    assert all(o[0] is None and o[1] == o[2] for o in out[1:])       # the other ranks are untouched
