@@ -84,7 +84,7 @@ def parse():
     ap.add_argument("--cpu-threads", type=int, default=16, help="OpenMP threads of the cpu_baseline leg "
                     "(16 = the host-core share of one GPU on the bench box)")
     ap.add_argument("--peak-ms", type=float, default=20.0, help="length of the v_fma_f64 peak measurement (0 = skip)")
-    ap.add_argument("--vthermal", type=float, default=0.5, help="N > 1: initial velocity scale of the bed")
+    ap.add_argument("--vthermal", type=float, default=0.25, help="N > 1: initial velocity scale of the bed")
     ap.add_argument("--one-device", action="store_true", help="N > 1 with --transport rccl: every rank uses GPU 0 (only to probe "
                     "what RCCL does with several ranks on one device; RCCL normally refuses)")
     a = ap.parse_args()
@@ -358,7 +358,7 @@ def multi_rank_body(args, rank, world, device, coll, hub, uid, result):
     xw, owner = mrank.plan_owner(geo, cfg["x"])
     mine = owner == rank
     halo = mrank.Halo(sp, rank, world, grid, cfg["lo"], cfg["hi"], cfg["periodic"], skin, hub=hub, unique_id_bytes=uid)
-    dt = 2.0e-3
+    dt = 1.0e-3
     run = mrank.RankRun(sp, halo, xw[mine], cfg["quat"][mine], cfg["shtype"][mine], cfg["tag"][mine], v=cfg["v"][mine],
                         mask=cfg["mask"][mine], dt=dt, gravity=(0.0, 0.0, -1.0), device=f"cuda:{device}",
                         capacity=int(1.5 * mine.sum()) + 4096)

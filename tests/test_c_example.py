@@ -29,3 +29,12 @@ def test_c_example_runs_on_the_gpu():
     r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "gfx950" in r.stdout and "F_i" in r.stdout
+
+
+def test_c_halo_planner_example_runs_without_a_gpu():
+    """include/shhalo.h is plain C99 and its host planner needs no device: 7 distinct peers at 2 x 2 x 2, one message
+    per peer and direction of travel."""
+    _build()
+    r = subprocess.run([os.path.join(EX, "c_halo_plan")], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "distinct peers: 7" in r.stdout and "7 messages each way" in r.stdout
