@@ -303,6 +303,48 @@ def test_rccl_self_communicator_through_the_c_abi():
     sp1.close()
 
 
+def test_rank_without_atoms_of_its_own():
+    """A brick that owns nothing (all atoms sit in the other half of an open box) still takes part: it receives ghosts,
+    builds an empty list, sends nothing back — and the other rank's forces are the single-domain forces."""
+    import torch
+    from shpair import shapes, mrank
+    from shpair.run import DeviceRun
+    lmax, nq, skin = 4, 8, 0.2
+    shp = [shapes.random_shape(lmax, 400 + s, amp=0.2) for s in range(2)]
+    per = (0, 0, 0)
+    x, quat, sht, tag, lo, hi, _ = _bed(1200, per)
+    hi = hi.copy()
+    hi[0] = lo[0] + 2.0 * (x[:, 0].max() - lo[0]) + 0.5          # the atoms fill the left half only (up to the cut)
+    world, grid = 2, (2, 1, 1)
+    sp0 = _ctx(lmax, shp, nq)
+    cut = 2.0 * max(sp0.rmax(s) for s in range(2)) + skin
+    xw, owner = _distribute(grid, lo, hi, per, cut, x)
+    assert (owner == 1).sum() == 0
+    hub = mrank.Hub(world)
+
+    def body(rank):
+        sp = _ctx(lmax, shp, nq)
+        halo = mrank.Halo(sp, rank, world, grid, lo, hi, per, skin, hub=hub)
+        mine = owner == rank
+        run = mrank.RankRun(sp, halo, xw[mine], quat[mine], sht[mine], tag[mine], dt=1e-3, capacity=4096)
+        run.run(3)
+        t, X, _, _, f, tq = run.owned()
+        res = dict(tag=t, x=X, n=run.n, nghost=run.nghost, npairs=run.npairs)
+        halo.close()
+        sp.close()
+        return res
+    parts = _run_ranks(world, body)
+    assert parts[1]["n"] == 0 and parts[1]["npairs"] == 0 and parts[1]["nghost"] > 0 and parts[0]["nghost"] == 0
+    ref = DeviceRun(sp0, x, quat, sht, lo, hi, per, skin, dt=1e-3)
+    ref.run(3)
+    torch.cuda.synchronize()
+    n = x.shape[0]
+    assert np.array_equal(parts[0]["tag"], np.arange(n))
+    assert np.abs(parts[0]["x"] - ref.x[:n].cpu().numpy()).max() < 1e-12
+    sp0.close()
+    hub.close()
+
+
 def test_failure_modes_are_loud():
     """Bricks shorter than the ghost cutoff, a capacity that cannot take the ghosts, and an atom that left its brick
     and all neighbouring bricks between two exchanges must come back as error codes, never as silent garbage."""
