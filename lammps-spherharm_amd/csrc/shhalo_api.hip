@@ -328,9 +328,9 @@ struct shhalo_ctx {
 
   // static: remote peers (ascending rank) and the slot tables of the two partitions
   int npeers = 0;
-  int peer_rank[26];
+  int peer_rank[26] = {};
   HaloSlots ghost_slots{}, mig_slots{};
-  int ghost_peer_of_slot[kHaloMaxSlots];  // index into peer_rank, -1: self
+  int ghost_peer_of_slot[kHaloMaxSlots] = {};  // index into peer_rank, -1: self
 
   // the current plan
   shhalo_layout lay{};
