@@ -126,6 +126,9 @@ constexpr int kPairErrType = 2;   // an atom type outside [1, ntypes]
 //   qri[kQueue], qrj[kQueue], qp[kQueue] (16-bit)   queue of inside nodes
 constexpr int kQueue = 128;  // entries; a slab adds <= 64 to a queue holding < 64
 constexpr int kFrame = 40;
+constexpr int kRedStride = 72;    // epilogue reduction: doubles between the 64-entry rows of the seven sums (64 + 8: rows
+                                  // four apart share banks, not all seven)
+constexpr int kRedDoubles = 7 * kRedStride + 56 + 7 + 6;   // scratch of the epilogue behind the frame
 constexpr int kRecStride = 40;   // doubles per pair record: the first kRecUsed are copied into the frame
 constexpr int kRecUsed = 37;
 // per-pair scalars live in the frame too: as VALU results they would sit in VGPR pairs for
@@ -173,6 +176,8 @@ __host__ __device__ inline WaveLdsLayout wave_lds_layout(const int L, const int 
 #else
   w.bytes = 8 * w.coef;
 #endif
+  // the epilogue's reduction scratch lies behind the frame, over everything that is dead by then
+  if (w.bytes < 8 * (kFrame + kRedDoubles)) w.bytes = 8 * (kFrame + kRedDoubles);
   w.bytes = (w.bytes + 15) & ~15;
   return w;
 }
@@ -181,6 +186,30 @@ __device__ __forceinline__ unsigned launder_u32(unsigned v)
 {
   asm volatile("" : "+v"(v));
   return v;
+}
+
+// The lane index, made where it is asked for.  Anything derived from threadIdx is invariant everywhere: addresses the
+// epilogue computes from it (lane * 8 as a 64-bit offset, ...) are merged with the prologue's and then carried —
+// or spilled — through the node loops, where registers are scarcest.  Two instructions.
+__device__ __forceinline__ int fresh_lane()
+{
+  int v;
+  asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(v));
+  return v;
+}
+
+// The kernel's arguments, read where they are used.  A by-value argument struct is loaded from the kernarg segment in
+// the entry block; the epilogue's sixteen pointers and flags (f, torque, pair_i, pair_j, type, kn, ...) would then sit
+// in ~30 scalar registers through the node loops, where the coefficient windows of sh_eval need them: the allocator
+// parks them in lanes of a vector register and restores eight of them in EVERY iteration of the root loop and of the
+// slab loop (v_readlane, ~330 vector instructions per pair at L = 6).  Reading them through a kernarg pointer the
+// compiler cannot see through makes them plain scalar loads at the point of use.
+typedef const PairParams __attribute__((address_space(4))) LateParams;
+__device__ __forceinline__ LateParams* late_params()
+{
+  unsigned long long a = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(a));
+  return (LateParams*)a;
 }
 
 __device__ __forceinline__ void wave_lds_sync()
@@ -412,7 +441,7 @@ template <int L, bool NEEDV, bool WEIGHTED = false>
 __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, WEIGHTED ? SHP_WMIN_WAVES(L) : SHP_MIN_WAVES(L, NEEDV)) pair_contact_kernel(const PairParams P)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  const int lane = threadIdx.x & 63;
+  int lane = threadIdx.x & 63;
   const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int w = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * P.waves_per_block)) + wib;
   if (w >= P.npairs) return;
@@ -436,8 +465,6 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, WEIGHTED ? SHP_WMIN_WA
   const bool centre_in_bj = rid[3] != 0;  // rho < Rj
   if (lane < kRecUsed) lw[lane] = P.rec[(size_t)kRecStride * w + lane];
   wave_lds_sync();
-  const int i = P.pair_i[w];
-  const int j = P.pair_j[w];
 #if defined(SHP_ABL) && SHP_ABL == 1   // timing-only build: stop after the pair prologue
   asm volatile("" ::"v"(lw[lane & 31]));
   return;
@@ -682,19 +709,14 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, WEIGHTED ? SHP_WMIN_WA
     if (lane == 0) atomicAdd(&P.dbg[4], 1ULL);
     if (active) atomicAdd(&P.dbg[7], 1ULL);
 #endif
-    const int p = ((const unsigned short*)(fr + W.qp))[e];   // Q = 2 nq^2 <= 2^15
+    int p = ((const unsigned short*)(fr + W.qp))[e];   // Q = 2 nq^2 <= 2^15
     const double ri = fr[W.qri + e];
-    const int k = (int)(((unsigned)p * magic) >> 24);
-    const int l = p - k * npsi;
-    double omi = active ? fr[FR_WSC] * P.glw[k] : 0.0;
-    const double omv = omi;  // the volume keeps the node's plain weight (SPEC §2.8)
+    int k = (int)(((unsigned)p * magic) >> 24);
+    int l = p - k * npsi;
+    double omi = active ? fr[FR_WSC] * P.glw[k] : 0.0;   // the node's plain weight
     bool outside = false;    // WEIGHTED: a node with g~ >= 0 has no ray segment inside j
-    if (WEIGHTED) {
-      const double qw = fr[W.qw + e];
-      outside = !(qw > 0.0);
-      omi *= fabs(qw);
-    }
-    const double c1 = P.cpsi[l], s1 = P.spsi[l];
+    if (WEIGHTED) outside = !(fr[W.qw + e] > 0.0);
+    double c1 = P.cpsi[l], s1 = P.spsi[l];
     double mu, sig;
     {
       const double* row = fr + W.ring + (k - k0) * rowlen;
@@ -780,8 +802,24 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, WEIGHTED ? SHP_WMIN_WA
       // a node outside j contributes exactly nothing (r^3 - r^3 under FMA contraction is a rounding residue, and
       // V^(m-1) turns a residue of 1e-22 into a visible force)
       const double dv3 = (WEIGHTED && outside) ? 0.0 : ri * ri * ri - rin * rin * rin;
-      aV = fma(omv * (1.0 / 3.0), dv3, aV);
+      if constexpr (WEIGHTED) {
+        // The weighted kernels have three slabs of residuals in registers on top of the root finder's state: the
+        // node (weight, psi, mu, sigma: nine registers) is looked up a second time here, through a copy of p the
+        // compiler cannot see through, instead of being carried across the loop — that is what keeps them free of
+        // spills.  The sharp kernels have the room (A/B: the second lookup costs them 1.5 %).
+        p = (int)launder_u32((unsigned)p);
+        k = (int)(((unsigned)p * magic) >> 24);
+        l = p - k * npsi;
+        omi = active ? fr[FR_WSC] * P.glw[k] : 0.0;
+        c1 = P.cpsi[l];
+        s1 = P.spsi[l];
+        const double* row = fr + W.ring + (k - k0) * rowlen;
+        mu = row[1];
+        sig = row[3];
+      }
+      aV = fma(omi * (1.0 / 3.0), dv3, aV);   // the volume keeps the node's plain weight (SPEC §2.8)
     }
+    if (WEIGHTED) omi *= fabs(fr[W.qw + e]);
 
     // surface gradient of i at the node, in the cap frame:
     //   A = r^2 u + r sigma r_mu gamma^ - (r / sigma) r_psi psi^,
@@ -808,92 +846,117 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, WEIGHTED ? SHP_WMIN_WA
   }
   }  // ring groups
 
-  aS0 = wave_sum(aS0); aS1 = wave_sum(aS1); aS2 = wave_sum(aS2);
-  aT0 = wave_sum(aT0); aT1 = wave_sum(aT1); aT2 = wave_sum(aT2);
-  if (NEEDV) aV = wave_sum(aV);
-  if (lane != 0) return;
+  // ---------------------------------------------------------------- epilogue
+  // Round 1: seven butterfly reductions (42 v_add_f64 + 84 ds_bpermute), then lane 0 alone rotated the sums to the
+  // space frame, applied the force law and issued 12 scalar atomics — ~250 vector instructions per pair of which
+  // ~150 ran with ONE active lane (an instruction costs its issue slots whatever the lane count): 7.4 % of the kernel
+  // (ablation A=5).  Now: the 64 x 7 partial sums are transposed through LDS (the ring tables and the queue are
+  // dead) and added in two levels of 8; the force law runs with one COMPONENT per lane — lanes 0-2 the force, 3-5
+  // the torque — so the rotation is 3 FMAs instead of 18 and the scatter is ONE 6-lane global_atomic_add_f64 per
+  // atom (f[3i..3i+2] and torque[3i..3i+2] are contiguous: 2 memory-side operations per atom instead of 6).
+  lane = fresh_lane();
+  {
+    double* red = SHP_LDS() + kFrame;   // [7][kRedStride] partial sums | [56] | [7] totals | [6] force components
+    red[0 * kRedStride + lane] = aS0; red[1 * kRedStride + lane] = aS1; red[2 * kRedStride + lane] = aS2;
+    red[3 * kRedStride + lane] = aT0; red[4 * kRedStride + lane] = aT1; red[5 * kRedStride + lane] = aT2;
+    red[6 * kRedStride + lane] = NEEDV ? aV : 0.0;
+    wave_lds_sync();
+    double* part = red + 7 * kRedStride;
+    if (lane < 56) {   // lane = (v, seg): the entries seg, seg + 8, ... of sum v
+      const double* src = red + (lane >> 3) * kRedStride + (lane & 7);
+      part[lane] = ((src[0] + src[8]) + (src[16] + src[24])) + ((src[32] + src[40]) + (src[48] + src[56]));
+    }
+    wave_lds_sync();
+    double* tot = part + 56;
+    if (lane < 7) {
+      const double* src = part + 8 * lane;
+      tot[lane] = ((src[0] + src[1]) + (src[2] + src[3])) + ((src[4] + src[5]) + (src[6] + src[7]));
+    }
+    wave_lds_sync();
+  }
+  if (lane >= 6) return;
   fr = SHP_LDS();
 #undef SHP_LDS
 #ifdef SHP_COEF_LDS
 #undef cwj
 #endif
+  const double* tot = fr + kFrame + 7 * kRedStride + 56;
+  double* fcomp = (double*)tot + 7;
+  const int comp = (lane >= 3) ? lane - 3 : lane;   // 0..2
+  const bool is_t = lane >= 3;                        // lanes 3-5: torque components
+  // rotate the cap-frame integrals to the space frame (columns e1, e2, c): this lane's component of S_n or T_n
+  const double a0 = tot[is_t ? 3 : 0], a1 = tot[is_t ? 4 : 1], a2 = tot[is_t ? 5 : 2];
+  const double val = fr[FR_E1 + comp] * a0 + fr[FR_E2 + comp] * a1 + fr[FR_C + comp] * a2;
+  const double aVt = tot[6];
 
-  // rotate the cap-frame integrals to the space frame: columns e1, e2, c
-  const double S0 = fr[FR_E1] * aS0 + fr[FR_E2] * aS1 + fr[FR_C] * aS2;
-  const double S1 = fr[FR_E1 + 1] * aS0 + fr[FR_E2 + 1] * aS1 + fr[FR_C + 1] * aS2;
-  const double S2 = fr[FR_E1 + 2] * aS0 + fr[FR_E2 + 2] * aS1 + fr[FR_C + 2] * aS2;
-  const double T0 = fr[FR_E1] * aT0 + fr[FR_E2] * aT1 + fr[FR_C] * aT2;
-  const double T1 = fr[FR_E1 + 1] * aT0 + fr[FR_E2 + 1] * aT1 + fr[FR_C + 1] * aT2;
-  const double T2 = fr[FR_E1 + 2] * aT0 + fr[FR_E2 + 2] * aT1 + fr[FR_C + 2] * aT2;
-  const double d0 = fr[FR_D], d1 = fr[FR_D + 1], d2 = fr[FR_D + 2];
-
-  if (P.pair_out) {
-    double* o = P.pair_out + 7 * (size_t)w;
-    o[0] = aV; o[1] = S0; o[2] = S1; o[3] = S2; o[4] = T0; o[5] = T1; o[6] = T2;
+  LateParams& E = *late_params();   // the first explicit argument starts the kernarg segment
+  if (E.pair_out) {
+    double* o = E.pair_out + 7 * (size_t)w;
+    o[1 + lane] = val;
+    if (lane == 0) o[0] = aVt;
   }
-  const bool touched = NEEDV ? (aV > 0.0) : (S0 != 0.0 || S1 != 0.0 || S2 != 0.0);
+  // touched: V > 0, or (forces only) any component of S_n non-zero
+  const bool touched = NEEDV ? (aVt > 0.0) : (__ballot(!is_t && val != 0.0) != 0ULL);
   // statistics go through a byte per slot, summed by count_flags_kernel: one
   // atomic per pair on a shared counter costs more than the whole kernel
-  if (P.flags) P.flags[w] = touched ? 2 : 1;
+  if (E.flags && lane == 0) E.flags[w] = touched ? 2 : 1;
   if (!touched) return;
 
   // SPEC §2.7 force law
-  const int ti = P.type[i], tj = P.type[j];
-  if (ti < 1 || ti > P.ntypes || tj < 1 || tj > P.ntypes) {
-    atomicOr(P.err, kPairErrType);
+  const int i = E.pair_i[w], j = E.pair_j[w];
+  const int ti = E.type[i], tj = E.type[j];
+  if (ti < 1 || ti > E.ntypes || tj < 1 || tj > E.ntypes) {
+    if (lane == 0) atomicOr(E.err, kPairErrType);
     return;
   }
-  const double knij = P.kn[ti * (P.ntypes + 1) + tj];
-  const double mij = P.expo[ti * (P.ntypes + 1) + tj];
-  const double vm1 = (mij == 1.0) ? 1.0 : pow_quarter(aV, mij - 1.0);  // V^(m-1)
+  const double knij = E.kn[ti * (E.ntypes + 1) + tj];
+  const double mij = E.expo[ti * (E.ntypes + 1) + tj];
+  const double vm1 = (mij == 1.0) ? 1.0 : pow_quarter(aVt, mij - 1.0);  // V^(m-1)
   const double pn = knij * mij * vm1;
-  const double F0 = -pn * S0, F1 = -pn * S1, F2 = -pn * S2;
-  const double M0 = -pn * T0, M1 = -pn * T1, M2 = -pn * T2;
-  atomicAdd(&P.f[3 * i], F0);
-  atomicAdd(&P.f[3 * i + 1], F1);
-  atomicAdd(&P.f[3 * i + 2], F2);
-  atomicAdd(&P.torque[3 * i], M0);
-  atomicAdd(&P.torque[3 * i + 1], M1);
-  atomicAdd(&P.torque[3 * i + 2], M2);
-  const bool applyj = P.newton_pair || j < P.nlocal;
+  const double Fm = -pn * val;   // lanes 0-2: F_i; lanes 3-5: tau_i
+  fcomp[lane] = Fm;
+  wave_lds_sync();
+  atomicAdd((is_t ? E.torque : E.f) + 3 * (size_t)i + comp, Fm);
+  const bool applyj = E.newton_pair || j < E.nlocal;
   if (applyj) {
-    // F_j = -F_i ;  tau_j = -tau_i - d x F_j
-    const double G0 = -F0, G1 = -F1, G2 = -F2;
-    atomicAdd(&P.f[3 * j], G0);
-    atomicAdd(&P.f[3 * j + 1], G1);
-    atomicAdd(&P.f[3 * j + 2], G2);
-    atomicAdd(&P.torque[3 * j], -M0 - (d1 * G2 - d2 * G1));
-    atomicAdd(&P.torque[3 * j + 1], -M1 - (d2 * G0 - d0 * G2));
-    atomicAdd(&P.torque[3 * j + 2], -M2 - (d0 * G1 - d1 * G0));
+    // F_j = -F_i ;  tau_j = -tau_i - d x F_j : component c needs d and F_j at c + 1, c + 2
+    const int c1 = (comp == 2) ? 0 : comp + 1, c2 = (comp == 0) ? 2 : comp - 1;
+    double vj = -Fm;
+    if (is_t) vj -= fr[FR_D + c1] * (-fcomp[c2]) - fr[FR_D + c2] * (-fcomp[c1]);
+    atomicAdd((is_t ? E.torque : E.f) + 3 * (size_t)j + comp, vj);
   }
-  if (P.eatom || P.vatom) {
+  if (lane != 0) return;
+  // the tallies (only when asked for) stay with lane 0
+  const double F0 = fcomp[0], F1 = fcomp[1], F2 = fcomp[2];
+  const double d0 = fr[FR_D], d1 = fr[FR_D + 1], d2 = fr[FR_D + 2];
+  if (E.eatom || E.vatom) {
     // ev_tally_xyz per-atom part: half of the pair's energy / virial to each atom this rank tallies for
-    const bool owni = P.newton_pair || i < P.nlocal;
-    if (P.eatom) {
-      const double eh = 0.5 * knij * (vm1 * aV);
-      if (owni) atomicAdd(&P.eatom[i], eh);
-      if (applyj) atomicAdd(&P.eatom[j], eh);
+    const bool owni = E.newton_pair || i < E.nlocal;
+    if (E.eatom) {
+      const double eh = 0.5 * knij * (vm1 * aVt);
+      if (owni) atomicAdd(&E.eatom[i], eh);
+      if (applyj) atomicAdd(&E.eatom[j], eh);
     }
-    if (P.vatom) {
+    if (E.vatom) {
       const double v[6] = {0.5 * (-d0) * F0, 0.5 * (-d1) * F1, 0.5 * (-d2) * F2,
                            0.5 * (-d0) * F1, 0.5 * (-d0) * F2, 0.5 * (-d1) * F2};
       for (int a = 0; a < 6; ++a) {
-        if (owni) atomicAdd(&P.vatom[6 * (size_t)i + a], v[a]);
-        if (applyj) atomicAdd(&P.vatom[6 * (size_t)j + a], v[a]);
+        if (owni) atomicAdd(&E.vatom[6 * (size_t)i + a], v[a]);
+        if (applyj) atomicAdd(&E.vatom[6 * (size_t)j + a], v[a]);
       }
     }
   }
-  if ((P.eflag || P.vflag) && P.ev) {
-    const double share = P.newton_pair ? 1.0 : (0.5 + (j < P.nlocal ? 0.5 : 0.0));
-    if (P.eflag) atomicAdd(&P.ev[0], share * knij * (vm1 * aV));
-    if (P.vflag) {
+  if ((E.eflag || E.vflag) && E.ev) {
+    const double share = E.newton_pair ? 1.0 : (0.5 + (j < E.nlocal ? 0.5 : 0.0));
+    if (E.eflag) atomicAdd(&E.ev[0], share * knij * (vm1 * aVt));
+    if (E.vflag) {
       // ev_tally_xyz with del = x_i - x_j = -d and the force on i
-      atomicAdd(&P.ev[1], share * (-d0) * F0);
-      atomicAdd(&P.ev[2], share * (-d1) * F1);
-      atomicAdd(&P.ev[3], share * (-d2) * F2);
-      atomicAdd(&P.ev[4], share * (-d0) * F1);
-      atomicAdd(&P.ev[5], share * (-d0) * F2);
-      atomicAdd(&P.ev[6], share * (-d1) * F2);
+      atomicAdd(&E.ev[1], share * (-d0) * F0);
+      atomicAdd(&E.ev[2], share * (-d1) * F1);
+      atomicAdd(&E.ev[3], share * (-d2) * F2);
+      atomicAdd(&E.ev[4], share * (-d0) * F1);
+      atomicAdd(&E.ev[5], share * (-d0) * F2);
+      atomicAdd(&E.ev[6], share * (-d1) * F2);
     }
   }
 }
