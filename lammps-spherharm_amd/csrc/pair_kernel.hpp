@@ -335,7 +335,16 @@ __device__ __forceinline__ void cap_frame_rotate(const PairParams& P, double* __
   // the rotated, scaled coefficients are now in v0
 }
 
-// Ring tables of rings k0 .. k0 + nrows - 1 from the rotated coefficients: one (k, m) per lane.
+// Ring tables of rings k0 .. k0 + nrows - 1 from the rotated coefficients.
+//
+// Lanes are (ring, order class): G = 8, 4, 2 or 1 lanes per ring — as many as 64 lanes give the group's rows — and
+// lane (kr, g) builds the orders m = g, g + G, g + 2G, ...  For one m the Legendre recurrence runs over n = m+1 .. L;
+// all lanes step through n together (compile-time n for the compiled orders: every LDS and table offset is an
+// immediate), a lane joins at n = m + 1 under the exec mask, and steps no lane of the pass needs (n <= the pass's
+// smallest m) are skipped wave-uniformly.  Q_n lives in one of two registers by the parity of n, so a step updates
+// the older value in place: 8 FP64 operations per step and no moves.  L = 6, n_q = 16: 8 steps in one pass, ~130
+// vector instructions per ring group.  (Round 2 up to here: one (k, m) per lane and, for every lane, L steps each
+// split by the divergent test t < m: ~200 instructions per 64 entries, 2 passes = ~400 per pair at the headline.)
 template <int L>
 __device__ __forceinline__ void cap_frame_rings(const PairParams& P, double* __restrict__ lw, const WaveLdsLayout& W,
                                                 const int LL, const int lane, const int k0, const int nrows,
@@ -343,47 +352,64 @@ __device__ __forceinline__ void cap_frame_rings(const PairParams& P, double* __r
 {
   const double* ch = lw + W.v0;
   double* ring = lw + W.ring;
-  const int nkm = nrows * (LL + 1);
-  for (int idx = lane; idx < nkm; idx += 64) {
-    const int kr = idx / (LL + 1);
-    const int m = idx - kr * (LL + 1);
-    const int k = k0 + kr;
-    const double mu = fma(hw, P.glt[k], hm);
+  const int lg = (nrows <= 8) ? 3 : (nrows <= 16) ? 2 : (nrows <= 32) ? 1 : 0;   // log2 G, wave-uniform
+  const int G = 1 << lg;
+  const int g = lane & (G - 1);
+  for (int kr0 = 0; kr0 < nrows; kr0 += (64 >> lg)) {
+    const int kr = kr0 + (lane >> lg);
+    const bool row_ok = kr < nrows;
+    const double mu = fma(hw, P.glt[k0 + (row_ok ? kr : 0)], hm);
     const double sig2 = fmax(0.0, fma(-mu, mu, 1.0));
     const double sig = sqrt_nr(sig2);
-    const double* rcm = P.rc + sh_moff(LL, m);
-    double q2 = 0.0, q1 = 1.0, d2 = 0.0, d1 = 0.0;  // Q_{n-2}, Q_{n-1} and mu-derivatives; start at n = m
-    double wa = ch[m * m + 2 * m], wb = (m > 0) ? ch[m * m] : 0.0, wad = 0.0, wbd = 0.0;
-    double sp = 1.0;  // sigma^m
-    // fixed trip count L: step t multiplies sigma^m while t < m, then is term n = t + 1
-#pragma unroll
-    for (int t = 0; t < ((L >= 0) ? L : LL); ++t) {
-      if (t < m) {
-        sp *= sig;
-      } else {
-        const int n = t + 1;
-        const double a = rcm[n - m];
-        const double q = fma(a, mu * q1, -q2);
-        const double d = fma(a, fma(mu, d1, q1), -d2);
-        const double ca = ch[n * n + n + m], cbm = (m > 0) ? ch[n * n + n - m] : 0.0;
-        wa = fma(ca, q, wa);
-        wb = fma(cbm, q, wb);
-        wad = fma(ca, d, wad);
-        wbd = fma(cbm, d, wbd);
-        q2 = q1; q1 = q; d2 = d1; d1 = d;
-      }
+    double sp = 1.0, sigG = sig;   // sigma^g and sigma^G
+    for (int t = 0; t < G - 1; ++t) {
+      if (t < g) sp *= sig;
     }
-    // d/dmu [sigma^m W] = sigma^m (W' - m mu W / sigma^2)
-    const double f = (m > 0) ? (double)m * mu * rcp_nr(sig2) : 0.0;
-    double* o = ring + 4 * idx;
-    o[0] = sp * wa;
-    o[2] = sp * fma(-f, wa, wad);
-    if (m == 0) {
-      o[1] = mu;   // B_k0 = 0: the slot carries mu_k
-      o[3] = sig;  // dB_k0/dmu = 0: carries sigma_k
-    } else {
-      o[1] = sp * wb;
-      o[3] = sp * fma(-f, wb, wbd);
+    for (int t = 0; t < lg; ++t) sigG *= sigG;
+    for (int m0 = 0; m0 <= LL; m0 += G) {
+      const int m = m0 + g;
+      const bool ok = row_ok && m <= LL;
+      const int mc = ok ? m : 0;   // idle lanes read in bounds
+      const double* rcm = P.rc + (sh_moff(LL, mc) - mc);   // a'_nm at rcm[n]
+      const double* cp = ch + mc;                          // C_nm at cp[n^2 + n], C_n,-m at cm[n^2 + n]
+      const double* cm = ch - mc;
+      // Q_n and dQ_n/dmu in q[n & 1], d[n & 1]; start: Q_m = 1, Q_(m-1) = 0
+      const bool modd = (mc & 1) != 0;
+      double qe = modd ? 0.0 : 1.0, qo = modd ? 1.0 : 0.0, de = 0.0, dd = 0.0;
+      // m = 0: the B sums read C_n0 again and are not stored (no select in the loop)
+      double wa = cp[mc * mc + mc], wb = cm[mc * mc + mc], wad = 0.0, wbd = 0.0;
+#pragma unroll
+      for (int n = 1; n <= ((L >= 0) ? L : LL); ++n) {
+        if (n <= m0) continue;   // wave-uniform: no lane of this pass has m < n
+        if (ok && n > m) {
+          const double a = rcm[n];
+          const double ca = cp[n * n + n], cbm = cm[n * n + n];
+          if (n & 1) {
+            dd = fma(a, fma(mu, de, qe), -dd);
+            qo = fma(a, mu * qe, -qo);
+            wa = fma(ca, qo, wa); wb = fma(cbm, qo, wb); wad = fma(ca, dd, wad); wbd = fma(cbm, dd, wbd);
+          } else {
+            de = fma(a, fma(mu, dd, qo), -de);
+            qe = fma(a, mu * qo, -qe);
+            wa = fma(ca, qe, wa); wb = fma(cbm, qe, wb); wad = fma(ca, de, wad); wbd = fma(cbm, de, wbd);
+          }
+        }
+      }
+      if (ok) {
+        // d/dmu [sigma^m W] = sigma^m (W' - m mu W / sigma^2)
+        const double f = (m > 0) ? (double)m * mu * rcp_nr(sig2) : 0.0;
+        double* o = ring + 4 * (kr * (LL + 1) + m);
+        o[0] = sp * wa;
+        o[2] = sp * fma(-f, wa, wad);
+        if (m == 0) {
+          o[1] = mu;   // B_k0 = 0: the slot carries mu_k
+          o[3] = sig;  // dB_k0/dmu = 0: carries sigma_k
+        } else {
+          o[1] = sp * wb;
+          o[3] = sp * fma(-f, wb, wbd);
+        }
+      }
+      sp *= sigG;
     }
   }
   wave_lds_sync();
@@ -527,7 +553,15 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, WEIGHTED ? SHP_WMIN_WA
   if (slab_end <= slab) return;  // cannot happen with the host's ring_rows; never spin
   {
     double* lr = SHP_LDS();
+    // the queue is empty between ring groups: four of the seven sums wait there while the ring tables are built
+    // (eight registers the build has for its recurrences instead of spilling)
+    double* park = lr + W.qri + lane;
+    park[0] = aT0; park[64] = aT1; park[128] = aT2; park[192] = NEEDV ? aV : aS0;
     cap_frame_rings<L>(P, lr, W, LL, lane, k0, kend - k0, lr[FR_HW], lr[FR_HM]);
+    park = SHP_LDS() + W.qri + lane;
+    aT0 = park[0]; aT1 = park[64]; aT2 = park[128];
+    if (NEEDV) aV = park[192]; else aS0 = park[192];
+    wave_lds_sync();
 #if defined(SHP_ABL) && SHP_ABL == 2   // timing-only build: stop after rotation + ring tables
     asm volatile("" ::"v"(lr[W.ring + lane]));
     return;
@@ -828,7 +862,7 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, WEIGHTED ? SHP_WMIN_WA
     double r2, rmu, rpsi;
     ring_eval<L, true>(fr + W.ring + (k - k0) * rowlen, LL, c1, s1, P.trig + (trig_lmajor(L) ? (size_t)P.trig_stride * l : (size_t)(2 * l)), P.trig_stride, r2, rmu, rpsi);
     const double rad = ri * fma(ri, sig, rmu * sig * mu);   // r (r sigma + sigma mu r_mu): multiplies (c, s)
-    const double tan_ = ri * rpsi / sig;                   // (r / sigma) r_psi
+    const double tan_ = ri * rpsi * rcp_nr(sig);           // (r / sigma) r_psi; sigma > 0 at Gauss-Legendre nodes
     const double A0 = fma(rad, c1, tan_ * s1);
     const double A1 = fma(rad, s1, -tan_ * c1);
     const double A2 = ri * fma(ri, mu, -(sig * sig) * rmu);
