@@ -498,10 +498,16 @@ def test_extreme_quadrature_orders(oracle, lmax, nq):
     sp.close()
 
 
-@pytest.mark.parametrize("lmax,nq,rows", [(6, 16, 3), (6, 16, 5), (4, 10, 5), (12, 32, 2), (12, 32, 9), (8, 7, 6)])
+@pytest.mark.parametrize("lmax,nq,rows", [(6, 16, 3), (6, 16, 5), (4, 10, 5), (12, 32, 2), (12, 32, 9), (8, 7, 6),
+                                          # the ring-table build maps lanes to (ring, order class) with 8 / 4 / 2 / 1 lanes
+                                          # per ring by the group's row count, in passes of 64 lanes:
+                                          (6, 16, 8), (5, 24, 9), (3, 40, 17), (3, 40, 33), (1, 96, 70), (2, 128, 128),
+                                          (0, 100, 100)])
 def test_ring_groups_do_not_change_the_result(oracle, lmax, nq, rows):
     """Large (lmax, nq) process the cap in groups of LDS-resident rings; forcing small groups on
-    small problems must reproduce the oracle (and the single-group result) exactly as well."""
+    small problems must reproduce the oracle (and the single-group result) exactly as well.  The later cases force
+    group sizes on either side of every lane-mapping threshold of cap_frame_rings (<= 8, <= 16, <= 32 rows, more than 64
+    rows = two passes), including last groups that are smaller than the others."""
     case = make_case(120, lmax, 2, seed=60 + lmax, rmax_fn=oracle.shape_rmax)
     K, E = coeff_tables(1, 1000.0, 1.25)
     sp = make_ctx(case, nq, K, E)
