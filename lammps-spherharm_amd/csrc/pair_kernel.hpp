@@ -795,42 +795,54 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, WEIGHTED ? SHP_WMIN_WA
         const double rj = sh_eval<L>(rc, cwj, lrt, y0 * iv, y1 * iv, y2 * iv);
         const double Rjl = fr[FR_RJ];
         const double gl = z0 ? -Rjl : ss2 * iv - rj;
-        if (act) {
-          if (gl >= 0.0) lo = lam; else hi = lam;
+        // The update has no divergent control flow: every lane goes through it, and a lane that is done (or never was
+        // active) carries on with values nobody reads — its r_in is frozen by `act`.  (Nested conditionals cost a
+        // copy of each loop-carried value per merge: 19 v_mov_b64 and 84 vector instructions per iteration beside
+        // the 86 of the radius evaluation.)  The common case — the extrapolated point lies strictly inside the
+        // bracket, which is not yet tiny — needs no decision at all: accepted value and next iterate are both `ext`;
+        // everything else (fallback to the secant, bisection, clamping, non-finite values) is a wave-uniform branch.
+        {
+          const bool pos = gl >= 0.0;
+          lo = pos ? lam : lo;
+          hi = pos ? hi : lam;
           const bool have3 = it >= 1;  // wave-uniform
           const double dbl = gb - gl;
           // extrapolation to g = 0: secant through two points on the first iterate, inverse
-          // quadratic interpolation (one common denominator) through three afterwards; the
-          // secant is then only a fallback and computed on demand
-          double ext, sec;
+          // quadratic interpolation (one common denominator) through three afterwards
+          double ext;
           if (!have3) {
-            sec = fma(gl * (lam - xb), rcp_nr(dbl), lam);
-            ext = sec;
+            ext = fma(gl * (lam - xb), rcp_nr(dbl), lam);
           } else {
             const double dab = ga - gb, dal = ga - gl;
             const double num = fma(xa * gb, gl * dbl, fma(lam * ga, gb * dab, -(xb * ga) * (gl * dal)));
             ext = num * rcp_nr(dab * dal * dbl);
-            sec = ext;
-            if (!(fabs(ext) <= 1e300) || !(ext > lo && ext < hi)) {
-              sec = fma(gl * (lam - xb), rcp_nr(dbl), lam);
-              if (!(fabs(ext) <= 1e300)) ext = sec;
-            }
           }
-          if (fabs(gl) <= (have3 ? SHP_TAU3 : 1e-7) * Rjl) {  // accept the extrapolated point
-            rin = (fabs(ext) <= 1e300) ? fmin(fmax(ext, lo), hi) : lam;
-            act = false;
-          } else {
-            double nxt = ext;
-            if (!(nxt > lo && nxt < hi)) nxt = sec;
-            if (!(nxt > lo && nxt < hi)) nxt = 0.5 * (lo + hi);
-            if (hi - lo <= 1e-14 * Rjl) {
-              rin = 0.5 * (lo + hi);
-              act = false;
-            } else {
-              rin = nxt;
-              xa = xb; ga = gb; xb = lam; gb = gl; lam = nxt;
+          const bool inb = ext > lo && ext < hi;   // false for NaN and inf
+          const bool accept = fabs(gl) <= (have3 ? SHP_TAU3 : 1e-7) * Rjl;  // accept the extrapolated point
+          const bool tiny = hi - lo <= 1e-14 * Rjl;
+          double res = ext, nxt = ext;
+          bool stop = accept;
+          if (__any(act && (!inb || tiny))) {
+            // the general case, lane by lane with selects: the secant is the fallback of the interpolation, the
+            // midpoint the fallback of both; an accepted point is clamped to the bracket
+            double sec = ext, e2 = ext;
+            if (have3) {
+              const double s2 = fma(gl * (lam - xb), rcp_nr(dbl), lam);
+              const bool fin0 = fabs(ext) <= 1e300;
+              sec = (!fin0 || !inb) ? s2 : ext;
+              e2 = fin0 ? ext : s2;
             }
+            const double mid = 0.5 * (lo + hi);
+            double n2 = (e2 > lo && e2 < hi) ? e2 : sec;
+            n2 = (n2 > lo && n2 < hi) ? n2 : mid;
+            const double accv = (fabs(e2) <= 1e300) ? fmin(fmax(e2, lo), hi) : lam;
+            res = accept ? accv : (tiny ? mid : n2);
+            nxt = n2;
+            stop = accept || tiny;
           }
+          rin = act ? res : rin;
+          act = act && !stop;
+          xa = xb; ga = gb; xb = lam; gb = gl; lam = nxt;
         }
       }
       // a node outside j contributes exactly nothing (r^3 - r^3 under FMA contraction is a rounding residue, and
