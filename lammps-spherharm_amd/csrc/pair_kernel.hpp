@@ -248,6 +248,10 @@ __device__ __forceinline__ double rsqrt_nr1(const double x)
 // (which rescales, iterates and fixes up special cases), accurate to the last ulp or two.
 __device__ __forceinline__ double sqrt_nr(const double x) { return (x > 0.0) ? x * rsqrt_nr(x) : 0.0; }
 
+// sqrt(x) with the one-step root: 2-3 ulp.  For the brackets, first iterate and end-point residual of the inner-radius
+// search and wherever else 1e-15 relative is far inside what the value is used for.
+__device__ __forceinline__ double sqrt_nr1(const double x) { return (x > 0.0) ? x * rsqrt_nr1(x) : 0.0; }
+
 // 1/d to the last ulp or two: v_rcp_f64 + two Newton steps (5 VALU ops instead of
 // the ~12 of an IEEE division); 0 and denormals give inf/NaN, which the callers test.
 __device__ __forceinline__ double rcp_nr(const double d)
@@ -256,6 +260,13 @@ __device__ __forceinline__ double rcp_nr(const double d)
   r = fma(fma(-d, r, 1.0), r, r);
   r = fma(fma(-d, r, 1.0), r, r);
   return r;
+}
+
+// 1/d with ONE Newton step: v_rcp_f64's 2^-26 squared is 2^-52, plus the step's own rounding: 2-3 ulp.
+__device__ __forceinline__ double rcp_nr1(const double d)
+{
+  const double r = __builtin_amdgcn_rcp(d);
+  return fma(fma(-d, r, 1.0), r, r);
 }
 
 // V^e for the exponents the force law usually asks for (m - 1 or m a multiple of 1/4) by square
@@ -773,11 +784,11 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, WEIGHTED ? SHP_WMIN_WA
         const double dj0 = fr[FR_DJ], dj1 = fr[FR_DJ + 1], dj2 = fr[FR_DJ + 2];
         const double bp = uj0 * dj0 + uj1 * dj1 + uj2 * dj2;
         const double rho2l = fr[FR_RHO2];
-        if (!centre_in_bj) lo = bp - sqrt_nr(fma(bp, bp, -(rho2l - fr[FR_RJ2])));
-        lam = bp - sqrt_nr(fma(bp, bp, -(rho2l - rj0 * rj0)));
+        if (!centre_in_bj) lo = bp - sqrt_nr1(fma(bp, bp, -(rho2l - fr[FR_RJ2])));
+        lam = bp - sqrt_nr1(fma(bp, bp, -(rho2l - rj0 * rj0)));
         if (!(lam > lo && lam < hi)) lam = 0.5 * (lo + hi);
         const double q0 = fma(ri, uj0, -dj0), q1 = fma(ri, uj1, -dj1), q2 = fma(ri, uj2, -dj2);
-        ga = gb = sqrt_nr(q0 * q0 + q1 * q1 + q2 * q2) - rj0;
+        ga = gb = sqrt_nr1(q0 * q0 + q1 * q1 + q2 * q2) - rj0;
       }
       if (!act) lam = ri;
       for (int it = 0; it < 60; ++it) {
@@ -811,11 +822,11 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, WEIGHTED ? SHP_WMIN_WA
           // quadratic interpolation (one common denominator) through three afterwards
           double ext;
           if (!have3) {
-            ext = fma(gl * (lam - xb), rcp_nr(dbl), lam);
+            ext = fma(gl * (lam - xb), rcp_nr1(dbl), lam);
           } else {
             const double dab = ga - gb, dal = ga - gl;
             const double num = fma(xa * gb, gl * dbl, fma(lam * ga, gb * dab, -(xb * ga) * (gl * dal)));
-            ext = num * rcp_nr(dab * dal * dbl);
+            ext = num * rcp_nr1(dab * dal * dbl);
           }
           const bool inb = ext > lo && ext < hi;   // false for NaN and inf
           const bool accept = fabs(gl) <= (have3 ? SHP_TAU3 : 1e-7) * Rjl;  // accept the extrapolated point
@@ -827,7 +838,7 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, WEIGHTED ? SHP_WMIN_WA
             // midpoint the fallback of both; an accepted point is clamped to the bracket
             double sec = ext, e2 = ext;
             if (have3) {
-              const double s2 = fma(gl * (lam - xb), rcp_nr(dbl), lam);
+              const double s2 = fma(gl * (lam - xb), rcp_nr1(dbl), lam);
               const bool fin0 = fabs(ext) <= 1e300;
               sec = (!fin0 || !inb) ? s2 : ext;
               e2 = fin0 ? ext : s2;
@@ -874,7 +885,7 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, WEIGHTED ? SHP_WMIN_WA
     double r2, rmu, rpsi;
     ring_eval<L, true>(fr + W.ring + (k - k0) * rowlen, LL, c1, s1, P.trig + (trig_lmajor(L) ? (size_t)P.trig_stride * l : (size_t)(2 * l)), P.trig_stride, r2, rmu, rpsi);
     const double rad = ri * fma(ri, sig, rmu * sig * mu);   // r (r sigma + sigma mu r_mu): multiplies (c, s)
-    const double tan_ = ri * rpsi * rcp_nr(sig);           // (r / sigma) r_psi; sigma > 0 at Gauss-Legendre nodes
+    const double tan_ = ri * rpsi * rcp_nr1(sig);          // (r / sigma) r_psi; sigma > 0 at Gauss-Legendre nodes
     const double A0 = fma(rad, c1, tan_ * s1);
     const double A1 = fma(rad, s1, -tan_ * c1);
     const double A2 = ri * fma(ri, mu, -(sig * sig) * rmu);
