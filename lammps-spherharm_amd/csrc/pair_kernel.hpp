@@ -64,6 +64,13 @@ struct PairParams {
   const int* xcol;       // ... and absolute column indices
   const int* xinfo;      // (lmax+1)^2: l | (m + l) << 8
   const double* gscale;  // (lmax+1)^2 ring-recurrence scale g_lm
+  // particle j in the pair's common frame (compiled orders; jpoly_build below)
+  const double* jval;    // first stage, ELL: (2 lmax + 4)(lmax + 1) rows x (lmax/2+1) values (sh_tables.cpp build_jpoly_ell)
+  const int* jcol;       // ... and indices into the rotated coefficient vector
+  const double* trigj;   // (cos, sin)(m psi_l), m = 0..lmax + 1, of the first nq azimuths, l-major
+  const double* rot;     // compiled orders: [2 w + which][(lmax+1)^2] rotated, scaled coefficient vectors of slot w's
+                         // particles (which 0: i, 1: j), written by pair_rotate_kernel
+  int jpoly;             // 1: the pair records carry the Euler angles of j's frame in the slots of FR_BJ1 / FR_BJ2
   // per-pair records written by pair_setup_kernel (pair_setup.hpp), read here instead of redoing the scalar set-up on
   // 64 lanes: rec[kRecStride * w] = the pair frame FR_* and the Euler cos/sin; rec_i[4 w] = status, shape i, shape j,
   // [rho < R_j]
@@ -110,6 +117,10 @@ constexpr int kPairErrType = 2;   // an atom type outside [1, ntypes]
 #define SHP_MIN_WAVES(L, NEEDV) \
   ((NEEDV) ? (((L) == 0 || (L) == 1 || (L) == 6) ? 6 : 5) : (((L) >= 0 && (L) <= 6) ? 6 : 5))
 #endif
+// kernels that evaluate particle j from per-azimuth polynomials (JPT): a lane's row sits in 4L + 2 registers
+#ifndef SHP_JMIN_WAVES
+#define SHP_JMIN_WAVES(L, NEEDV) (((L) <= 6) ? 4 : (((L) <= 8) ? 3 : 2))
+#endif
 
 // docs/SPEC.md §2.6: residual below which the inverse-quadratic extrapolation is accepted
 #ifndef SHP_TAU3
@@ -133,6 +144,9 @@ constexpr int kRecStride = 40;   // doubles per pair record: the first kRecUsed 
 constexpr int kRecUsed = 37;
 // per-pair scalars live in the frame too: as VALU results they would sit in VGPR pairs for
 // the whole kernel (wave-uniform FP64 values cannot be SGPRs without readfirstlane)
+// With P.jpoly the six slots of FR_BJ1 / FR_BJ2 carry cos, sin of the Euler angles of j's frame M_j = [BJ1 BJ2 BJC]
+// instead (FR_EULERJ): the compiled orders never form a direction in j's body frame.
+enum { FR_EULERJ = 0 };
 enum { FR_BJ1 = 0, FR_BJ2 = 3, FR_BJC = 6, FR_DJ = 9, FR_E1 = 12, FR_E2 = 15, FR_C = 18, FR_D = 21,
        FR_RJ = 24, FR_RJ2 = 25, FR_RHO2 = 26, FR_HW = 27, FR_HM = 28, FR_WSC = 29,
        FR_EULER = 30 /* cos, sin of alpha, beta, gamma */, FR_RHO = 36 };
@@ -144,8 +158,16 @@ struct WaveLdsLayout {
   int trig, v0, v1, ring, qri, qrj, qp, bytes;  // offsets in doubles (qp: in doubles too), total bytes
   int qw;                                        // weighted rule only: the queued nodes' weights
   int coef;                                      // SHP_COEF_LDS ablation build only
+  int pj, gh;                                    // particle j's polynomials: first-stage scratch, per-azimuth table
 };
-__host__ __device__ inline WaveLdsLayout wave_lds_layout(const int L, const int rows, const bool weighted = false)
+// Row of the per-azimuth table: G_l (L + 1 coefficients, descending powers), H_l (L), one pad, then cos(m psi_l) and
+// sin(m psi_l), m = 1..L (phase 1 evaluates r_i with them): 4L + 2 doubles, 16-byte rows.
+__host__ __device__ constexpr int jpoly_row(const int L) { return 4 * L + 2; }
+__host__ __device__ constexpr int jpoly_trig(const int L) { return 2 * L + 2; }   // offset of cos(psi_l) in a row
+// Rows of the first-stage table PJ: (order m, part) for m = 0..L+1 — the order L + 1 is empty (zeros), see jpoly_build.
+__host__ __device__ constexpr int jpoly_rows(const int L) { return 2 * L + 4; }
+__host__ __device__ inline WaveLdsLayout wave_lds_layout(const int L, const int rows, const bool weighted = false,
+                                                         const int nqj = 0)
 {
   WaveLdsLayout w;
   const int ns = (L + 1) * (L + 1);
@@ -154,27 +176,34 @@ __host__ __device__ inline WaveLdsLayout wave_lds_layout(const int L, const int 
   // L = 7 on it lies over the queue, which leaves room for more resident ring rows (L = 12, n_q = 32: +3 %); up to
   // L = 6 it keeps its own place: the wave count is limited elsewhere there (A/B: no gain from 24 instead of 21
   // waves per CU) and the separate layout compiles without a spill under the 80-VGPR bound.
+  // Compiled orders (nqj > 0): the rotations run in pair_rotate_kernel; frame | v0 | ring rows | queue | per-azimuth
+  // polynomials of particle j.
   const bool alias = SHP_ALIAS_FROM_L <= L;
   w.trig = kFrame;
-  w.v0 = alias ? kFrame : w.trig + 6 * (L + 1);
+  w.v0 = (alias || nqj > 0) ? kFrame : w.trig + 6 * (L + 1);
   w.v1 = w.v0 + ns;
-  w.ring = alias ? w.v0 + ns : w.v1 + ns;
+  w.ring = (alias || nqj > 0) ? w.v0 + ns : w.v1 + ns;
   w.ring += w.ring & 1;  // 16-byte aligned rows for ds_read_b128
-  w.qri = w.ring + 4 * rows * (L + 1);
+  // the first stage of particle j's polynomials ((2L+4)(L+1) doubles, +2: a read one past a row's end) lies over the ring rows, which are built later
+  int ringsz = 4 * rows * (L + 1);
+  if (nqj > 0 && rows > 0 && ringsz < jpoly_rows(L) * (L + 1) + 2) ringsz = jpoly_rows(L) * (L + 1) + 2;
+  w.pj = w.ring;
+  w.qri = w.ring + ringsz;
   w.qrj = w.qri + kQueue;
   w.qp = w.qrj + kQueue;
   w.qw = w.qp + kQueue / 4;
   w.coef = w.qw + (weighted ? kQueue : 0);
-  if (alias) {
+  if (alias && nqj == 0) {
     w.trig = w.qri;
     w.v1 = w.trig + 6 * (L + 1);
     if (w.v1 + ns > w.coef) w.coef = w.v1 + ns;  // large L: the scratch is longer than the queue
   }
   w.coef += w.coef & 1;
+  w.gh = w.coef;   // per-azimuth polynomials of particle j: nqj rows, resident for the whole pair
 #ifdef SHP_COEF_LDS
   w.bytes = 8 * (w.coef + sh_chunk_stride(L));
 #else
-  w.bytes = 8 * w.coef;
+  w.bytes = 8 * (w.gh + nqj * jpoly_row(L));
 #endif
   // the epilogue's reduction scratch lies behind the frame, over everything that is dead by then
   if (w.bytes < 8 * (kFrame + kRedDoubles)) w.bytes = 8 * (kFrame + kRedDoubles);
@@ -294,7 +323,7 @@ __device__ __forceinline__ double pow_quarter(const double v, const double e)
 // axis of a vanishing tilt.
 template <int L>
 __device__ __forceinline__ void cap_frame_rotate(const PairParams& P, double* __restrict__ lw, const WaveLdsLayout& W,
-                                                 const int LL, const int si, const int lane)
+                                                 const int LL, const int si, const int lane, const int fr_euler = FR_EULER)
 {
   const int ns = (LL + 1) * (LL + 1);
   double* trig = lw + W.trig;
@@ -302,7 +331,7 @@ __device__ __forceinline__ void cap_frame_rotate(const PairParams& P, double* __
   double* v1 = lw + W.v1;
   // Euler angles (computed per pair by pair_setup_kernel): lanes 0,1,2 tabulate cos/sin(m angle) for alpha, beta, gamma
   if (lane < 3) {
-    const double c1 = lw[FR_EULER + 2 * lane], s1 = lw[FR_EULER + 2 * lane + 1];
+    const double c1 = lw[fr_euler + 2 * lane], s1 = lw[fr_euler + 2 * lane + 1];
     double* t = trig + 2 * (LL + 1) * lane;
     double cm = 1.0, sm = 0.0;
     for (int m = 0; m <= LL; ++m) {
@@ -344,6 +373,42 @@ __device__ __forceinline__ void cap_frame_rotate(const PairParams& P, double* __
     wave_lds_sync();
   }
   // the rotated, scaled coefficients are now in v0
+}
+
+// The rotations as a kernel of their own (compiled orders): ONE WAVE PER (list slot, particle).  Inside the contact
+// kernel a rotation is a chain of five dependent table-load / LDS steps, ~4 500 cycles during which the wave holds its
+// ~120 registers and 8 KB of LDS and issues 85 instructions; with particle j rotated as well that was a third of the
+// contact kernel's time (ablation builds, round 2).  Here a wave needs 24 registers and 1.2 KB, forty of them fit a
+// CU, and the chains of different waves overlap.  Output: (L+1)^2 doubles per particle, 784 B per pair at L = 6, read
+// back by the contact kernel with two coalesced loads at its start.
+struct RotLds {
+  static __host__ __device__ constexpr int euler() { return 0; }
+  static __host__ __device__ constexpr int trig() { return 8; }
+  static __host__ __device__ int v0(const int L) { return 8 + 6 * (L + 1); }
+  static __host__ __device__ int v1(const int L) { return v0(L) + (L + 1) * (L + 1); }
+  static __host__ __device__ int bytes(const int L) { return 8 * (v1(L) + (L + 1) * (L + 1)); }
+};
+template <int L>
+__global__ void __launch_bounds__(64) pair_rotate_kernel(const PairParams P, double* __restrict__ rot)
+{
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_rot[];
+  double* lw = (double*)smem_rot;
+  const int lane = threadIdx.x;
+  const int w = blockIdx.x >> 1, which = blockIdx.x & 1;
+  const int* rid = P.rec_i + 4 * (size_t)w;
+  if (rid[0] == 0) return;   // no contact pair in this slot (or a shape index outside the table): nothing will read it
+  const int shape = rid[1 + which];
+  const int LL = (L >= 0) ? L : P.lmax;
+  if (lane < 6) lw[lane] = P.rec[(size_t)kRecStride * w + (which ? FR_EULERJ : FR_EULER) + lane];
+  WaveLdsLayout W;
+  W.trig = RotLds::trig();
+  W.v0 = RotLds::v0(LL);
+  W.v1 = RotLds::v1(LL);
+  wave_lds_sync();
+  cap_frame_rotate<L>(P, lw, W, LL, shape, lane, RotLds::euler());
+  const int ns = (LL + 1) * (LL + 1);
+  double* out = rot + (size_t)blockIdx.x * ns;
+  for (int e = lane; e < ns; e += 64) out[e] = lw[W.v0 + e];
 }
 
 // Ring tables of rings k0 .. k0 + nrows - 1 from the rotated coefficients.
@@ -470,12 +535,190 @@ __device__ __forceinline__ void ring_eval(const double* __restrict__ row, const 
   }
 }
 
+// ---- particle j in the pair's COMMON frame ------------------------------------------------------------------------
+// Every point at which a pair evaluates r_j — a cap node's surface point r_i u, or a point x_i + lambda u of the
+// node's ray in the inner-radius search — lies in the half-plane through the line of centres that contains u: seen
+// from x_j in the frame (e1, e2, c) it has the node's azimuth psi_l, and only its polar angle varies,
+//   cos(theta_j) = (lambda mu_k - rho) / s,   sin(theta_j) = lambda sigma_k / s,   s^2 = lambda^2 - 2 lambda mu_k rho + rho^2.
+// So particle j gets the treatment of particle i: its expansion is rotated into the common frame (the same
+// cap_frame_rotate with M_j = [R_j^T e1, R_j^T e2, R_j^T c], whose Euler angles come with the pair record), where
+//   r_j(mu, psi) = sum_m sigma^m [cos(m psi) Wc_m(mu) + sin(m psi) Ws_m(mu)],   sigma = sqrt(1 - mu^2).
+// For a FIXED azimuth the even orders sum to a polynomial G_l(mu) of degree L (sigma^m = (1 - mu^2)^(m/2)) and the odd
+// ones to sigma H_l(mu), H_l of degree L - 1:   r_j = G_l(mu_j) + sigma_j H_l(mu_j)   — 2L + 1 coefficients and 2L + 1
+// v_fma_f64 per evaluation instead of (L+1)^2 coefficients and ~(L+1)^2 + 4L operations of a body-frame evaluation
+// (L = 6: 13 against 69, and no direction in j's body frame: 14 more), kept in VGPRs across the inner-radius
+// iterations (and across phase 1, where a lane's azimuth does not change when 2 n_q divides 64).  The azimuths
+// psi_l and psi_(l + n_q) = psi_l + pi share a row: G is the same, H changes sign.
+// Built per pair in two steps from the rotated, scaled vector v0 (both sparse matrix-vector products):
+//   1. PJ[2m + part][k] = sum_n v0[n^2 + n +- m] E_nm[k]   (host table P.jval / P.jcol, ELL rows; sh_tables.cpp)
+//   2. G_l[k] = sum_(m even) cos(m psi_l) PJ[2m][k] + sin(m psi_l) PJ[2m+1][k],  H_l likewise over the odd m.
+// The first-stage rows of a lane (NP passes of 64 rows, XW entries each) and the cos/sin of its orders for the first
+// 16 azimuths: constants of the launch, requested at the very start of the kernel so that their latency runs
+// beside that of the pair's record (small orders only: 24 + 16 registers at L = 6).
+template <int L>
+struct JPolyPre {
+  static constexpr int K = L + 1, NR = jpoly_rows(L) * K, XW = L / 2 + 1, NP = (NR + 63) / 64, NM = L / 2 + 1;
+  static constexpr bool on = NP * XW <= 8;
+  double val[on ? NP * XW : 1];
+  int col[on ? NP * XW : 1];
+  double cs[NM], sn[NM];
+  __device__ __forceinline__ void fetch(const PairParams& P, const int lane, const int nq)
+  {
+    if constexpr (on) {
+#pragma unroll
+      for (int ps = 0; ps < NP; ++ps) {
+        const int o = lane + 64 * ps;
+        const size_t at = (size_t)(o < NR ? o : 0) * XW;
+#pragma unroll
+        for (int t = 0; t < XW; ++t) {
+          val[ps * XW + t] = P.jval[at + t];
+          col[ps * XW + t] = P.jcol[at + t];
+        }
+      }
+    }
+    const int l = lane & 15, par = (lane >> 4) & 1;
+    const double* tj = P.trigj + (size_t)(l < nq ? l : 0) * (2 * (L + 2)) + 2 * par;
+#pragma unroll
+    for (int a = 0; a < NM; ++a) {
+      cs[a] = tj[4 * a];
+      sn[a] = tj[4 * a + 1];
+    }
+  }
+};
+
+template <int L>
+__device__ __forceinline__ void jpoly_build(const PairParams& P, double* __restrict__ lw, const WaveLdsLayout& W,
+                                            const int lane, const int nq, const JPolyPre<L>& pre)
+{
+  // K powers per polynomial; the tables carry one order more than exist (m = L + 1: empty rows of PJ, a real
+  // cos/sin pair) so that the azimuth stage below needs no guard on its reads
+  constexpr int K = L + 1, NR = jpoly_rows(L) * K, XW = L / 2 + 1, RS = jpoly_row(L);
+  const double* v0 = lw + W.v0;
+  double* pj = lw + W.pj;
+  if constexpr (JPolyPre<L>::on) {
+#pragma unroll
+    for (int ps = 0; ps < JPolyPre<L>::NP; ++ps) {
+      const int o = lane + 64 * ps;
+      double acc = 0.0;
+#pragma unroll
+      for (int t = 0; t < XW; ++t) acc = fma(pre.val[ps * XW + t], v0[pre.col[ps * XW + t]], acc);
+      if (o < NR) pj[o] = acc;
+    }
+  } else {
+    for (int o = lane; o < NR; o += 64) {
+      const double* val = P.jval + (size_t)o * XW;
+      const int* col = P.jcol + (size_t)o * XW;
+      double acc = 0.0;
+#pragma unroll
+      for (int t = 0; t < XW; ++t) acc = fma(val[t], v0[col[t]], acc);
+      pj[o] = acc;
+    }
+  }
+  wave_lds_sync();
+  // Azimuth stage.  Lanes are (azimuth l, parity of m, parity of k), 16 azimuths per pass: a lane loads the
+  // cos/sin(m psi_l) of its orders m = par, par + 2, ... once and walks its powers k = kq, kq + 2, ...; every LDS
+  // address is the lane's base plus an immediate.  G (par = 0) has the powers 0..L, H (par = 1) the powers 0..L-1.
+  double* gh = lw + W.gh;
+  constexpr int NM = L / 2 + 1;                  // orders of one parity (the last may be the empty order L + 1)
+  const int par = (lane >> 4) & 1, kq = lane >> 5;
+  const int kmax = L - par;
+  const double* pjl = pj + (2 * par) * K + kq;   // PJ[2 (2a + par) + part][kq + 2 b] at pjl[(4 a + part) K + 2 b]
+  for (int l0 = 0; l0 < nq; l0 += 16) {
+    const int l = l0 + (lane & 15);
+    const bool lok = l < nq;
+    double cs[NM], sn[NM];
+    if (l0 == 0) {   // wave-uniform: requested at the start of the kernel
+#pragma unroll
+      for (int a = 0; a < NM; ++a) {
+        cs[a] = pre.cs[a];
+        sn[a] = pre.sn[a];
+      }
+    } else {
+      const double* tj = P.trigj + (size_t)(lok ? l : 0) * (2 * (L + 2)) + 2 * par;   // (cos, sin)(m psi_l) at tj[4a], tj[4a+1]
+#pragma unroll
+      for (int a = 0; a < NM; ++a) {
+        cs[a] = tj[4 * a];
+        sn[a] = tj[4 * a + 1];
+      }
+    }
+    if (lok && kq == 0) {   // the row's own cos/sin(m psi_l), m = 1..L: orders of this lane's parity
+      double* tr = gh + l * RS + jpoly_trig(L) - 1;
+#pragma unroll
+      for (int a = 0; a < NM; ++a) {
+        const int m = 2 * a + par;
+        if (m >= 1 && m <= L) {
+          tr[m] = cs[a];
+          tr[L + m] = sn[a];
+        }
+      }
+    }
+    // column of the power k in a row: G: L - k; H: 2L - k  (descending powers, Horner order)
+    double* out = gh + (lok ? l : 0) * RS + (par ? 2 * L : L) - kq;
+#pragma unroll
+    for (int b = 0; b <= L / 2; ++b) {
+      double acc = 0.0;
+#pragma unroll
+      for (int a = 0; a < NM; ++a) {
+        acc = fma(cs[a], pjl[(4 * a) * K + 2 * b], acc);
+        acc = fma(sn[a], pjl[(4 * a + 1) * K + 2 * b], acc);
+      }
+      if (lok && kq + 2 * b <= kmax) out[-2 * b] = acc;
+    }
+  }
+  wave_lds_sync();
+}
+
+// r_j at polar angle (mu, sigma) of the common frame from a lane's row of the per-azimuth table; `sig` carries the
+// sign of the azimuth's half (l >= n_q: -).  The row is read from LDS at every evaluation: the 64 lanes of a wave
+// address at most n_q distinct rows (the hardware broadcasts), 7 ds_read_b128 at L = 6 beside ~25 v_fma_f64 — and the
+// 2L + 1 coefficients do not sit in 4L + 2 registers through the node loops (held there they cost the kernel a wave
+// per SIMD, and with the waves the cover for its dependent FP64 chains: 11 cycles from one v_fma_f64 to the next).
+template <int L>
+__device__ __forceinline__ double jpoly_eval(const double* __restrict__ row, const double mu, const double sig)
+{
+  double g = row[0];
+#pragma unroll
+  for (int t = 1; t <= L; ++t) g = fma(g, mu, row[t]);
+  if constexpr (L >= 1) {
+    double h = row[L + 1];
+#pragma unroll
+    for (int t = L + 2; t <= 2 * L; ++t) h = fma(h, mu, row[t]);
+    g = fma(sig, h, g);
+  }
+  return g;
+}
+
+// A lane's row of the per-azimuth table in registers: phase 1 keeps it from slab to slab when the lanes' azimuths do
+// not change (n_q divides 64), the inner-radius search across its iterations.
+template <int L>
+struct JPoly {
+  double c[2 * L + 1];
+  __device__ __forceinline__ void load(const double* __restrict__ row)
+  {
+#pragma unroll
+    for (int t = 0; t < 2 * L + 1; ++t) c[t] = row[t];
+  }
+  __device__ __forceinline__ double eval(const double mu, const double sig) const
+  {
+    double g = c[0];
+#pragma unroll
+    for (int t = 1; t <= L; ++t) g = fma(g, mu, c[t]);
+    if constexpr (L >= 1) {
+      double h = c[L + 1];
+#pragma unroll
+      for (int t = L + 2; t <= 2 * L; ++t) h = fma(h, mu, c[t]);
+      g = fma(sig, h, g);
+    }
+    return g;
+  }
+};
+
 // WEIGHTED (SPEC §2.8): phase 1 keeps the residuals g~ of three consecutive slabs in registers, so that a
 // node's azimuth and ring neighbours are a cross-lane read away, and queues every node with a positive
 // covered fraction together with that fraction; phase 2 scales the node's weight by it.  n_q <= 32 (a ring
 // neighbour is at most one slab away) and ring groups of at least two slabs' worth of rings: checked on the host.
-template <int L, bool NEEDV, bool WEIGHTED = false>
-__global__ void __launch_bounds__(64 * kMaxWavesPerBlock, WEIGHTED ? SHP_WMIN_WAVES(L) : SHP_MIN_WAVES(L, NEEDV)) pair_contact_kernel(const PairParams P)
+template <int L, bool NEEDV, bool WEIGHTED = false, bool JPT = false>
+__global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L, NEEDV) : (WEIGHTED ? SHP_WMIN_WAVES(L) : SHP_MIN_WAVES(L, NEEDV))) pair_contact_kernel(const PairParams P)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   int lane = threadIdx.x & 63;
@@ -484,7 +727,11 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, WEIGHTED ? SHP_WMIN_WA
   if (w >= P.npairs) return;
   const int LL = (L >= 0) ? L : P.lmax;
   const int nq = P.nq;
-  const WaveLdsLayout W = wave_lds_layout(LL, P.ring_rows, WEIGHTED);
+  // compiled orders: particle j from per-azimuth polynomials in the pair's common frame (jpoly_build above); the
+  // run-time-order kernel keeps the body-frame evaluation sh_eval_rt
+  constexpr bool JP = JPT && (L >= 0) && !WEIGHTED;
+  constexpr int LJ = JP ? L : 0;
+  const WaveLdsLayout W = wave_lds_layout(LL, P.ring_rows, WEIGHTED, JP ? nq : 0);
   // The frame and ring tables are loop invariant: a plain LDS load would be
   // hoisted out of the node loops and pinned in VGPRs, which is what they are
   // in LDS to avoid.  Each loop iteration therefore re-derives its base pointer
@@ -499,14 +746,45 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, WEIGHTED ? SHP_WMIN_WA
   const int status = rid[0];
   if (status == 0) return;   // bounding spheres apart (SPEC §2.1) or a shape index outside the table; wave-uniform
   const int si = rid[1], sj = rid[2];
+  (void)si; (void)sj;
   const bool centre_in_bj = rid[3] != 0;  // rho < Rj
+  // compiled orders: both particles' rotated coefficient vectors come from pair_rotate_kernel; everything the
+  // prologue reads from memory is requested here, before the first wait
+  constexpr int NSL = JP ? ((LJ + 1) * (LJ + 1) + 63) / 64 : 1;
+  double vi[NSL], vj[NSL];
+  JPolyPre<LJ> pre;
+  if constexpr (JP) {
+    constexpr int ns = (LJ + 1) * (LJ + 1);
+    const double* rv = P.rot + (size_t)(2 * w) * ns;
+#pragma unroll
+    for (int t = 0; t < NSL; ++t) {
+      const int e = lane + 64 * t;
+      vi[t] = rv[e < ns ? e : 0];
+      vj[t] = rv[ns + (e < ns ? e : 0)];
+    }
+    pre.fetch(P, lane, nq);
+  }
   if (lane < kRecUsed) lw[lane] = P.rec[(size_t)kRecStride * w + lane];
+  if constexpr (JP) {
+#pragma unroll
+    for (int t = 0; t < NSL; ++t)
+      if (lane + 64 * t < (LJ + 1) * (LJ + 1)) lw[W.v0 + lane + 64 * t] = vj[t];
+  }
   wave_lds_sync();
 #if defined(SHP_ABL) && SHP_ABL == 1   // timing-only build: stop after the pair prologue
   asm volatile("" ::"v"(lw[lane & 31]));
   return;
 #endif
-  cap_frame_rotate<L>(P, lw, W, LL, si, lane);
+  if constexpr (JP) {
+    // particle j first: its vector shares the place of particle i's, which has to stay for the ring groups
+    jpoly_build<LJ>(P, lw, W, lane, nq, pre);
+#pragma unroll
+    for (int t = 0; t < NSL; ++t)
+      if (lane + 64 * t < (LJ + 1) * (LJ + 1)) lw[W.v0 + lane + 64 * t] = vi[t];
+    wave_lds_sync();
+  } else {
+    cap_frame_rotate<L>(P, lw, W, LL, si, lane);
+  }
 #if defined(SHP_ABL) && SHP_ABL == 4   // timing-only build: stop after the coefficient rotation
   asm volatile("" ::"v"(lw[W.v0 + lane]));
   return;
@@ -526,14 +804,21 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, WEIGHTED ? SHP_WMIN_WA
 #define cwj (SHP_LDS() + W.coef)
 #endif
   const int lrt = P.lmax;
+  (void)rc; (void)lrt;
   const double* fr = SHP_LDS();
 
   // SPEC §2.6: centre of i inside j (only possible when rho < Rj)
   bool centre_inside = false;
   if (NEEDV && centre_in_bj) {
     const double rho = fr[FR_RHO];
-    const double ir = rcp_nr(rho);
-    const double rj = sh_eval<L>(rc, cwj, lrt, -fr[FR_DJ] * ir, -fr[FR_DJ + 1] * ir, -fr[FR_DJ + 2] * ir);
+    double rj;
+    if constexpr (JP) {
+      // x_i seen from x_j lies on the axis, opposite to c: mu = -1, sigma = 0, any azimuth
+      rj = jpoly_eval<LJ>(fr + W.gh, -1.0, 0.0);
+    } else {
+      const double ir = rcp_nr(rho);
+      rj = sh_eval<L>(rc, cwj, lrt, -fr[FR_DJ] * ir, -fr[FR_DJ + 1] * ir, -fr[FR_DJ + 2] * ir);
+    }
     centre_inside = (rho - rj <= 0.0);
   }
 
@@ -542,7 +827,11 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, WEIGHTED ? SHP_WMIN_WA
   // p / npsi for 0 <= p < Q <= 2^15 as a multiply-shift: exact because
   // magic * npsi - 2^24 < npsi <= 256 < 2^24 / 2^15
   const unsigned magic = ((1u << 24) + (unsigned)npsi - 1u) / (unsigned)npsi;
-  const int nslabs = (Q + 63) >> 6;
+  // lanes per ring in phase 1: the JPT kernels give a lane the node PAIR (k, l), (k, l + n_q) — the two azimuths of
+  // a row of particle j's table, and r_i at both from one pass over the ring row (even orders + / - odd orders)
+  const int per_ring = JP ? nq : npsi;
+  const unsigned magicr = ((1u << 24) + (unsigned)per_ring - 1u) / (unsigned)per_ring;
+  const int nslabs = (nq * per_ring + 63) >> 6;
   const int rowlen = 4 * (LL + 1);
 
   double aV = 0.0, aS0 = 0.0, aS1 = 0.0, aS2 = 0.0, aT0 = 0.0, aT1 = 0.0, aT2 = 0.0;
@@ -550,6 +839,14 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, WEIGHTED ? SHP_WMIN_WA
   double wg1 = 0.0, wg2 = 0.0, wri1 = 0.0, wrj1 = 0.0;  // WEIGHTED: residuals of slabs t-1, t-2; r_i, r_j of slab t-1
   bool win1 = false;
   const bool aligned = (npsi <= 64) && ((64 % npsi) == 0);  // wave-uniform
+  // JPT: a lane's azimuth is the same in every slab when n_q divides 64; its rows then stay in registers
+  const bool jaligned = (nq <= 64) && ((64 % nq) == 0);
+  bool jp_stale = true;          // wave-uniform: `jp` does not hold this lane's phase-1 row
+  JPoly<LJ> jp;
+  // the second node of a lane's pair waits here while a full batch is drained (the queue holds 128)
+  bool pend = false, pend_in = false;   // pend: wave-uniform
+  int pend_p = 0;
+  double pend_ri = 0.0, pend_rj = 0.0;
 
   // Ring groups: the tables of P.ring_rows consecutive rings are resident at a time (all nq of
   // them unless that would starve the CU of waves); the queue is drained at the end of a group.
@@ -558,9 +855,9 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, WEIGHTED ? SHP_WMIN_WA
   // group runs one iteration past the last slab.  The host sizes ring_rows so that every group advances.
   while (WEIGHTED ? (slab <= nslabs) : (slab < nslabs)) {
   const int sfirst = (WEIGHTED && slab > 0) ? slab - 1 : slab;
-  const int k0 = (int)(((unsigned)(sfirst << 6) * magic) >> 24);
+  const int k0 = (int)(((unsigned)(sfirst << 6) * magicr) >> 24);
   const int kend = (k0 + P.ring_rows < nq) ? k0 + P.ring_rows : nq;
-  const int slab_end = (kend == nq) ? (WEIGHTED ? nslabs + 1 : nslabs) : ((kend * npsi) >> 6);
+  const int slab_end = (kend == nq) ? (WEIGHTED ? nslabs + 1 : nslabs) : ((kend * per_ring) >> 6);
   if (slab_end <= slab) return;  // cannot happen with the host's ring_rows; never spin
   {
     double* lr = SHP_LDS();
@@ -681,6 +978,75 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, WEIGHTED ? SHP_WMIN_WA
       wrj1 = rj00;
       win1 = in0;
     }
+    } else if constexpr (JP) {
+    // queue append of one node per lane flagged `in` (ballot + prefix count)
+#define SHP_PUSH(in, pn, rin_, rjn_)                                                                                  \
+    {                                                                                                                  \
+      const unsigned long long m_ = __ballot(in);                                                                      \
+      if (m_ != 0ULL) {                                                                                                \
+        if (in) {                                                                                                      \
+          const int pos_ = (qhead + qcount + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m_ >> 32),                      \
+                                                    __builtin_amdgcn_mbcnt_lo((unsigned)m_, 0u))) & (kQueue - 1);     \
+          double* lq_ = SHP_LDS();                                                                                     \
+          ((unsigned short*)(lq_ + W.qp))[pos_] = (unsigned short)(pn);                                                \
+          lq_[W.qri + pos_] = (rin_);                                                                                  \
+          lq_[W.qrj + pos_] = (rjn_);                                                                                  \
+        }                                                                                                              \
+        qcount += __builtin_popcountll(m_);                                                                            \
+      }                                                                                                                \
+    }
+    if (pend) {   // wave-uniform
+      SHP_PUSH(pend_in, pend_p, pend_ri, pend_rj);
+      pend = false;
+    }
+    while (qcount < 64 && slab < slab_end) {
+      fr = SHP_LDS();
+      const int pp = (slab << 6) + lane;   // node pair: ring k, azimuths l and l + n_q
+      ++slab;
+      const bool valid = pp < nq * nq;
+      const int k = valid ? (int)(((unsigned)pp * magicr) >> 24) : 0;
+      const int l = valid ? pp - k * nq : 0;
+      if (!jaligned || jp_stale) {   // wave-uniform
+        jp.load(fr + W.gh + l * jpoly_row(LJ));
+        jp_stale = false;
+      }
+      const double* row = fr + W.ring + (k - k0) * rowlen;
+      const double mu = row[1], sig = row[3];
+      // r_i at the two azimuths: psi + pi changes the sign of the odd orders
+      const double* tg = fr + W.gh + l * jpoly_row(LJ) + jpoly_trig(LJ) - 1;   // cos(m psi_l) at tg[m], sin at tg[L + m]
+      double re = row[0], ro = 0.0;
+#pragma unroll
+      for (int m = 1; m <= LJ; ++m) {
+        const double A = row[4 * m], B = row[4 * m + 1];
+        if (m & 1) ro = fma(A, tg[m], fma(B, tg[LJ + m], ro));
+        else re = fma(A, tg[m], fma(B, tg[LJ + m], re));
+      }
+      const double ria = re + ro, rib = re - ro;
+      const double rho = fr[FR_RHO], rj2 = fr[FR_RJ2];
+      const double qa0 = fma(ria, mu, -rho), qa1 = ria * sig;
+      const double qb0 = fma(rib, mu, -rho), qb1 = -rib * sig;
+      const double sa2 = fma(qa0, qa0, qa1 * qa1), sb2 = fma(qb0, qb0, qb1 * qb1);
+      const bool canda = valid && (sa2 < rj2), candb = valid && (sb2 < rj2);
+      if (!__any(canda || candb)) continue;   // wave-uniform: all 128 nodes miss B_j
+      const bool za = !(sa2 > 0.0), zb = !(sb2 > 0.0);
+      const double inva = rsqrt_nr1(fmax(sa2, 1e-300)), invb = rsqrt_nr1(fmax(sb2, 1e-300));
+      const double rjae = jp.eval(qa0 * inva, qa1 * inva), rjbe = jp.eval(qb0 * invb, qb1 * invb);
+      const double Rjl = fr[FR_RJ];
+      const double rja = za ? Rjl : rjae, rjb = zb ? Rjl : rjbe;
+      const bool ina = canda && (za || sa2 * inva < rja), inb = candb && (zb || sb2 * invb < rjb);
+      const int pa = k * npsi + l;
+      SHP_PUSH(ina, pa, ria, rja);
+      if (qcount >= 64) {   // wave-uniform: a batch is ready; the second nodes wait in registers
+        pend = __any(inb);
+        pend_in = inb;
+        pend_p = pa + nq;
+        pend_ri = rib;
+        pend_rj = rjb;
+        break;
+      }
+      SHP_PUSH(inb, pa + nq, rib, rjb);
+    }
+#undef SHP_PUSH
     } else {
     while (qcount < 64 && slab < slab_end) {
       fr = SHP_LDS();
@@ -734,7 +1100,8 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, WEIGHTED ? SHP_WMIN_WA
       qcount += __builtin_popcountll(m);
     }
     }
-    if (qcount == 0) break;
+    if (qcount == 0 && !pend) break;
+    if (qcount == 0) continue;   // only the waiting second nodes are left: queue them
 #if defined(SHP_ABL) && SHP_ABL == 3   // timing-only build: phase 1 only, the queue is discarded
     qhead = (qhead + qcount) & (kQueue - 1);
     qcount = 0;
@@ -773,22 +1140,41 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, WEIGHTED ? SHP_WMIN_WA
     if (NEEDV) {
       // SPEC §2.6 inner radius, all lanes in lock step
       const double rj0 = fr[W.qrj + e];
-      const double a1 = sig * c1, a2 = sig * s1;
-      const double uj0 = fma(a1, fr[FR_BJ1], fma(a2, fr[FR_BJ2], mu * fr[FR_BJC]));
-      const double uj1 = fma(a1, fr[FR_BJ1 + 1], fma(a2, fr[FR_BJ2 + 1], mu * fr[FR_BJC + 1]));
-      const double uj2 = fma(a1, fr[FR_BJ1 + 2], fma(a2, fr[FR_BJ2 + 2], mu * fr[FR_BJC + 2]));
+      // the node's ray seen from x_j: compiled orders (axial, signed radial) = (lambda mu - rho, +-lambda sigma) in the
+      // common frame; run-time-order kernel lambda u_j - d_j in j's body frame
+      double uj0, uj1, uj2 = 0.0;
+      if constexpr (JP) {
+        jp.load(fr + W.gh + (l >= nq ? l - nq : l) * jpoly_row(LJ));   // this node's row of particle j's table
+        jp_stale = true;
+        uj0 = mu;
+        uj1 = (l >= nq) ? -sig : sig;
+      } else {
+        const double a1 = sig * c1, a2 = sig * s1;
+        uj0 = fma(a1, fr[FR_BJ1], fma(a2, fr[FR_BJ2], mu * fr[FR_BJC]));
+        uj1 = fma(a1, fr[FR_BJ1 + 1], fma(a2, fr[FR_BJ2 + 1], mu * fr[FR_BJC + 1]));
+        uj2 = fma(a1, fr[FR_BJ1 + 2], fma(a2, fr[FR_BJ2 + 2], mu * fr[FR_BJC + 2]));
+      }
       bool act = active && !centre_inside && !outside;
       // three most recent points: (xa,ga) oldest, (xb,gb), (lam,gl) newest
       double lo = 0.0, hi = ri, lam, xa = ri, ga, xb = ri, gb;
       {
-        const double dj0 = fr[FR_DJ], dj1 = fr[FR_DJ + 1], dj2 = fr[FR_DJ + 2];
-        const double bp = uj0 * dj0 + uj1 * dj1 + uj2 * dj2;
+        double bp, s2i;
+        if constexpr (JP) {
+          const double rho = fr[FR_RHO];
+          bp = mu * rho;   // u . d: d = rho c
+          const double q0 = fma(ri, uj0, -rho), q1 = ri * uj1;
+          s2i = fma(q0, q0, q1 * q1);
+        } else {
+          const double dj0 = fr[FR_DJ], dj1 = fr[FR_DJ + 1], dj2 = fr[FR_DJ + 2];
+          bp = uj0 * dj0 + uj1 * dj1 + uj2 * dj2;
+          const double q0 = fma(ri, uj0, -dj0), q1 = fma(ri, uj1, -dj1), q2 = fma(ri, uj2, -dj2);
+          s2i = q0 * q0 + q1 * q1 + q2 * q2;
+        }
         const double rho2l = fr[FR_RHO2];
         if (!centre_in_bj) lo = bp - sqrt_nr1(fma(bp, bp, -(rho2l - fr[FR_RJ2])));
         lam = bp - sqrt_nr1(fma(bp, bp, -(rho2l - rj0 * rj0)));
         if (!(lam > lo && lam < hi)) lam = 0.5 * (lo + hi);
-        const double q0 = fma(ri, uj0, -dj0), q1 = fma(ri, uj1, -dj1), q2 = fma(ri, uj2, -dj2);
-        ga = gb = sqrt_nr1(q0 * q0 + q1 * q1 + q2 * q2) - rj0;
+        ga = gb = sqrt_nr1(s2i) - rj0;
       }
       if (!act) lam = ri;
       for (int it = 0; it < 60; ++it) {
@@ -798,12 +1184,22 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, WEIGHTED ? SHP_WMIN_WA
         if (lane == 0) atomicAdd(&P.dbg[5], 1ULL);
         if (act) atomicAdd(&P.dbg[6], 1ULL);
 #endif
-        const double y0 = fma(lam, uj0, -fr[FR_DJ]), y1 = fma(lam, uj1, -fr[FR_DJ + 1]),
-                     y2 = fma(lam, uj2, -fr[FR_DJ + 2]);
-        const double ss2 = y0 * y0 + y1 * y1 + y2 * y2;
+        double y0, y1, y2 = 0.0, ss2;
+        if constexpr (JP) {
+          y0 = fma(lam, uj0, -fr[FR_RHO]);
+          y1 = lam * uj1;
+          ss2 = fma(y0, y0, y1 * y1);
+        } else {
+          y0 = fma(lam, uj0, -fr[FR_DJ]);
+          y1 = fma(lam, uj1, -fr[FR_DJ + 1]);
+          y2 = fma(lam, uj2, -fr[FR_DJ + 2]);
+          ss2 = y0 * y0 + y1 * y1 + y2 * y2;
+        }
         const bool z0 = !(ss2 > 0.0);
         const double iv = rsqrt_nr1(fmax(ss2, 1e-300));
-        const double rj = sh_eval<L>(rc, cwj, lrt, y0 * iv, y1 * iv, y2 * iv);
+        double rj;
+        if constexpr (JP) rj = jp.eval(y0 * iv, y1 * iv);
+        else rj = sh_eval<L>(rc, cwj, lrt, y0 * iv, y1 * iv, y2 * iv);
         const double Rjl = fr[FR_RJ];
         const double gl = z0 ? -Rjl : ss2 * iv - rj;
         // The update has no divergent control flow: every lane goes through it, and a lane that is done (or never was
@@ -1021,17 +1417,30 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, WEIGHTED ? SHP_WMIN_WA
 // Host-callable launcher, one per compiled order (pair_kernels_L*.hip).
 typedef void (*pair_launch_fn)(const PairParams&, bool needv, hipStream_t);
 // Register / LDS footprint of the kernel that launch would pick (occupancy evidence for bench.py).
-typedef hipError_t (*pair_attr_fn)(bool needv, bool weighted, hipFuncAttributes*);
+typedef hipError_t (*pair_attr_fn)(bool needv, bool weighted, hipFuncAttributes*, bool jpoly);
 
 template <int L>
-hipError_t pair_contact_attributes(bool needv, bool weighted, hipFuncAttributes* a)
+hipError_t pair_contact_attributes(bool needv, bool weighted, hipFuncAttributes* a, bool jpoly = false)
 {
   if (weighted) {
     if constexpr (L >= 0) return hipFuncGetAttributes(a, (const void*)pair_contact_kernel<L, true, true>);
     return hipErrorInvalidValue;
   }
+  if constexpr (L >= 0) {
+    if (jpoly)
+      return needv ? hipFuncGetAttributes(a, (const void*)pair_contact_kernel<L, true, false, true>)
+                   : hipFuncGetAttributes(a, (const void*)pair_contact_kernel<L, false, false, true>);
+  }
   return needv ? hipFuncGetAttributes(a, (const void*)pair_contact_kernel<L, true>)
                : hipFuncGetAttributes(a, (const void*)pair_contact_kernel<L, false>);
+}
+
+template <typename K>
+static inline void launch_contact_one(K kern, const dim3 grid, const dim3 block, const size_t lds, hipStream_t st,
+                                      const PairParams& P)
+{
+  if (lds > 65536) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(kern, grid, block, lds, st, P);
 }
 
 template <int L>
@@ -1043,22 +1452,21 @@ void launch_pair_contact(const PairParams& P, bool needv, hipStream_t st)
   const size_t lds = (size_t)wpb * P.wave_lds_bytes;
   if (P.rule) {
     // SPEC §2.8; one instantiation (with the volume path) serves both force laws
-    if constexpr (L >= 0) {
-      if (lds > 65536) (void)hipFuncSetAttribute((const void*)pair_contact_kernel<L, true, true>,
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      hipLaunchKernelGGL((pair_contact_kernel<L, true, true>), grid, block, lds, st, P);
-    }
+    if constexpr (L >= 0) launch_contact_one(pair_contact_kernel<L, true, true>, grid, block, lds, st, P);
     return;
   }
-  if (needv) {
-    if (lds > 65536) (void)hipFuncSetAttribute((const void*)pair_contact_kernel<L, true>,
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((pair_contact_kernel<L, true>), grid, block, lds, st, P);
-  } else {
-    if (lds > 65536) (void)hipFuncSetAttribute((const void*)pair_contact_kernel<L, false>,
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((pair_contact_kernel<L, false>), grid, block, lds, st, P);
+  if constexpr (L >= 0) {
+    if (P.jpoly) {
+      // both particles' coefficient rotations, one wave each, then the contact kernel that reads them
+      hipLaunchKernelGGL((pair_rotate_kernel<L>), dim3(2 * (unsigned)P.npairs), dim3(64), RotLds::bytes(L), st, P,
+                         const_cast<double*>(P.rot));
+      if (needv) launch_contact_one(pair_contact_kernel<L, true, false, true>, grid, block, lds, st, P);
+      else launch_contact_one(pair_contact_kernel<L, false, false, true>, grid, block, lds, st, P);
+      return;
+    }
   }
+  if (needv) launch_contact_one(pair_contact_kernel<L, true>, grid, block, lds, st, P);
+  else launch_contact_one(pair_contact_kernel<L, false>, grid, block, lds, st, P);
 }
 
 }  // namespace shp

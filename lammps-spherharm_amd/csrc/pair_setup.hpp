@@ -19,6 +19,38 @@ constexpr int kSetupPad = kRecStride + 1;   // LDS row stride: odd, so that the 
 
 __device__ __forceinline__ void pair_setup_one(const PairParams& P, const int w, double* __restrict__ o, int* __restrict__ ri);
 
+// cos, sin of the Euler angles of M = [b1 b2 bc] = Rz(alpha) Ry(beta) Rz(gamma) (pair_kernel.hpp cap_frame_rotate), six
+// doubles.  sin(beta) from the x,y components of the pole, NOT sqrt(1 - cos^2): near the poles the latter is
+// quantised at 1e-8 and rotates by a wrong tilt (4.8e-9 in r at L = 6, caught by tests/test_host_tables.py); gamma
+// from the WELL CONDITIONED sum (cos beta >= 0) or difference of the two angles.
+__device__ __forceinline__ void euler_zyz(const double* b1, const double* b2, const double* bc, double* __restrict__ o)
+{
+  const double cb = bc[2];
+  const double sb2 = bc[0] * bc[0] + bc[1] * bc[1];
+  double sb = 0.0, ca = 1.0, sa = 0.0;
+  if (sb2 > 1e-280) {  // below: exactly polar (and v_rsq_f64 would meet a denormal)
+    const double n = rsqrt_nr(sb2);
+    sb = sb2 * n;
+    ca = bc[0] * n;
+    sa = bc[1] * n;
+  }
+  double cg, sgm;
+  if (cb >= 0.0) {
+    const double iv = rcp_nr(1.0 + cb);
+    const double cs = (b1[0] + b2[1]) * iv, ss = (b1[1] - b2[0]) * iv;  // alpha + gamma
+    cg = cs * ca + ss * sa;
+    sgm = ss * ca - cs * sa;
+  } else {
+    const double iv = rcp_nr(1.0 - cb);
+    const double cd = -(b1[0] - b2[1]) * iv, sd = -(b1[1] + b2[0]) * iv;  // alpha - gamma
+    cg = ca * cd + sa * sd;
+    sgm = sa * cd - ca * sd;
+  }
+  o[0] = ca; o[1] = sa;
+  o[2] = cb; o[3] = sb;
+  o[4] = cg; o[5] = sgm;
+}
+
 __global__ __launch_bounds__(kSetupBlock) void pair_setup_kernel(const PairParams P, double* __restrict__ rec,
                                                                   int* __restrict__ rec_i)
 {
@@ -103,34 +135,19 @@ __device__ __forceinline__ void pair_setup_one(const PairParams& P, const int w,
   o[FR_WSC] = hw0 * (6.283185307179586476925286766559 / (double)(2 * P.nq));  // hw dpsi
   o[FR_RHO] = rho;
 
-  // Euler angles of M = [b1 b2 bc] = Rz(alpha) Ry(beta) Rz(gamma) (pair_kernel.hpp cap_frame_rotate):
-  // sin(beta) from the x,y components of the pole, NOT sqrt(1 - cos^2): near the poles the latter is quantised at
-  // 1e-8 and rotates by a wrong tilt (4.8e-9 in r at L = 6, caught by tests/test_host_tables.py); gamma from the
-  // WELL CONDITIONED sum (cos beta >= 0) or difference of the two angles
-  const double cb = bc[2];
-  const double sb2 = bc[0] * bc[0] + bc[1] * bc[1];
-  double sb = 0.0, ca = 1.0, sa = 0.0;
-  if (sb2 > 1e-280) {  // below: exactly polar (and v_rsq_f64 would meet a denormal)
-    const double n = rsqrt_nr(sb2);
-    sb = sb2 * n;
-    ca = bc[0] * n;
-    sa = bc[1] * n;
+  euler_zyz(b1, b2, bc, o + FR_EULER);
+  if (P.jpoly) {
+    // compiled orders: particle j is rotated into the common frame like particle i (pair_kernel.hpp jpoly_build);
+    // the Euler angles of M_j = [BJ1 BJ2 BJC] take the slots of BJ1, BJ2, which those kernels never read
+    double j1[3], j2[3], jc[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      j1[a] = o[FR_BJ1 + a];
+      j2[a] = o[FR_BJ2 + a];
+      jc[a] = o[FR_BJC + a];
+    }
+    euler_zyz(j1, j2, jc, o + FR_EULERJ);
   }
-  double cg, sgm;
-  if (cb >= 0.0) {
-    const double iv = rcp_nr(1.0 + cb);
-    const double cs = (b1[0] + b2[1]) * iv, ss = (b1[1] - b2[0]) * iv;  // alpha + gamma
-    cg = cs * ca + ss * sa;
-    sgm = ss * ca - cs * sa;
-  } else {
-    const double iv = rcp_nr(1.0 - cb);
-    const double cd = -(b1[0] - b2[1]) * iv, sd = -(b1[1] + b2[0]) * iv;  // alpha - gamma
-    cg = ca * cd + sa * sd;
-    sgm = sa * cd - ca * sd;
-  }
-  o[FR_EULER] = ca; o[FR_EULER + 1] = sa;
-  o[FR_EULER + 2] = cb; o[FR_EULER + 3] = sb;
-  o[FR_EULER + 4] = cg; o[FR_EULER + 5] = sgm;
 }
 
 inline void launch_pair_setup(const PairParams& P, double* rec, int* rec_i, hipStream_t st)

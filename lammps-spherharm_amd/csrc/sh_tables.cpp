@@ -115,6 +115,67 @@ void build_monomial(int L, int lmax, const double* anm, std::vector<double>& wm)
   }
 }
 
+// Particle j in the pair's common frame (pair_kernel.hpp, jpoly_build): with the rotated, scaled coefficients v0 (the
+// same vector cap_frame_rotate leaves for particle i),
+//   r_j(mu, psi) = sum_m sigma^m [cos(m psi) sum_n v0[n^2+n+m] Q_n^m(mu) + sin(m psi) sum_n v0[n^2+n-m] Q_n^m(mu)],
+// and every point the kernel evaluates r_j at lies on one of the 2 n_q azimuths psi_l of the quadrature.  With
+//   E_nm(mu) = (1 - mu^2)^floor(m/2) Q_n^m(mu)        (a polynomial of degree n - (m & 1), parity n - m)
+// the even orders sum to a polynomial G_l(mu) of degree L and the odd ones to sigma H_l(mu), H_l of degree L - 1.
+// This table is the azimuth-independent first stage as a sparse matrix in ELL form (2L + 4 polynomials of L + 1
+// coefficients; the last two, of the non-existent order L + 1, are zero): row o = (2 m + part) (L + 1) + k
+// (part 0: cos, 1: sin) holds the <= L/2 + 1 products E_nm[k] that make up the coefficient of mu^k of
+//   PJ[2 m + part](mu) = sum_n v0[n^2 + n +- m] E_nm(mu).
+// Built in long double from the exact Pi_n^m and divided by the very double coef_scale(n, m) that is folded into v0.
+void build_jpoly_ell(int L, std::vector<double>& val, std::vector<int>& col)
+{
+  const int W = L / 2 + 1, K = L + 1, NR = (2 * L + 4) * K;   // the two rows of the order L + 1 stay empty
+  val.assign((size_t)NR * W, 0.0);
+  col.assign((size_t)NR * W, 0);
+  std::vector<int> fill(NR, 0);
+  for (int m = 0; m <= L; ++m) {
+    std::vector<long double> p2(K + 2, 0.0L), p1(K + 2, 0.0L), p(K + 2, 0.0L);
+    long double pmm = sqrtl(1.0L / (4.0L * kPi));
+    for (int k = 1; k <= m; ++k) pmm = -pmm * sqrtl((2.0L * k + 1.0L) / (2.0L * k));
+    for (int n = m; n <= L; ++n) {
+      if (n == m) {
+        p.assign(K + 2, 0.0L);
+        p[0] = pmm;
+      } else {
+        const long double a = sqrtl((4.0L * n * n - 1.0L) / ((long double)n * n - (long double)m * m));
+        const long double b = (n - m >= 2) ? sqrtl(((2.0L * n + 1.0L) * (n + m - 1.0L) * (n - m - 1.0L)) /
+                                                   ((long double)(n - m) * (n + m) * (2.0L * n - 3.0L)))
+                                           : 0.0L;
+        for (int k = 0; k < K + 2; ++k) p[k] = ((k > 0) ? a * p1[k - 1] : 0.0L) - b * p2[k];
+      }
+      std::vector<long double> e(p);
+      for (int j = 0; j < m / 2; ++j) {  // times (1 - mu^2)
+        std::vector<long double> t(e.size(), 0.0L);
+        for (size_t k = 0; k < e.size(); ++k) {
+          t[k] += e[k];
+          if (k + 2 < e.size()) t[k + 2] -= e[k];
+        }
+        e = t;
+      }
+      const long double cs = (long double)sh_const::coef_scale(n, m);
+      for (int k = 0; k <= L; ++k) {
+        if (e[k] == 0.0L) continue;  // the other parity: never written
+        for (int part = 0; part < (m ? 2 : 1); ++part) {
+          const int o = (2 * m + part) * K + k;
+          const int t = fill[o]++;
+          if (t >= W) {  // cannot happen (n runs over one parity class above max(m, k)); never truncate silently
+            val.clear();
+            return;
+          }
+          val[(size_t)o * W + t] = (double)(e[k] / cs);
+          col[(size_t)o * W + t] = n * n + n + (part ? -m : m);
+        }
+      }
+      p2 = p1;
+      p1 = p;
+    }
+  }
+}
+
 void to_m_major(int L, int width, const std::vector<double>& src, std::vector<double>& dst)
 {
   dst.assign(src.size(), 0.0);

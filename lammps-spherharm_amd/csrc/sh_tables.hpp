@@ -21,6 +21,8 @@ void build_coefficients(int L, int lmax, const double* anm, const std::vector<do
 // m-major in the same layout and stride as the recurrence table: wm[2 sh_index(L, m+k, m)] is the
 // real part of the coefficient of z^(L-m-k).  Polynomial arithmetic in long double.
 void build_monomial(int L, int lmax, const double* anm, std::vector<double>& wm);
+// First stage of particle j's per-azimuth polynomials in the pair's common frame (sh_tables.cpp), ELL rows of width L/2+1.
+void build_jpoly_ell(int L, std::vector<double>& val, std::vector<int>& col);
 
 // Permutes an n-major table (k = n(n+1)/2+m, `width` doubles per term) into
 // the m-major device layout of sh_device.hpp.

@@ -24,12 +24,12 @@
 
 namespace shp {
 #define SHP_DECL(L) void shp_launch_L##L(const PairParams&, bool, hipStream_t); \
-  hipError_t shp_attr_L##L(bool, bool, hipFuncAttributes*);
+  hipError_t shp_attr_L##L(bool, bool, hipFuncAttributes*, bool);
 SHP_DECL(0) SHP_DECL(1) SHP_DECL(2) SHP_DECL(3) SHP_DECL(4) SHP_DECL(5) SHP_DECL(6)
 SHP_DECL(7) SHP_DECL(8) SHP_DECL(9) SHP_DECL(10) SHP_DECL(11) SHP_DECL(12)
 #undef SHP_DECL
 void shp_launch_Lrt(const PairParams&, bool, hipStream_t);
-hipError_t shp_attr_Lrt(bool, bool, hipFuncAttributes*);
+hipError_t shp_attr_Lrt(bool, bool, hipFuncAttributes*, bool);
 
 constexpr int kMaxUnrolledL = 12;
 static const pair_launch_fn kLaunch[kMaxUnrolledL + 1] = {
@@ -103,6 +103,7 @@ int shpair_create(shpair_ctx** out, int device_id)
   shpair_ctx* c = new (std::nothrow) shpair_ctx();
   if (!c) return SHPAIR_ENOMEM;
   c->device = device_id;
+  if (const char* e = getenv("SHPAIR_JPOLY")) c->opt_jpoly = atoi(e);   // test hook: default of the "jpoly" option
   if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
       hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess ||
       hipEventCreate(&c->evA) != hipSuccess || hipEventCreate(&c->evB) != hipSuccess ||
@@ -126,10 +127,10 @@ void shpair_destroy(shpair_ctx* c)
   shstep_release_state(c);
   c->d_rc.release(); c->d_coef.release(); c->d_coefm.release(); c->d_rmax.release(); c->d_kn.release(); c->d_expo.release();
   c->d_quad.release(); c->d_pair_i.release(); c->d_pair_j.release();
-  c->d_creal.release(); c->d_xval.release(); c->d_gscale.release(); c->d_xcol.release(); c->d_xinfo.release();
+  c->d_creal.release(); c->d_xval.release(); c->d_gscale.release(); c->d_xcol.release(); c->d_xinfo.release(); c->d_jval.release(); c->d_jcol.release();
   c->d_x.release(); c->d_quat.release(); c->d_f.release(); c->d_torque.release(); c->d_ev.release();
   c->d_type.release(); c->d_shtype.release(); c->d_counters.release(); c->d_flags.release();
-  c->d_eatom.release(); c->d_vatom.release(); c->d_list.release(); c->d_err.release(); c->d_rec.release(); c->d_rec_i.release();
+  c->d_eatom.release(); c->d_vatom.release(); c->d_list.release(); c->d_err.release(); c->d_rec.release(); c->d_rec_i.release(); c->d_rot.release();
   if (c->h_list) (void)hipHostFree(c->h_list);
   if (c->h_err) (void)hipHostFree(c->h_err);
   if (c->h_ev) (void)hipHostFree(c->h_ev);
@@ -421,6 +422,10 @@ static int upload_tables(shpair_ctx* c)
   build_xmats_ell(L, xval, xcol, xinfo);
   if (xval.empty()) CTX_FAIL(c, SHPAIR_EINVAL, "internal: X matrix row wider than lmax/2+1");
   build_ring_scale(L, gs);
+  std::vector<double> jval;
+  std::vector<int> jcol;
+  build_jpoly_ell(L, jval, jcol);
+  if (jval.empty()) CTX_FAIL(c, SHPAIR_EINVAL, "internal: per-azimuth polynomial row wider than lmax/2+1");
   // a kernel still in flight on ANY stream (the caller's, not only the context's) may be reading the old tables
   HIPCHK(c, hipDeviceSynchronize());
   HIPCHK(c, c->d_creal.ensure(creal_all.size()));
@@ -428,6 +433,10 @@ static int upload_tables(shpair_ctx* c)
   HIPCHK(c, c->d_xcol.ensure(xcol.size()));
   HIPCHK(c, c->d_xinfo.ensure(xinfo.size()));
   HIPCHK(c, c->d_gscale.ensure(gs.size()));
+  HIPCHK(c, c->d_jval.ensure(jval.size()));
+  HIPCHK(c, c->d_jcol.ensure(jcol.size()));
+  HIPCHK(c, hipMemcpy(c->d_jval.p, jval.data(), jval.size() * sizeof(double), hipMemcpyHostToDevice));
+  HIPCHK(c, hipMemcpy(c->d_jcol.p, jcol.data(), jcol.size() * sizeof(int), hipMemcpyHostToDevice));
   HIPCHK(c, hipMemcpy(c->d_creal.p, creal_all.data(), creal_all.size() * sizeof(double), hipMemcpyHostToDevice));
   HIPCHK(c, hipMemcpy(c->d_xval.p, xval.data(), xval.size() * sizeof(double), hipMemcpyHostToDevice));
   HIPCHK(c, hipMemcpy(c->d_xcol.p, xcol.data(), xcol.size() * sizeof(int), hipMemcpyHostToDevice));
@@ -458,7 +467,10 @@ static int upload_quadrature(shpair_ctx* c)
 {
   const int nq = c->nq, npsi = 2 * nq;
   const int nm = c->lmax >= 2 ? c->lmax - 1 : 0;  // orders m = 2..lmax of the cos/sin(m psi) table, m-major
-  std::vector<double> t, w, q(2 * nq + 2 * npsi + (size_t)nm * 2 * npsi);
+  // ... followed by (cos, sin)(m psi_l), m = 0..lmax + 1, of the first n_q azimuths, l-major: the azimuth stage of particle
+  // j's polynomials (pair_kernel.hpp jpoly_build; psi_(l + n_q) = psi_l + pi only flips the sign of the odd orders)
+  const size_t trigj_off = 2 * nq + 2 * npsi + (size_t)nm * 2 * npsi;
+  std::vector<double> t, w, q(trigj_off + (size_t)nq * (c->lmax + 2) * 2);
   gauss_legendre(nq, t, w);
   for (int k = 0; k < nq; ++k) {
     q[k] = t[k];
@@ -474,6 +486,11 @@ static int upload_quadrature(shpair_ctx* c)
       q[2 * nq + 2 * npsi + 2 * e] = std::cos(m * psi);
       q[2 * nq + 2 * npsi + 2 * e + 1] = std::sin(m * psi);
     }
+    if (l < nq)
+      for (int m = 0; m <= c->lmax + 1; ++m) {   // one order more than exists: jpoly_build reads it against zeros
+        q[trigj_off + ((size_t)l * (c->lmax + 2) + m) * 2] = std::cos(m * psi);
+        q[trigj_off + ((size_t)l * (c->lmax + 2) + m) * 2 + 1] = std::sin(m * psi);
+      }
   }
   HIPCHK(c, hipDeviceSynchronize());  // as in upload_tables
   HIPCHK(c, c->d_quad.ensure(q.size()));
@@ -497,6 +514,8 @@ int shpair_prepare_tables(shpair_ctx* c)
     const int rc = upload_quadrature(c);
     if (rc) return rc;
   }
+  if (c->opt_jpoly == 1 && c->lmax <= kMaxUnrolledL && c->opt_variant != 1 && !c->opt_rule && c->npairs > 0)
+    HIPCHK(c, c->d_rot.ensure((size_t)c->npairs * 2 * (c->lmax + 1) * (c->lmax + 1)));
   return SHPAIR_OK;
 }
 
@@ -579,6 +598,13 @@ int shpair_compute_device(shpair_ctx* c, int nlocal, int nghost, const double* x
   P.trig = c->d_quad.p + 6 * nq;
   P.trig_stride = trig_lmajor(c->lmax) ? 2 * (c->lmax - 1) : 4 * nq;
   P.creal = c->d_creal.p; P.xval = c->d_xval.p; P.xcol = c->d_xcol.p; P.xinfo = c->d_xinfo.p; P.gscale = c->d_gscale.p;
+  P.jval = c->d_jval.p; P.jcol = c->d_jcol.p;
+  P.trigj = c->d_quad.p + 6 * nq + (size_t)(c->lmax >= 2 ? c->lmax - 1 : 0) * 4 * nq;
+  // compiled orders evaluate particle j from per-azimuth polynomials in the pair's common frame (pair_kernel.hpp)
+  const bool jpoly = c->opt_jpoly == 1 && c->lmax <= kMaxUnrolledL && c->opt_variant != 1 && !c->opt_rule;
+  c->last_jpoly = jpoly;
+  P.jpoly = jpoly ? 1 : 0;
+  const int nqj = jpoly ? nq : 0;   // rows of the per-azimuth table in a wave's LDS
   {
     // Resident ring rows: all nq if a wave then needs <= 8 KB of LDS (five 4-wave workgroups per CU,
     // the VGPR-limited 5 waves/SIMD), else as many as fit 8 KB, never fewer than one slab of 64 nodes
@@ -588,8 +614,8 @@ int shpair_compute_device(shpair_ctx* c, int nlocal, int nghost, const double* x
     const int rows_min = 1 + (63 + npsi - 1) / npsi;
     int rows = nq;
     if (c->opt_ring_rows > 0) rows = c->opt_ring_rows;
-    else if (wave_lds_layout(c->lmax, nq).bytes > 8 * 1024) {
-      const int fixed = wave_lds_layout(c->lmax, 0).bytes;
+    else if (wave_lds_layout(c->lmax, nq, false, nqj).bytes > 8 * 1024) {
+      const int fixed = wave_lds_layout(c->lmax, 0, false, nqj).bytes;
       rows = (8 * 1024 - fixed) / (32 * (c->lmax + 1));
     }
     if (rows < rows_min) rows = rows_min;
@@ -603,15 +629,15 @@ int shpair_compute_device(shpair_ctx* c, int nlocal, int nghost, const double* x
       // the queue carries the weights too (+1 KB): all rings resident up to 8.75 KB per wave (18 waves per CU;
       // L = 6, n_q = 16 needs 8.5 KB and runs 6 % faster that way than in two groups), 8 KB groups beyond
       rows = (c->opt_ring_rows > 0) ? c->opt_ring_rows : nq;
-      if (c->opt_ring_rows <= 0 && wave_lds_layout(c->lmax, nq, true).bytes > 8960) {
-        const int fixed = wave_lds_layout(c->lmax, 0, true).bytes;
+      if (c->opt_ring_rows <= 0 && wave_lds_layout(c->lmax, nq, true, nqj).bytes > 8960) {
+        const int fixed = wave_lds_layout(c->lmax, 0, true, nqj).bytes;
         rows = (8 * 1024 - fixed) / (32 * (c->lmax + 1));
       }
       const int rows_min_w = 2 + (127 + npsi - 1) / npsi;
       if (rows < rows_min_w) rows = rows_min_w;
       if (rows > nq) rows = nq;
     }
-    const WaveLdsLayout wl = wave_lds_layout(c->lmax, rows, c->opt_rule != 0);
+    const WaveLdsLayout wl = wave_lds_layout(c->lmax, rows, c->opt_rule != 0, nqj);
     if (wl.bytes > 160 * 1024)
       CTX_FAIL(c, SHPAIR_ELMAX, "lmax %d with nq %d needs %d bytes of LDS per pair, more than a CU has", c->lmax, nq,
                wl.bytes);
@@ -647,6 +673,12 @@ int shpair_compute_device(shpair_ctx* c, int nlocal, int nghost, const double* x
   HIPCHK(c, c->d_rec_i.ensure((size_t)c->npairs * 4));
   P.rec = c->d_rec.p;
   P.rec_i = c->d_rec_i.p;
+  if (jpoly) {   // grows only when the list or the order grew: sized by shpair_prepare_tables() ahead of a stream capture
+    HIPCHK(c, c->d_rot.ensure((size_t)c->npairs * 2 * (c->lmax + 1) * (c->lmax + 1)));
+    P.rot = c->d_rot.p;
+  } else {
+    P.rot = nullptr;
+  }
   if (c->opt_timing) HIPCHK(c, hipEventRecord(c->ev0, st));
   launch_pair_setup(P, c->d_rec.p, c->d_rec_i.p, st);
   if (c->lmax <= kMaxUnrolledL && c->opt_variant != 1) {
@@ -758,7 +790,7 @@ int shpair_get_kernel_info(shpair_ctx* c, shpair_kernel_info* out)
   HIPCHK(c, hipSetDevice(c->device));
   hipFuncAttributes a;
   const bool compiled = c->lmax <= kMaxUnrolledL && c->opt_variant != 1;
-  HIPCHK(c, compiled ? kAttr[c->lmax](c->last_needv, c->opt_rule != 0, &a) : shp_attr_Lrt(c->last_needv, false, &a));
+  HIPCHK(c, compiled ? kAttr[c->lmax](c->last_needv, c->opt_rule != 0, &a, c->last_jpoly) : shp_attr_Lrt(c->last_needv, false, &a, false));
   out->lmax = c->lmax;
   out->compiled_order = compiled ? 1 : 0;
   out->vgprs = a.numRegs;
@@ -805,6 +837,7 @@ int shpair_set_option(shpair_ctx* c, const char* key, int value)
     c->opt_rule = value;
   }
   else if (!strcmp(key, "ring_rows")) c->opt_ring_rows = value;
+  else if (!strcmp(key, "jpoly")) c->opt_jpoly = value;
   else if (!strcmp(key, "waves_per_block")) c->opt_wpb = value;
   else CTX_FAIL(c, SHPAIR_EINVAL, "unknown option '%s'", key);
   return SHPAIR_OK;

@@ -60,7 +60,10 @@ struct shpair_ctx {
 
   shp::DevBuf<double> d_rc, d_coef, d_coefm, d_rmax, d_kn, d_expo, d_quad, d_creal, d_xval, d_gscale;
   shp::DevBuf<int> d_xcol, d_xinfo;
+  shp::DevBuf<double> d_jval;   // first stage of particle j's per-azimuth polynomials (sh_tables.cpp build_jpoly_ell)
+  shp::DevBuf<int> d_jcol;
   shp::DevBuf<int> d_pair_i, d_pair_j;
+  shp::DevBuf<double> d_rot;  // rotated coefficient vectors of both particles of every list slot (pair_rotate_kernel)
   shp::DevBuf<double> d_rec;  // per-pair records of pair_setup.hpp, kRecStride doubles per list slot
   shp::DevBuf<int> d_rec_i;   // 4 ints per list slot
   int npairs = 0;
@@ -89,6 +92,8 @@ struct shpair_ctx {
   unsigned long long* h_counters = nullptr;  // pinned 2
 
   int opt_force_volume = 0, opt_timing = 0, opt_count = 0, opt_variant = 0, opt_ring_rows = 0, opt_wpb = 0, opt_rule = 0;
+  int opt_jpoly = 0;       // 1: compiled orders evaluate particle j from per-azimuth polynomials (pair_kernel.hpp, JPT)
+  bool last_jpoly = false;
   int last_lds_bytes = 0, last_ring_rows = 0;  // of the last launch (shpair_get_kernel_info)
   bool last_needv = false;
   double* pair_out = nullptr;

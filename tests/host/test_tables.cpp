@@ -5,6 +5,9 @@
 //     r = sum_m (A_m cos m psi + B_m sin m psi) — reproduces r_body(M u') for random rotations M,
 //     including the pole-degenerate ones, using exactly the tables the kernel reads.
 //  3. The monomial (Horner) table reproduces the recurrence evaluation.
+//  4. Particle j's per-azimuth polynomials (build_jpoly_ell + the azimuth stage of pair_kernel.hpp jpoly_build):
+//     r = G_l(mu) + sigma H_l(mu) on the quadrature's azimuths reproduces r_body(M u'), and the second half of the
+//     azimuths is the first with the sign of H flipped.
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -78,7 +81,11 @@ int main(int argc, char** argv)
   build_ring_scale(L, g);
   build_recurrence(L, rc_n, scale);
   to_m_major(L, 1, rc_n, rc);
-  double worst = 0.0;
+  double worst = 0.0, jworst = 0.0;
+  std::vector<double> jval;
+  std::vector<int> jcol;
+  build_jpoly_ell(L, jval, jcol);
+  if (jval.empty()) jworst = 1.0;
   for (int trial = 0; trial < 40; ++trial) {
     double q[4] = {urand() - 0.5, urand() - 0.5, urand() - 0.5, urand() - 0.5};
     if (trial == 0) { q[0] = 1; q[1] = q[2] = q[3] = 0; }                 // identity: sin(beta) = 0
@@ -160,8 +167,40 @@ int main(int argc, char** argv)
                             M[6] * up[0] + M[7] * up[1] + M[8] * up[2]};
       worst = fmax(worst, fabs(r - host_radius(L, anm.data(), ub)));
     }
+    // ---- 4. per-azimuth polynomials of the same rotated vector, n_q azimuth pairs
+    if (!jval.empty()) {
+      const int K = L + 1, NR = (2 * L + 4) * K, nqa = 3 + trial % 6, npsi = 2 * nqa;
+      std::vector<double> pj(NR, 0.0);
+      for (int o = 0; o < NR; ++o)
+        for (int t = 0; t < XW; ++t) pj[o] += jval[(size_t)o * XW + t] * ch[jcol[(size_t)o * XW + t]];
+      for (int l = 0; l < npsi; ++l) {
+        const int lrow = l >= nqa ? l - nqa : l;
+        const double psi_row = 2.0 * M_PI * (lrow + 0.5) / npsi, psi = 2.0 * M_PI * (l + 0.5) / npsi;
+        std::vector<double> G(K, 0.0), H(K, 0.0);
+        for (int k = 0; k <= L; ++k)
+          for (int m = 0; m <= L; ++m) {
+            const double v = std::cos(m * psi_row) * pj[(2 * m) * K + k] + std::sin(m * psi_row) * pj[(2 * m + 1) * K + k];
+            ((m & 1) ? H : G)[k] += v;
+          }
+        if (L >= 1 && H[L] != 0.0) jworst = 1.0;  // H has degree L - 1
+        for (int k = 0; k <= L; ++k)               // the rows of the order L + 1 are empty
+          if (pj[(2 * L + 2) * K + k] != 0.0 || pj[(2 * L + 3) * K + k] != 0.0) jworst = 1.0;
+        for (int s = 0; s < 8; ++s) {
+          const double mu = 2 * urand() - 1, sig = std::sqrt(1 - mu * mu);
+          double g = G[L], h = (L >= 1) ? H[L - 1] : 0.0;
+          for (int k = L - 1; k >= 0; --k) g = g * mu + G[k];
+          for (int k = L - 2; k >= 0; --k) h = h * mu + H[k];
+          const double r = g + (l >= nqa ? -sig : sig) * h;
+          const double up[3] = {sig * std::cos(psi), sig * std::sin(psi), mu};
+          const double ub[3] = {M[0] * up[0] + M[1] * up[1] + M[2] * up[2], M[3] * up[0] + M[4] * up[1] + M[5] * up[2],
+                                M[6] * up[0] + M[7] * up[1] + M[8] * up[2]};
+          jworst = fmax(jworst, fabs(r - host_radius(L, anm.data(), ub)));
+        }
+      }
+    }
   }
   printf("cap_frame_error %.3e\n", worst);
+  printf("jpoly_error %.3e\n", jworst);
 
   // ---- 3. monomial table vs recurrence
   std::vector<double> wm;

@@ -28,3 +28,4 @@ def test_host_tables(binary, lmax, tol):
     assert v["x_ell_mismatch"] == 0.0 and v["x_row_excess"] <= 0
     assert v["cap_frame_error"] < tol
     assert v["horner_error"] < tol
+    assert v["jpoly_error"] < tol

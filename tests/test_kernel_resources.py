@@ -22,7 +22,9 @@ def test_no_kernel_spills_vector_registers_or_touches_scratch():
     scr = M.scratch_instruction_counts(lib)
     pair = [k for k in ks if "pair_contact_kernel" in k["symbol"]]
     # one instantiation per compiled order (0..12) and run-time order, x {forces only, volume path} + weighted (0..12)
-    assert len(pair) == 13 * 3 + 2, len(pair)
+    # + the per-azimuth-polynomial variants of the compiled orders x {forces only, volume path}
+    assert len(pair) == 13 * 3 + 2 + 13 * 2, len(pair)
+    assert len([k for k in ks if "pair_rotate_kernel" in k["symbol"]]) == 13
     assert len(ks) >= len(pair) + 20           # the integrator / list / halo kernels
     nominal = []
     for k in ks:
@@ -34,19 +36,23 @@ def test_no_kernel_spills_vector_registers_or_touches_scratch():
     # tolerated for one known instantiation: the forces-only L = 7 kernel (20 bytes; not removable by flags or wave bounds).
     assert all(re.search(r"pair_contact_kernelILi7ELb0ELb0", s) for s, _ in nominal), nominal
     # the headline kernel: 80 VGPRs -> 6 waves per SIMD
-    head = [k for k in pair if "ILi6ELb1ELb0E" in k["symbol"]][0]
+    head = [k for k in pair if "ILi6ELb1ELb0ELb0E" in k["symbol"]][0]
     assert head["vgprs"] <= 80 and head["scratch_bytes"] == 0
 
 
 def test_register_budgets_match_the_wave_targets():
     M = _meta()
     ks = M.kernels(os.path.join(ROOT, "lammps-spherharm_amd", "shpair", "libshpair.so"))
+    checked = 0
     for k in ks:
-        m = re.search(r"pair_contact_kernelILi(n?\\d+)ELb([01])ELb([01])E", k["symbol"])
+        m = re.search(r"pair_contact_kernelILi(n?\d+)ELb([01])ELb([01])ELb([01])E", k["symbol"])
         if not m or m.group(1).startswith("n"):
             continue
-        L, needv, weighted = int(m.group(1)), m.group(2) == "1", m.group(3) == "1"
-        if weighted:
+        checked += 1
+        L, needv, weighted, jpoly = int(m.group(1)), m.group(2) == "1", m.group(3) == "1", m.group(4) == "1"
+        if jpoly:
+            waves = 4 if L <= 6 else (3 if L <= 8 else 2)
+        elif weighted:
             waves = 5 if (L <= 6 and L != 3) else 4
         elif needv:
             waves = 6 if L in (0, 1, 6) else 5
@@ -54,3 +60,4 @@ def test_register_budgets_match_the_wave_targets():
             waves = 6 if L <= 6 else 5
         alloc = (k["vgprs"] + 7) // 8 * 8
         assert 512 // alloc >= waves, (k["symbol"], k["vgprs"], waves)
+    assert checked == 13 * 5, checked

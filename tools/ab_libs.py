@@ -21,6 +21,7 @@ ap.add_argument("--rounds", type=int, default=5)
 ap.add_argument("--rule", type=int, default=0, help="0 sharp, 1 weighted (docs/SPEC.md §2.8)")
 ap.add_argument("--wpb", type=int, nargs="*", default=[0], help="waves per workgroup per lib (0 = default)")
 ap.add_argument("--ring-rows", type=int, nargs="*", default=[0], help="one value per lib (0 = library default)")
+ap.add_argument("--jpoly", type=int, nargs="*", default=[-1], help="one value per lib: the 'jpoly' option (-1 = leave the default)")
 a = ap.parse_args()
 
 ctxs = []
@@ -33,7 +34,10 @@ rmax = None
 b = None
 rr = (a.ring_rows * len(ctxs))[:len(ctxs)] if len(a.ring_rows) == 1 else a.ring_rows
 wp = (a.wpb * len(ctxs))[:len(ctxs)] if len(a.wpb) == 1 else a.wpb
-for sp, rows, w in zip(ctxs, rr, wp):
+jp = (a.jpoly * len(ctxs))[:len(ctxs)] if len(a.jpoly) == 1 else a.jpoly
+for sp, rows, w, j in zip(ctxs, rr, wp, jp):
+    if j >= 0:
+        sp.set_option("jpoly", j)
     sp.set_option("ring_rows", rows)
     sp.set_option("waves_per_block", w)
     sp.settings(a.nq)
@@ -55,7 +59,7 @@ ty = torch.from_numpy(b["type"]).to(dev)
 sh = torch.from_numpy(b["shtype"]).to(dev)
 f = torch.zeros(a.n, 3, dtype=torch.float64, device=dev)
 tq = torch.zeros_like(f)
-a.libs = [f"{lib}#{rows}w{w}" for lib, rows, w in zip(a.libs, rr, wp)]
+a.libs = [f"{lib}#{rows}w{w}j{j}" for lib, rows, w, j in zip(a.libs, rr, wp, jp)]
 res = {lib: [] for lib in a.libs}
 fref = None
 for r in range(a.rounds + 1):
