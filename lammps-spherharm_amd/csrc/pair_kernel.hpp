@@ -70,6 +70,7 @@ struct PairParams {
   const double* trigj;   // (cos, sin)(m psi_l), m = 0..lmax + 1, of the first nq azimuths, l-major
   const double* rot;     // compiled orders: [2 w + which][(lmax+1)^2] rotated, scaled coefficient vectors of slot w's
                          // particles (which 0: i, 1: j), written by pair_rotate_kernel
+  int rot_by_wave;       // 1: pair_rotate_kernel (a wave per rotation) instead of pair_rotate_lane_kernel (diagnostic)
   int jpoly;             // 1: the pair records carry the Euler angles of j's frame in the slots of FR_BJ1 / FR_BJ2
   // per-pair records written by pair_setup_kernel (pair_setup.hpp), read here instead of redoing the scalar set-up on
   // 64 lanes: rec[kRecStride * w] = the pair frame FR_* and the Euler cos/sin; rec_i[4 w] = status, shape i, shape j,
@@ -386,19 +387,23 @@ struct RotLds {
   static __host__ __device__ constexpr int trig() { return 8; }
   static __host__ __device__ int v0(const int L) { return 8 + 6 * (L + 1); }
   static __host__ __device__ int v1(const int L) { return v0(L) + (L + 1) * (L + 1); }
-  static __host__ __device__ int bytes(const int L) { return 8 * (v1(L) + (L + 1) * (L + 1)); }
+  static __host__ __device__ int bytes(const int L) { return (8 * (v1(L) + (L + 1) * (L + 1)) + 15) & ~15; }
 };
+constexpr int kRotWaves = 4;   // rotations per workgroup (one per wave): a quarter of the workgroup launches
 template <int L>
-__global__ void __launch_bounds__(64) pair_rotate_kernel(const PairParams P, double* __restrict__ rot)
+__global__ void __launch_bounds__(64 * kRotWaves) pair_rotate_kernel(const PairParams P, double* __restrict__ rot)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_rot[];
-  double* lw = (double*)smem_rot;
-  const int lane = threadIdx.x;
-  const int w = blockIdx.x >> 1, which = blockIdx.x & 1;
+  const int lane = threadIdx.x & 63;
+  const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int LL = (L >= 0) ? L : P.lmax;
+  double* lw = (double*)(smem_rot + (size_t)wib * RotLds::bytes(LL));
+  const int task = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * kRotWaves)) + wib;   // 2 * slot + particle
+  if (task >= 2 * P.npairs) return;
+  const int w = task >> 1, which = task & 1;
   const int* rid = P.rec_i + 4 * (size_t)w;
   if (rid[0] == 0) return;   // no contact pair in this slot (or a shape index outside the table): nothing will read it
   const int shape = rid[1 + which];
-  const int LL = (L >= 0) ? L : P.lmax;
   if (lane < 6) lw[lane] = P.rec[(size_t)kRecStride * w + (which ? FR_EULERJ : FR_EULER) + lane];
   WaveLdsLayout W;
   W.trig = RotLds::trig();
@@ -407,8 +412,119 @@ __global__ void __launch_bounds__(64) pair_rotate_kernel(const PairParams P, dou
   wave_lds_sync();
   cap_frame_rotate<L>(P, lw, W, LL, shape, lane, RotLds::euler());
   const int ns = (LL + 1) * (LL + 1);
-  double* out = rot + (size_t)blockIdx.x * ns;
+  double* out = rot + (size_t)task * ns;
   for (int e = lane; e < ns; e += 64) out[e] = lw[W.v0 + e];
+}
+
+// The same rotations with ONE LANE PER ROTATION (compiled orders).  The wave-per-rotation form above is a chain of
+// five table-load / LDS steps per rotation, ~10 000 cycles of latency for 85 instructions: 0.6 ms per launch at the
+// headline however many waves are resident.  Here a wave carries 64 rotations through the same five steps; the
+// rotation is block diagonal in l, so a lane's block of 2l + 1 values lives in LDS as [element][lane] (conflict
+// free), the X matrices are wave-uniform (scalar loads, SGPR operands) and every loop is wave-uniform: ~24
+// instructions per rotation, half of them LDS.  The arithmetic and its order are those of cap_frame_rotate.
+template <int L>
+struct RotLaneLds {
+  static constexpr int NB = 2 * L + 1;
+  static constexpr int a() { return 0; }
+  static constexpr int b() { return NB * 64; }
+  static constexpr int t() { return 2 * NB * 64; }                       // cos/sin(m angle): [(2 angle + cs) L + m - 1][lane]
+  static constexpr int bytes() { return 8 * (2 * NB * 64 + 6 * (L > 0 ? L : 1) * 64); }
+};
+template <int L, int LB>
+__device__ __forceinline__ void rotate_lane_block(const PairParams& P, double* __restrict__ sm, const int lane,
+                                                  const double* __restrict__ cre, double* __restrict__ rot,
+                                                  const int task0, const int ntasks)
+{
+  constexpr int ns = (L + 1) * (L + 1), n = 2 * LB + 1, base = LB * LB, XW = L / 2 + 1, XN = LB / 2 + 1;
+  double* A = sm + RotLaneLds<L>::a() + lane;
+  double* B = sm + RotLaneLds<L>::b() + lane;
+  const double* T = sm + RotLaneLds<L>::t() + lane;
+#pragma unroll
+  for (int r = 0; r < n; ++r) A[64 * r] = cre[base + r];
+  // Z(alpha), in place: the pair (l, +m), (l, -m) turns by m alpha
+#pragma unroll
+  for (int m = 1; m <= LB; ++m) {
+    const double c = T[64 * (0 * L + m - 1)], s = T[64 * (1 * L + m - 1)];
+    const double p = A[64 * (LB + m)], q = A[64 * (LB - m)];
+    A[64 * (LB + m)] = fma(c, p, s * q);
+    A[64 * (LB - m)] = fma(c, q, -(s * p));
+  }
+  // X^T: rows ns + e of the ELL table
+#pragma unroll
+  for (int r = 0; r < n; ++r) {
+    const size_t ro = ((size_t)ns + base + r) * XW;
+    double o = 0.0;
+#pragma unroll
+    for (int t = 0; t < XN; ++t) o = fma(P.xval[ro + t], A[64 * (P.xcol[ro + t] - base)], o);
+    B[64 * r] = o;
+  }
+#pragma unroll
+  for (int m = 1; m <= LB; ++m) {
+    const double c = T[64 * (2 * L + m - 1)], s = T[64 * (3 * L + m - 1)];
+    const double p = B[64 * (LB + m)], q = B[64 * (LB - m)];
+    B[64 * (LB + m)] = fma(c, p, s * q);
+    B[64 * (LB - m)] = fma(c, q, -(s * p));
+  }
+  // X
+#pragma unroll
+  for (int r = 0; r < n; ++r) {
+    const size_t ro = ((size_t)base + r) * XW;
+    double o = 0.0;
+#pragma unroll
+    for (int t = 0; t < XN; ++t) o = fma(P.xval[ro + t], B[64 * (P.xcol[ro + t] - base)], o);
+    A[64 * r] = o;
+  }
+  // Z(gamma) and the ring scale
+  A[64 * LB] *= P.gscale[base + LB];
+#pragma unroll
+  for (int m = 1; m <= LB; ++m) {
+    const double c = T[64 * (4 * L + m - 1)], s = T[64 * (5 * L + m - 1)];
+    const double p = A[64 * (LB + m)], q = A[64 * (LB - m)];
+    A[64 * (LB + m)] = fma(c, p, s * q) * P.gscale[base + LB + m];
+    A[64 * (LB - m)] = fma(c, q, -(s * p)) * P.gscale[base + LB - m];
+  }
+  // the block leaves transposed: consecutive lanes write consecutive elements of one rotation
+  wave_lds_sync();
+  const double* At = sm + RotLaneLds<L>::a();
+#pragma unroll
+  for (int it = 0; it < n; ++it) {
+    const int idx = lane + 64 * it;   // < 64 n
+    const int tk = idx / n, r = idx - tk * n;
+    if (task0 + tk < ntasks) rot[(size_t)(task0 + tk) * ns + base + r] = At[64 * r + tk];
+  }
+  wave_lds_sync();
+  if constexpr (LB < L) rotate_lane_block<L, LB + 1>(P, sm, lane, cre, rot, task0, ntasks);
+}
+template <int L>
+__global__ void __launch_bounds__(64) pair_rotate_lane_kernel(const PairParams P, double* __restrict__ rot)
+{
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_rl[];
+  double* sm = (double*)smem_rl;
+  const int lane = threadIdx.x;
+  const int task0 = blockIdx.x * 64, ntasks = 2 * P.npairs;
+  const int task = task0 + lane;
+  const int w = (task < ntasks ? task : ntasks - 1) >> 1, which = task & 1;
+  const int* rid = P.rec_i + 4 * (size_t)w;
+  const bool live = task < ntasks && rid[0] != 0;
+  const int shape = live ? rid[1 + which] : 0;   // dead slots rotate shape 0 by the identity: nobody reads the result
+  const double* eu = P.rec + (size_t)kRecStride * w + (which ? FR_EULERJ : FR_EULER);
+  if constexpr (L >= 1) {
+    double* T = sm + RotLaneLds<L>::t() + lane;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const double c1 = live ? eu[2 * a] : 1.0, s1 = live ? eu[2 * a + 1] : 0.0;
+      double cm = c1, sn = s1;
+#pragma unroll
+      for (int m = 1; m <= L; ++m) {
+        T[64 * ((2 * a) * L + m - 1)] = cm;
+        T[64 * ((2 * a + 1) * L + m - 1)] = sn;
+        const double c = fma(cm, c1, -(sn * s1)), s = fma(cm, s1, sn * c1);
+        cm = c;
+        sn = s;
+      }
+    }
+  }
+  rotate_lane_block<L, 0>(P, sm, lane, P.creal + (size_t)shape * ((L + 1) * (L + 1)), rot, task0, ntasks);
 }
 
 // Ring tables of rings k0 .. k0 + nrows - 1 from the rotated coefficients.
@@ -747,6 +863,16 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
   if (status == 0) return;   // bounding spheres apart (SPEC §2.1) or a shape index outside the table; wave-uniform
   const int si = rid[1], sj = rid[2];
   (void)si; (void)sj;
+  // JPT: the pair's scalars as scalar loads of its record (SGPR operands), not LDS reads at the head of every loop
+  // iteration — the kernel has the scalar registers now that no coefficient windows live in them
+  double s_rho = 0.0, s_rj = 0.0, s_rj2 = 0.0, s_rho2 = 0.0;
+  if constexpr (JPT && L >= 0 && !WEIGHTED) {
+    const cdptr rs = launder_uniform(P.rec + (size_t)kRecStride * w);
+    s_rho = rs[FR_RHO];
+    s_rj = rs[FR_RJ];
+    s_rj2 = rs[FR_RJ2];
+    s_rho2 = rs[FR_RHO2];
+  }
   const bool centre_in_bj = rid[3] != 0;  // rho < Rj
   // compiled orders: both particles' rotated coefficient vectors come from pair_rotate_kernel; everything the
   // prologue reads from memory is requested here, before the first wait
@@ -863,13 +989,17 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
     double* lr = SHP_LDS();
     // the queue is empty between ring groups: four of the seven sums wait there while the ring tables are built
     // (eight registers the build has for its recurrences instead of spilling)
-    double* park = lr + W.qri + lane;
-    park[0] = aT0; park[64] = aT1; park[128] = aT2; park[192] = NEEDV ? aV : aS0;
-    cap_frame_rings<L>(P, lr, W, LL, lane, k0, kend - k0, lr[FR_HW], lr[FR_HM]);
-    park = SHP_LDS() + W.qri + lane;
-    aT0 = park[0]; aT1 = park[64]; aT2 = park[128];
-    if (NEEDV) aV = park[192]; else aS0 = park[192];
-    wave_lds_sync();
+    if constexpr (JP) {   // 128 registers: nothing has to make room
+      cap_frame_rings<L>(P, lr, W, LL, lane, k0, kend - k0, lr[FR_HW], lr[FR_HM]);
+    } else {
+      double* park = lr + W.qri + lane;
+      park[0] = aT0; park[64] = aT1; park[128] = aT2; park[192] = NEEDV ? aV : aS0;
+      cap_frame_rings<L>(P, lr, W, LL, lane, k0, kend - k0, lr[FR_HW], lr[FR_HM]);
+      park = SHP_LDS() + W.qri + lane;
+      aT0 = park[0]; aT1 = park[64]; aT2 = park[128];
+      if (NEEDV) aV = park[192]; else aS0 = park[192];
+      wave_lds_sync();
+    }
 #if defined(SHP_ABL) && SHP_ABL == 2   // timing-only build: stop after rotation + ring tables
     asm volatile("" ::"v"(lr[W.ring + lane]));
     return;
@@ -1022,7 +1152,7 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
         else re = fma(A, tg[m], fma(B, tg[LJ + m], re));
       }
       const double ria = re + ro, rib = re - ro;
-      const double rho = fr[FR_RHO], rj2 = fr[FR_RJ2];
+      const double rho = s_rho, rj2 = s_rj2;
       const double qa0 = fma(ria, mu, -rho), qa1 = ria * sig;
       const double qb0 = fma(rib, mu, -rho), qb1 = -rib * sig;
       const double sa2 = fma(qa0, qa0, qa1 * qa1), sb2 = fma(qb0, qb0, qb1 * qb1);
@@ -1031,7 +1161,7 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
       const bool za = !(sa2 > 0.0), zb = !(sb2 > 0.0);
       const double inva = rsqrt_nr1(fmax(sa2, 1e-300)), invb = rsqrt_nr1(fmax(sb2, 1e-300));
       const double rjae = jp.eval(qa0 * inva, qa1 * inva), rjbe = jp.eval(qb0 * invb, qb1 * invb);
-      const double Rjl = fr[FR_RJ];
+      const double Rjl = s_rj;
       const double rja = za ? Rjl : rjae, rjb = zb ? Rjl : rjbe;
       const bool ina = canda && (za || sa2 * inva < rja), inb = candb && (zb || sb2 * invb < rjb);
       const int pa = k * npsi + l;
@@ -1160,7 +1290,7 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
       {
         double bp, s2i;
         if constexpr (JP) {
-          const double rho = fr[FR_RHO];
+          const double rho = s_rho;
           bp = mu * rho;   // u . d: d = rho c
           const double q0 = fma(ri, uj0, -rho), q1 = ri * uj1;
           s2i = fma(q0, q0, q1 * q1);
@@ -1170,8 +1300,8 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
           const double q0 = fma(ri, uj0, -dj0), q1 = fma(ri, uj1, -dj1), q2 = fma(ri, uj2, -dj2);
           s2i = q0 * q0 + q1 * q1 + q2 * q2;
         }
-        const double rho2l = fr[FR_RHO2];
-        if (!centre_in_bj) lo = bp - sqrt_nr1(fma(bp, bp, -(rho2l - fr[FR_RJ2])));
+        const double rho2l = JP ? s_rho2 : fr[FR_RHO2];
+        if (!centre_in_bj) lo = bp - sqrt_nr1(fma(bp, bp, -(rho2l - (JP ? s_rj2 : fr[FR_RJ2]))));
         lam = bp - sqrt_nr1(fma(bp, bp, -(rho2l - rj0 * rj0)));
         if (!(lam > lo && lam < hi)) lam = 0.5 * (lo + hi);
         ga = gb = sqrt_nr1(s2i) - rj0;
@@ -1186,7 +1316,7 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
 #endif
         double y0, y1, y2 = 0.0, ss2;
         if constexpr (JP) {
-          y0 = fma(lam, uj0, -fr[FR_RHO]);
+          y0 = fma(lam, uj0, -s_rho);
           y1 = lam * uj1;
           ss2 = fma(y0, y0, y1 * y1);
         } else {
@@ -1200,7 +1330,7 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
         double rj;
         if constexpr (JP) rj = jp.eval(y0 * iv, y1 * iv);
         else rj = sh_eval<L>(rc, cwj, lrt, y0 * iv, y1 * iv, y2 * iv);
-        const double Rjl = fr[FR_RJ];
+        const double Rjl = JP ? s_rj : fr[FR_RJ];
         const double gl = z0 ? -Rjl : ss2 * iv - rj;
         // The update has no divergent control flow: every lane goes through it, and a lane that is done (or never was
         // active) carries on with values nobody reads — its r_in is frozen by `act`.  (Nested conditionals cost a
@@ -1255,7 +1385,8 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
       // a node outside j contributes exactly nothing (r^3 - r^3 under FMA contraction is a rounding residue, and
       // V^(m-1) turns a residue of 1e-22 into a visible force)
       const double dv3 = (WEIGHTED && outside) ? 0.0 : ri * ri * ri - rin * rin * rin;
-      if constexpr (WEIGHTED) {
+      if constexpr (WEIGHTED || JP) {
+        // (JPT kernels likewise: the root loop holds a row of particle j's table in 4L + 2 registers.)
         // The weighted kernels have three slabs of residuals in registers on top of the root finder's state: the
         // node (weight, psi, mu, sigma: nine registers) is looked up a second time here, through a copy of p the
         // compiler cannot see through, instead of being carried across the loop — that is what keeps them free of
@@ -1458,8 +1589,12 @@ void launch_pair_contact(const PairParams& P, bool needv, hipStream_t st)
   if constexpr (L >= 0) {
     if (P.jpoly) {
       // both particles' coefficient rotations, one wave each, then the contact kernel that reads them
-      hipLaunchKernelGGL((pair_rotate_kernel<L>), dim3(2 * (unsigned)P.npairs), dim3(64), RotLds::bytes(L), st, P,
-                         const_cast<double*>(P.rot));
+      if (P.rot_by_wave)
+        hipLaunchKernelGGL((pair_rotate_kernel<L>), dim3((2 * (unsigned)P.npairs + kRotWaves - 1) / kRotWaves),
+                           dim3(64 * kRotWaves), (size_t)kRotWaves * RotLds::bytes(L), st, P, const_cast<double*>(P.rot));
+      else
+        hipLaunchKernelGGL((pair_rotate_lane_kernel<L>), dim3((2 * (unsigned)P.npairs + 63) / 64), dim3(64),
+                           RotLaneLds<L>::bytes(), st, P, const_cast<double*>(P.rot));
       if (needv) launch_contact_one(pair_contact_kernel<L, true, false, true>, grid, block, lds, st, P);
       else launch_contact_one(pair_contact_kernel<L, false, false, true>, grid, block, lds, st, P);
       return;

@@ -604,6 +604,7 @@ int shpair_compute_device(shpair_ctx* c, int nlocal, int nghost, const double* x
   const bool jpoly = c->opt_jpoly == 1 && c->lmax <= kMaxUnrolledL && c->opt_variant != 1 && !c->opt_rule;
   c->last_jpoly = jpoly;
   P.jpoly = jpoly ? 1 : 0;
+  P.rot_by_wave = (c->opt_jpoly_rot == 1) ? 1 : 0;
   const int nqj = jpoly ? nq : 0;   // rows of the per-azimuth table in a wave's LDS
   {
     // Resident ring rows: all nq if a wave then needs <= 8 KB of LDS (five 4-wave workgroups per CU,
@@ -611,11 +612,14 @@ int shpair_compute_device(shpair_ctx* c, int nlocal, int nghost, const double* x
     // spans.  Measured at lmax 12, nq 32 (tools/ab_libs.py --ring-rows): 32 or 18 rows 55 ms
     // (2 workgroups per CU), 9 rows 38.7 ms, 4 rows 37.4 ms.
     const int npsi = 2 * nq;
-    const int rows_min = 1 + (63 + npsi - 1) / npsi;
+    // lanes per ring in phase 1: 2 n_q nodes, or n_q node pairs in the per-azimuth-polynomial kernels, whose table of
+    // particle j comes on top of the 8 KB
+    const int per_ring = jpoly ? nq : npsi;
+    const int rows_min = 1 + (63 + per_ring - 1) / per_ring;
     int rows = nq;
     if (c->opt_ring_rows > 0) rows = c->opt_ring_rows;
-    else if (wave_lds_layout(c->lmax, nq, false, nqj).bytes > 8 * 1024) {
-      const int fixed = wave_lds_layout(c->lmax, 0, false, nqj).bytes;
+    else if (wave_lds_layout(c->lmax, nq, false, 0).bytes > 8 * 1024) {
+      const int fixed = wave_lds_layout(c->lmax, 0, false, 0).bytes;
       rows = (8 * 1024 - fixed) / (32 * (c->lmax + 1));
     }
     if (rows < rows_min) rows = rows_min;
@@ -838,6 +842,7 @@ int shpair_set_option(shpair_ctx* c, const char* key, int value)
   }
   else if (!strcmp(key, "ring_rows")) c->opt_ring_rows = value;
   else if (!strcmp(key, "jpoly")) c->opt_jpoly = value;
+  else if (!strcmp(key, "jpoly_rot")) c->opt_jpoly_rot = value;
   else if (!strcmp(key, "waves_per_block")) c->opt_wpb = value;
   else CTX_FAIL(c, SHPAIR_EINVAL, "unknown option '%s'", key);
   return SHPAIR_OK;
