@@ -119,6 +119,11 @@ constexpr int kPairErrType = 2;   // an atom type outside [1, ntypes]
   ((NEEDV) ? (((L) == 0 || (L) == 1 || (L) == 6) ? 6 : 5) : (((L) >= 0 && (L) <= 6) ? 6 : 5))
 #endif
 // kernels that evaluate particle j from per-azimuth polynomials (JPT): a lane's row sits in 4L + 2 registers
+#ifndef SHP_GRAD_LDS
+#define SHP_GRAD_LDS 0   // JPT kernels: weights and cos/sin(m psi) of the gradient from LDS (1) or the global tables (0).
+                         // 1 is correct and saves a table round trip per batch, but the register allocator then spills 130
+                         // registers of the L = 6 kernel under its 128-register bound (round 2); kept for another try
+#endif
 #ifndef SHP_JMIN_WAVES
 #define SHP_JMIN_WAVES(L, NEEDV) (((L) <= 6) ? 4 : (((L) <= 8) ? 3 : 2))
 #endif
@@ -147,7 +152,8 @@ constexpr int kRecUsed = 37;
 // the whole kernel (wave-uniform FP64 values cannot be SGPRs without readfirstlane)
 // With P.jpoly the six slots of FR_BJ1 / FR_BJ2 carry cos, sin of the Euler angles of j's frame M_j = [BJ1 BJ2 BJC]
 // instead (FR_EULERJ): the compiled orders never form a direction in j's body frame.
-enum { FR_EULERJ = 0 };
+enum { FR_EULERJ = 0, FR_JPJ = 6 /* rho^2 - R_j^2 */, FR_JTOL1 = 7 /* 1e-7 R_j */, FR_JTOL3 = 8 /* SHP_TAU3 R_j */,
+       FR_JTINY = 9 /* 1e-14 R_j */ };   // ... and the slots of BJC, d_j these (pair_setup.hpp)
 enum { FR_BJ1 = 0, FR_BJ2 = 3, FR_BJC = 6, FR_DJ = 9, FR_E1 = 12, FR_E2 = 15, FR_C = 18, FR_D = 21,
        FR_RJ = 24, FR_RJ2 = 25, FR_RHO2 = 26, FR_HW = 27, FR_HM = 28, FR_WSC = 29,
        FR_EULER = 30 /* cos, sin of alpha, beta, gamma */, FR_RHO = 36 };
@@ -160,6 +166,7 @@ struct WaveLdsLayout {
   int qw;                                        // weighted rule only: the queued nodes' weights
   int coef;                                      // SHP_COEF_LDS ablation build only
   int pj, gh;                                    // particle j's polynomials: first-stage scratch, per-azimuth table
+  int glw;                                       // JPT kernels: the Gauss-Legendre weights (nqj doubles)
 };
 // Row of the per-azimuth table: G_l (L + 1 coefficients, descending powers), H_l (L), one pad, then cos(m psi_l) and
 // sin(m psi_l), m = 1..L (phase 1 evaluates r_i with them): 4L + 2 doubles, 16-byte rows.
@@ -204,7 +211,8 @@ __host__ __device__ inline WaveLdsLayout wave_lds_layout(const int L, const int 
 #ifdef SHP_COEF_LDS
   w.bytes = 8 * (w.coef + sh_chunk_stride(L));
 #else
-  w.bytes = 8 * (w.gh + nqj * jpoly_row(L));
+  w.glw = w.gh + nqj * jpoly_row(L);
+  w.bytes = 8 * (w.glw + nqj);
 #endif
   // the epilogue's reduction scratch lies behind the frame, over everything that is dead by then
   if (w.bytes < 8 * (kFrame + kRedDoubles)) w.bytes = 8 * (kFrame + kRedDoubles);
@@ -537,7 +545,10 @@ __global__ void __launch_bounds__(64) pair_rotate_lane_kernel(const PairParams P
 // the older value in place: 8 FP64 operations per step and no moves.  L = 6, n_q = 16: 8 steps in one pass, ~130
 // vector instructions per ring group.  (Round 2 up to here: one (k, m) per lane and, for every lane, L steps each
 // split by the divergent test t < m: ~200 instructions per 64 entries, 2 passes = ~400 per pair at the headline.)
-template <int L>
+// PRE (the JPT kernels, which have the registers): the recurrence constants and the coefficients of ALL steps of a
+// pass are requested before the first step instead of inside each step's divergent branch — a pass then waits for
+// one table load, not for one per step (six dependent ~1000-cycle round trips at L = 6).
+template <int L, bool PRE = false>
 __device__ __forceinline__ void cap_frame_rings(const PairParams& P, double* __restrict__ lw, const WaveLdsLayout& W,
                                                 const int LL, const int lane, const int k0, const int nrows,
                                                 const double hw, const double hm)
@@ -570,12 +581,29 @@ __device__ __forceinline__ void cap_frame_rings(const PairParams& P, double* __r
       double qe = modd ? 0.0 : 1.0, qo = modd ? 1.0 : 0.0, de = 0.0, dd = 0.0;
       // m = 0: the B sums read C_n0 again and are not stored (no select in the loop)
       double wa = cp[mc * mc + mc], wb = cm[mc * mc + mc], wad = 0.0, wbd = 0.0;
+      constexpr int NPRE = (PRE && L >= 1) ? L : 1;
+      double pa[NPRE], pca[NPRE], pcb[NPRE];
+      if constexpr (PRE && L >= 1) {
+#pragma unroll
+        for (int n = 1; n <= L; ++n) {
+          if (n <= m0) continue;
+          pa[n - 1] = rcm[n];              // every lane, whatever its m: the addresses are inside the tables (the
+          pca[n - 1] = cp[n * n + n];      // LDS reads at worst inside the wave's frame), the values unused
+          pcb[n - 1] = cm[n * n + n];
+        }
+#pragma unroll
+        for (int n = 1; n <= L; ++n) {
+          if (n <= m0) continue;
+          asm volatile("" : "+v"(pa[n - 1]), "+v"(pca[n - 1]), "+v"(pcb[n - 1]));   // keep the requests up here
+        }
+      }
 #pragma unroll
       for (int n = 1; n <= ((L >= 0) ? L : LL); ++n) {
         if (n <= m0) continue;   // wave-uniform: no lane of this pass has m < n
         if (ok && n > m) {
-          const double a = rcm[n];
-          const double ca = cp[n * n + n], cbm = cm[n * n + n];
+          const double a = (PRE && L >= 1) ? pa[(PRE && L >= 1) ? n - 1 : 0] : rcm[n];
+          const double ca = (PRE && L >= 1) ? pca[(PRE && L >= 1) ? n - 1 : 0] : cp[n * n + n];
+          const double cbm = (PRE && L >= 1) ? pcb[(PRE && L >= 1) ? n - 1 : 0] : cm[n * n + n];
           if (n & 1) {
             dd = fma(a, fma(mu, de, qe), -dd);
             qo = fma(a, mu * qe, -qo);
@@ -804,6 +832,32 @@ __device__ __forceinline__ double jpoly_eval(const double* __restrict__ row, con
   return g;
 }
 
+// mu- and psi-derivative of r_i at a node of ring row `row` for the JPT kernels: cos/sin(m psi) come from the node's
+// row of particle j's table (tg[m], tg[L + m]; the row of azimuth l - n_q serves l >= n_q with sg = -1 on the odd orders)
+template <int L>
+__device__ __forceinline__ void ring_grad_jp(const double* __restrict__ row, const double* __restrict__ tg, const double sg,
+                                             double& rmu, double& rpsi)
+{
+  double mue = row[2], muo = 0.0, pse = 0.0, pso = 0.0;
+#pragma unroll
+  for (int m = 1; m <= L; ++m) {
+    const double A = row[4 * m], B = row[4 * m + 1], Am = row[4 * m + 2], Bm = row[4 * m + 3];
+    const double c = tg[m], s = tg[L + m], dm = (double)m;
+    if (m & 1) {
+      muo = fma(Am, c, fma(Bm, s, muo));
+      pso = fma(dm * B, c, fma(-dm * A, s, pso));
+    } else {
+      mue = fma(Am, c, fma(Bm, s, mue));
+      pse = fma(dm * B, c, fma(-dm * A, s, pse));
+    }
+    // two orders' operands in flight at a time: left alone the scheduler requests all 6 L values first, and the
+    // kernel spills a hundred registers around the root loop
+    if ((m & 1) == 0) __builtin_amdgcn_sched_barrier(0);
+  }
+  rmu = fma(sg, muo, mue);
+  rpsi = fma(sg, pso, pse);
+}
+
 // A lane's row of the per-azimuth table in registers: phase 1 keeps it from slab to slab when the lanes' azimuths do
 // not change (n_q divides 64), the inner-radius search across its iterations.
 template <int L>
@@ -865,13 +919,17 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
   (void)si; (void)sj;
   // JPT: the pair's scalars as scalar loads of its record (SGPR operands), not LDS reads at the head of every loop
   // iteration — the kernel has the scalar registers now that no coefficient windows live in them
-  double s_rho = 0.0, s_rj = 0.0, s_rj2 = 0.0, s_rho2 = 0.0;
+  double s_rho = 0.0, s_rj = 0.0, s_rj2 = 0.0, s_rho2 = 0.0, s_pj = 0.0, s_tol1 = 0.0, s_tol3 = 0.0, s_tiny = 0.0;
   if constexpr (JPT && L >= 0 && !WEIGHTED) {
     const cdptr rs = launder_uniform(P.rec + (size_t)kRecStride * w);
     s_rho = rs[FR_RHO];
     s_rj = rs[FR_RJ];
     s_rj2 = rs[FR_RJ2];
     s_rho2 = rs[FR_RHO2];
+    s_pj = rs[FR_JPJ];
+    s_tol1 = rs[FR_JTOL1];
+    s_tol3 = rs[FR_JTOL3];
+    s_tiny = rs[FR_JTINY];
   }
   const bool centre_in_bj = rid[3] != 0;  // rho < Rj
   // compiled orders: both particles' rotated coefficient vectors come from pair_rotate_kernel; everything the
@@ -889,6 +947,8 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
       vj[t] = rv[ns + (e < ns ? e : 0)];
     }
     pre.fetch(P, lane, nq);
+    if constexpr (SHP_GRAD_LDS)
+      for (int t = lane; t < nq; t += 64) lw[W.glw + t] = P.glw[t];
   }
   if (lane < kRecUsed) lw[lane] = P.rec[(size_t)kRecStride * w + lane];
   if constexpr (JP) {
@@ -990,7 +1050,7 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
     // the queue is empty between ring groups: four of the seven sums wait there while the ring tables are built
     // (eight registers the build has for its recurrences instead of spilling)
     if constexpr (JP) {   // 128 registers: nothing has to make room
-      cap_frame_rings<L>(P, lr, W, LL, lane, k0, kend - k0, lr[FR_HW], lr[FR_HM]);
+      cap_frame_rings<L, (L <= 8)>(P, lr, W, LL, lane, k0, kend - k0, lr[FR_HW], lr[FR_HM]);
     } else {
       double* park = lr + W.qri + lane;
       park[0] = aT0; park[64] = aT1; park[128] = aT2; park[192] = NEEDV ? aV : aS0;
@@ -1255,7 +1315,7 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
     const double ri = fr[W.qri + e];
     int k = (int)(((unsigned)p * magic) >> 24);
     int l = p - k * npsi;
-    double omi = active ? fr[FR_WSC] * P.glw[k] : 0.0;   // the node's plain weight
+    double omi = active ? fr[FR_WSC] * ((JP && SHP_GRAD_LDS) ? fr[W.glw + k] : P.glw[k]) : 0.0;   // the node's plain weight
     bool outside = false;    // WEIGHTED: a node with g~ >= 0 has no ray segment inside j
     if (WEIGHTED) outside = !(fr[W.qw + e] > 0.0);
     double c1 = P.cpsi[l], s1 = P.spsi[l];
@@ -1301,7 +1361,7 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
           s2i = q0 * q0 + q1 * q1 + q2 * q2;
         }
         const double rho2l = JP ? s_rho2 : fr[FR_RHO2];
-        if (!centre_in_bj) lo = bp - sqrt_nr1(fma(bp, bp, -(rho2l - (JP ? s_rj2 : fr[FR_RJ2]))));
+        if (!centre_in_bj) lo = bp - sqrt_nr1(JP ? fma(bp, bp, -s_pj) : fma(bp, bp, -(rho2l - fr[FR_RJ2])));
         lam = bp - sqrt_nr1(fma(bp, bp, -(rho2l - rj0 * rj0)));
         if (!(lam > lo && lam < hi)) lam = 0.5 * (lo + hi);
         ga = gb = sqrt_nr1(s2i) - rj0;
@@ -1355,8 +1415,9 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
             ext = num * rcp_nr1(dab * dal * dbl);
           }
           const bool inb = ext > lo && ext < hi;   // false for NaN and inf
-          const bool accept = fabs(gl) <= (have3 ? SHP_TAU3 : 1e-7) * Rjl;  // accept the extrapolated point
-          const bool tiny = hi - lo <= 1e-14 * Rjl;
+          // accept the extrapolated point
+          const bool accept = JP ? (fabs(gl) <= (have3 ? s_tol3 : s_tol1)) : (fabs(gl) <= (have3 ? SHP_TAU3 : 1e-7) * Rjl);
+          const bool tiny = JP ? (hi - lo <= s_tiny) : (hi - lo <= 1e-14 * Rjl);
           double res = ext, nxt = ext;
           bool stop = accept;
           if (__any(act && (!inb || tiny))) {
@@ -1385,8 +1446,21 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
       // a node outside j contributes exactly nothing (r^3 - r^3 under FMA contraction is a rounding residue, and
       // V^(m-1) turns a residue of 1e-22 into a visible force)
       const double dv3 = (WEIGHTED && outside) ? 0.0 : ri * ri * ri - rin * rin * rin;
-      if constexpr (WEIGHTED || JP) {
-        // (JPT kernels likewise: the root loop holds a row of particle j's table in 4L + 2 registers.)
+      if constexpr (JP) {
+        // The node is looked up a second time here (the root loop holds a row of particle j's table in 4L + 2
+        // registers and has none to carry weight, psi, mu, sigma across), from LDS only.
+        p = (int)launder_u32((unsigned)p);
+        k = (int)(((unsigned)p * magic) >> 24);
+        l = p - k * npsi;
+        omi = active ? fr[FR_WSC] * (SHP_GRAD_LDS ? fr[W.glw + k] : P.glw[k]) : 0.0;
+        if constexpr (!SHP_GRAD_LDS) {
+          c1 = P.cpsi[l];
+          s1 = P.spsi[l];
+        }
+        const double* row = fr + W.ring + (k - k0) * rowlen;
+        mu = row[1];
+        sig = row[3];
+      } else if constexpr (WEIGHTED) {
         // The weighted kernels have three slabs of residuals in registers on top of the root finder's state: the
         // node (weight, psi, mu, sigma: nine registers) is looked up a second time here, through a copy of p the
         // compiler cannot see through, instead of being carried across the loop — that is what keeps them free of
@@ -1410,7 +1484,18 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
     //   u = (sigma c, sigma s, mu), gamma^ = (mu c, mu s, -sigma), psi^ = (-s, c, 0)
     fr = SHP_LDS();
     double r2, rmu, rpsi;
-    ring_eval<L, true>(fr + W.ring + (k - k0) * rowlen, LL, c1, s1, P.trig + (trig_lmajor(L) ? (size_t)P.trig_stride * l : (size_t)(2 * l)), P.trig_stride, r2, rmu, rpsi);
+    if constexpr (JP && SHP_GRAD_LDS) {
+      const double sg = (l >= nq) ? -1.0 : 1.0;
+      const double* tg = fr + W.gh + (l >= nq ? l - nq : l) * jpoly_row(LJ) + jpoly_trig(LJ) - 1;
+      if constexpr (LJ >= 1) {
+        c1 = sg * tg[1];
+        s1 = sg * tg[LJ + 1];
+      }
+      ring_grad_jp<LJ>(fr + W.ring + (k - k0) * rowlen, tg, sg, rmu, rpsi);
+      (void)r2;
+    } else {
+      ring_eval<L, true>(fr + W.ring + (k - k0) * rowlen, LL, c1, s1, P.trig + (trig_lmajor(L) ? (size_t)P.trig_stride * l : (size_t)(2 * l)), P.trig_stride, r2, rmu, rpsi);
+    }
     const double rad = ri * fma(ri, sig, rmu * sig * mu);   // r (r sigma + sigma mu r_mu): multiplies (c, s)
     const double tan_ = ri * rpsi * rcp_nr1(sig);          // (r / sigma) r_psi; sigma > 0 at Gauss-Legendre nodes
     const double A0 = fma(rad, c1, tan_ * s1);

@@ -147,6 +147,12 @@ __device__ __forceinline__ void pair_setup_one(const PairParams& P, const int w,
       jc[a] = o[FR_BJC + a];
     }
     euler_zyz(j1, j2, jc, o + FR_EULERJ);
+    // ... and wave-uniform FP64 products of the inner-radius search take the slots of BJC and d_j: computed in the
+    // contact kernel they are loop invariants the compiler parks in vector registers (no scalar FP64 unit)
+    o[FR_JPJ] = rho2 - Rj * Rj;
+    o[FR_JTOL1] = 1e-7 * Rj;
+    o[FR_JTOL3] = SHP_TAU3 * Rj;
+    o[FR_JTINY] = 1e-14 * Rj;
   }
 }
 
