@@ -120,7 +120,8 @@ constexpr int kPairErrType = 2;   // an atom type outside [1, ntypes]
 #endif
 // kernels that evaluate particle j from per-azimuth polynomials (JPT): a lane's row sits in 4L + 2 registers
 #ifndef SHP_GRAD_LDS
-#define SHP_GRAD_LDS 0   // JPT kernels: weights and cos/sin(m psi) of the gradient from LDS (1) or the global tables (0).
+#define SHP_GRAD_LDS 2   // JPT kernels: weights and cos/sin(m psi) of the gradient from LDS (1), from LDS with the orders above
+                         // 1 by the angle-addition recurrence (2: no table round trip per batch, -1.4 %) or the global tables (0).
                          // 1 is correct and saves a table round trip per batch, but the register allocator then spills 130
                          // registers of the L = 6 kernel under its 128-register bound (round 2); kept for another try
 #endif
@@ -147,7 +148,7 @@ constexpr int kRedStride = 72;    // epilogue reduction: doubles between the 64-
                                   // four apart share banks, not all seven)
 constexpr int kRedDoubles = 7 * kRedStride + 56 + 7 + 6;   // scratch of the epilogue behind the frame
 constexpr int kRecStride = 40;   // doubles per pair record: the first kRecUsed are copied into the frame
-constexpr int kRecUsed = 37;
+constexpr int kRecUsed = 40;
 // per-pair scalars live in the frame too: as VALU results they would sit in VGPR pairs for
 // the whole kernel (wave-uniform FP64 values cannot be SGPRs without readfirstlane)
 // With P.jpoly the six slots of FR_BJ1 / FR_BJ2 carry cos, sin of the Euler angles of j's frame M_j = [BJ1 BJ2 BJC]
@@ -156,7 +157,10 @@ enum { FR_EULERJ = 0, FR_JPJ = 6 /* rho^2 - R_j^2 */, FR_JTOL1 = 7 /* 1e-7 R_j *
        FR_JTINY = 9 /* 1e-14 R_j */ };   // ... and the slots of BJC, d_j these (pair_setup.hpp)
 enum { FR_BJ1 = 0, FR_BJ2 = 3, FR_BJC = 6, FR_DJ = 9, FR_E1 = 12, FR_E2 = 15, FR_C = 18, FR_D = 21,
        FR_RJ = 24, FR_RJ2 = 25, FR_RHO2 = 26, FR_HW = 27, FR_HM = 28, FR_WSC = 29,
-       FR_EULER = 30 /* cos, sin of alpha, beta, gamma */, FR_RHO = 36 };
+       FR_EULER = 30 /* cos, sin of alpha, beta, gamma */, FR_RHO = 36,
+       // P.jpoly: the force law's operands, looked up by the set-up kernel (the epilogue's chain of three dependent
+       // table loads — pair_i/j -> type -> kn — ends every pair while the wave holds all its registers and LDS)
+       FR_KN = 37, FR_EXPO = 38, FR_IJ = 39 /* i, j as two ints */ };
 
 #ifndef SHP_ALIAS_FROM_L
 #define SHP_ALIAS_FROM_L 7
@@ -545,7 +549,7 @@ __global__ void __launch_bounds__(64) pair_rotate_lane_kernel(const PairParams P
 // the older value in place: 8 FP64 operations per step and no moves.  L = 6, n_q = 16: 8 steps in one pass, ~130
 // vector instructions per ring group.  (Round 2 up to here: one (k, m) per lane and, for every lane, L steps each
 // split by the divergent test t < m: ~200 instructions per 64 entries, 2 passes = ~400 per pair at the headline.)
-// PRE (the JPT kernels, which have the registers): the recurrence constants and the coefficients of ALL steps of a
+// PRE (the JPT kernels, which have the registers): the recurrence constants of ALL steps of a
 // pass are requested before the first step instead of inside each step's divergent branch — a pass then waits for
 // one table load, not for one per step (six dependent ~1000-cycle round trips at L = 6).
 template <int L, bool PRE = false>
@@ -582,19 +586,17 @@ __device__ __forceinline__ void cap_frame_rings(const PairParams& P, double* __r
       // m = 0: the B sums read C_n0 again and are not stored (no select in the loop)
       double wa = cp[mc * mc + mc], wb = cm[mc * mc + mc], wad = 0.0, wbd = 0.0;
       constexpr int NPRE = (PRE && L >= 1) ? L : 1;
-      double pa[NPRE], pca[NPRE], pcb[NPRE];
+      double pa[NPRE];
       if constexpr (PRE && L >= 1) {
 #pragma unroll
         for (int n = 1; n <= L; ++n) {
           if (n <= m0) continue;
-          pa[n - 1] = rcm[n];              // every lane, whatever its m: the addresses are inside the tables (the
-          pca[n - 1] = cp[n * n + n];      // LDS reads at worst inside the wave's frame), the values unused
-          pcb[n - 1] = cm[n * n + n];
+          pa[n - 1] = rcm[n];   // every lane, whatever its m: the address is inside the table, the value unused
         }
 #pragma unroll
         for (int n = 1; n <= L; ++n) {
           if (n <= m0) continue;
-          asm volatile("" : "+v"(pa[n - 1]), "+v"(pca[n - 1]), "+v"(pcb[n - 1]));   // keep the requests up here
+          asm volatile("" : "+v"(pa[n - 1]));   // keep the requests up here
         }
       }
 #pragma unroll
@@ -602,8 +604,7 @@ __device__ __forceinline__ void cap_frame_rings(const PairParams& P, double* __r
         if (n <= m0) continue;   // wave-uniform: no lane of this pass has m < n
         if (ok && n > m) {
           const double a = (PRE && L >= 1) ? pa[(PRE && L >= 1) ? n - 1 : 0] : rcm[n];
-          const double ca = (PRE && L >= 1) ? pca[(PRE && L >= 1) ? n - 1 : 0] : cp[n * n + n];
-          const double cbm = (PRE && L >= 1) ? pcb[(PRE && L >= 1) ? n - 1 : 0] : cm[n * n + n];
+          const double ca = cp[n * n + n], cbm = cm[n * n + n];
           if (n & 1) {
             dd = fma(a, fma(mu, de, qe), -dd);
             qo = fma(a, mu * qe, -qo);
@@ -858,6 +859,30 @@ __device__ __forceinline__ void ring_grad_jp(const double* __restrict__ row, con
   rpsi = fma(sg, pso, pse);
 }
 
+// The same from (cos psi, sin psi) alone, the higher orders by the angle-addition recurrence (4 v_fma_f64 per order):
+// no table is read, at 4 (L - 1) more instructions per batch.
+template <int L>
+__device__ __forceinline__ void ring_grad_rec(const double* __restrict__ row, const double c1, const double s1, double& rmu,
+                                              double& rpsi)
+{
+  rmu = row[2];
+  rpsi = 0.0;
+  double cm = c1, sm = s1;
+#pragma unroll
+  for (int m = 1; m <= L; ++m) {
+    const double A = row[4 * m], B = row[4 * m + 1], dm = (double)m;
+    rmu = fma(row[4 * m + 2], cm, rmu);
+    rmu = fma(row[4 * m + 3], sm, rmu);
+    rpsi = fma(dm * B, cm, rpsi);
+    rpsi = fma(-dm * A, sm, rpsi);
+    if (m < L) {
+      const double c = fma(cm, c1, -(sm * s1)), s = fma(cm, s1, sm * c1);
+      cm = c;
+      sm = s;
+    }
+  }
+}
+
 // A lane's row of the per-azimuth table in registers: phase 1 keeps it from slab to slab when the lanes' azimuths do
 // not change (n_q divides 64), the inner-radius search across its iterations.
 template <int L>
@@ -1049,8 +1074,14 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
     double* lr = SHP_LDS();
     // the queue is empty between ring groups: four of the seven sums wait there while the ring tables are built
     // (eight registers the build has for its recurrences instead of spilling)
-    if constexpr (JP) {   // 128 registers: nothing has to make room
+    if constexpr (JP) {   // 128 registers: two sums wait in the empty queue (they would be spilled otherwise)
+      double* park = lr + W.qri + lane;
+      park[0] = aT2; park[64] = NEEDV ? aV : aS0;
       cap_frame_rings<L, (L <= 8)>(P, lr, W, LL, lane, k0, kend - k0, lr[FR_HW], lr[FR_HM]);
+      park = SHP_LDS() + W.qri + lane;
+      aT2 = park[0];
+      if (NEEDV) aV = park[64]; else aS0 = park[64];
+      wave_lds_sync();
     } else {
       double* park = lr + W.qri + lane;
       park[0] = aT0; park[64] = aT1; park[128] = aT2; park[192] = NEEDV ? aV : aS0;
@@ -1312,7 +1343,7 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
     if (active) atomicAdd(&P.dbg[7], 1ULL);
 #endif
     int p = ((const unsigned short*)(fr + W.qp))[e];   // Q = 2 nq^2 <= 2^15
-    const double ri = fr[W.qri + e];
+    double ri = fr[W.qri + e];
     int k = (int)(((unsigned)p * magic) >> 24);
     int l = p - k * npsi;
     double omi = active ? fr[FR_WSC] * ((JP && SHP_GRAD_LDS) ? fr[W.glw + k] : P.glw[k]) : 0.0;   // the node's plain weight
@@ -1445,6 +1476,13 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
       }
       // a node outside j contributes exactly nothing (r^3 - r^3 under FMA contraction is a rounding residue, and
       // V^(m-1) turns a residue of 1e-22 into a visible force)
+      if constexpr (JP) {
+        // the batch's queue slots are untouched until the next phase 1: r_i and the node index are read again from
+        // the slot instead of being carried through the root loop (three registers become one)
+        const int e2 = (int)launder_u32((unsigned)e);
+        ri = fr[W.qri + e2];
+        p = ((const unsigned short*)(fr + W.qp))[e2];
+      }
       const double dv3 = (WEIGHTED && outside) ? 0.0 : ri * ri * ri - rin * rin * rin;
       if constexpr (JP) {
         // The node is looked up a second time here (the root loop holds a row of particle j's table in 4L + 2
@@ -1484,7 +1522,16 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
     //   u = (sigma c, sigma s, mu), gamma^ = (mu c, mu s, -sigma), psi^ = (-s, c, 0)
     fr = SHP_LDS();
     double r2, rmu, rpsi;
-    if constexpr (JP && SHP_GRAD_LDS) {
+    if constexpr (JP && SHP_GRAD_LDS == 2) {
+      const double sg = (l >= nq) ? -1.0 : 1.0;
+      const double* tg = fr + W.gh + (l >= nq ? l - nq : l) * jpoly_row(LJ) + jpoly_trig(LJ) - 1;
+      if constexpr (LJ >= 1) {
+        c1 = sg * tg[1];
+        s1 = sg * tg[LJ + 1];
+      }
+      ring_grad_rec<LJ>(fr + W.ring + (k - k0) * rowlen, c1, s1, rmu, rpsi);
+      (void)r2;
+    } else if constexpr (JP && SHP_GRAD_LDS == 1) {
       const double sg = (l >= nq) ? -1.0 : 1.0;
       const double* tg = fr + W.gh + (l >= nq ? l - nq : l) * jpoly_row(LJ) + jpoly_trig(LJ) - 1;
       if constexpr (LJ >= 1) {
@@ -1572,14 +1619,25 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
   if (!touched) return;
 
   // SPEC §2.7 force law
-  const int i = E.pair_i[w], j = E.pair_j[w];
-  const int ti = E.type[i], tj = E.type[j];
-  if (ti < 1 || ti > E.ntypes || tj < 1 || tj > E.ntypes) {
-    if (lane == 0) atomicOr(E.err, kPairErrType);
-    return;
+  int i, j;
+  double knij, mij;
+  if constexpr (JP) {   // looked up (and the types range-checked) by the set-up kernel
+    const int* ij = (const int*)(fr + FR_IJ);
+    i = ij[0];
+    j = ij[1];
+    knij = fr[FR_KN];
+    mij = fr[FR_EXPO];
+  } else {
+    i = E.pair_i[w];
+    j = E.pair_j[w];
+    const int ti = E.type[i], tj = E.type[j];
+    if (ti < 1 || ti > E.ntypes || tj < 1 || tj > E.ntypes) {
+      if (lane == 0) atomicOr(E.err, kPairErrType);
+      return;
+    }
+    knij = E.kn[ti * (E.ntypes + 1) + tj];
+    mij = E.expo[ti * (E.ntypes + 1) + tj];
   }
-  const double knij = E.kn[ti * (E.ntypes + 1) + tj];
-  const double mij = E.expo[ti * (E.ntypes + 1) + tj];
   const double vm1 = (mij == 1.0) ? 1.0 : pow_quarter(aVt, mij - 1.0);  // V^(m-1)
   const double pn = knij * mij * vm1;
   const double Fm = -pn * val;   // lanes 0-2: F_i; lanes 3-5: tau_i

@@ -382,6 +382,22 @@ int shpair_set_neighbors_device(shpair_ctx* c, int inum, const int* ilist, const
   return SHPAIR_OK;
 }
 
+// Which kernel family evaluates particle j (pair_kernel.hpp): per-azimuth polynomials in the pair's common frame
+// (JPT kernels + rotation kernel) or the body-frame Horner evaluation.  The first trades ~170 instructions and a
+// table build per pair for 60 fewer per radius evaluation, at 4 (L <= 6), 3 or 2 resident waves per SIMD instead of
+// 5-6: it wins when a pair has enough cap nodes.  Option "jpoly": 1 / 0 force, -1 (default) the measured rule
+// (interleaved A/B over L = 2..12 x n_q = 8..32, profiles/r02_w_jpoly_matrix.txt).
+static bool use_jpoly(const shpair_ctx* c)
+{
+  if (c->lmax > kMaxUnrolledL || c->opt_variant == 1 || c->opt_rule) return false;
+  if (c->opt_jpoly >= 0) return c->opt_jpoly == 1;
+  const int L = c->lmax, nq = c->nq;
+  if (L <= 4) return true;
+  if (L <= 6) return nq >= 12;
+  if (L <= 10) return nq >= 16;
+  return nq >= 32;
+}
+
 static int upload_tables(shpair_ctx* c)
 {
   if (c->nshapes <= 0 || c->ntypes <= 0) CTX_FAIL(c, SHPAIR_ESTATE, "shpair_set_ntypes() not called");
@@ -514,7 +530,7 @@ int shpair_prepare_tables(shpair_ctx* c)
     const int rc = upload_quadrature(c);
     if (rc) return rc;
   }
-  if (c->opt_jpoly == 1 && c->lmax <= kMaxUnrolledL && c->opt_variant != 1 && !c->opt_rule && c->npairs > 0)
+  if (use_jpoly(c) && c->npairs > 0)
     HIPCHK(c, c->d_rot.ensure((size_t)c->npairs * 2 * (c->lmax + 1) * (c->lmax + 1)));
   return SHPAIR_OK;
 }
@@ -601,7 +617,7 @@ int shpair_compute_device(shpair_ctx* c, int nlocal, int nghost, const double* x
   P.jval = c->d_jval.p; P.jcol = c->d_jcol.p;
   P.trigj = c->d_quad.p + 6 * nq + (size_t)(c->lmax >= 2 ? c->lmax - 1 : 0) * 4 * nq;
   // compiled orders evaluate particle j from per-azimuth polynomials in the pair's common frame (pair_kernel.hpp)
-  const bool jpoly = c->opt_jpoly == 1 && c->lmax <= kMaxUnrolledL && c->opt_variant != 1 && !c->opt_rule;
+  const bool jpoly = use_jpoly(c);
   c->last_jpoly = jpoly;
   P.jpoly = jpoly ? 1 : 0;
   P.rot_by_wave = (c->opt_jpoly_rot == 1) ? 1 : 0;

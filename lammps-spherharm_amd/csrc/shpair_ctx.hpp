@@ -92,7 +92,8 @@ struct shpair_ctx {
   unsigned long long* h_counters = nullptr;  // pinned 2
 
   int opt_force_volume = 0, opt_timing = 0, opt_count = 0, opt_variant = 0, opt_ring_rows = 0, opt_wpb = 0, opt_rule = 0;
-  int opt_jpoly = 0;       // 1: compiled orders evaluate particle j from per-azimuth polynomials (pair_kernel.hpp, JPT)
+  int opt_jpoly = -1;      // 1 / 0: compiled orders evaluate particle j from per-azimuth polynomials or not; -1: by the
+                           // measured rule (shpair_api.hip use_jpoly)
   int opt_jpoly_rot = 0;   // 1: rotations by pair_rotate_kernel (diagnostic; default pair_rotate_lane_kernel)
   bool last_jpoly = false;
   int last_lds_bytes = 0, last_ring_rows = 0;  // of the last launch (shpair_get_kernel_info)
