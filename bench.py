@@ -44,11 +44,13 @@ def flops_per_pair(lmax, nq):
     return (60 + 6 * lmax + 9 * T) * 2 * nq * nq
 
 
-def pmc_traffic(args):
+def pmc_traffic(args, family=0):
     """(bytes per launch, source) of the HBM-side traffic measured with rocprofv3 PMC passes for this exact workload
     and kernel variant, or (None, reason).  A static table: counters cannot be read from inside the timed run."""
     path = os.path.join("profiles", "pmc_traffic.json")
     key = f"{args.particles}:{args.lmax}:{args.nq}:{args.nshapes}:{args.exponent:g}:{args.rule}"
+    if family == 1:   # the table's plain keys are the body-frame kernels
+        key += ":jpoly"
     try:
         tab = json.load(open(os.path.join(ROOT, path)))
     except (OSError, ValueError):
@@ -69,6 +71,8 @@ def parse():
     ap.add_argument("--nq", type=int, default=16)
     ap.add_argument("--nshapes", type=int, default=1)
     ap.add_argument("--exponent", type=float, default=1.25)
+    ap.add_argument("--jpoly", type=int, default=-1, choices=[-1, 0, 1],
+                    help="kernel family of the compiled orders (shpair_set_option \"jpoly\"): -1 the library's rule")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--transport", default="rccl", choices=["rccl", "local"],
                     help="N > 1: rccl = one process per GPU, ncclSend/ncclRecv over xGMI (the product path); local = "
@@ -102,21 +106,25 @@ def make_ctx(args, shp, device):
         sp.set_shape(s, args.lmax, a)
     sp.coeff("*", "*", 1000.0, args.exponent)
     sp.set_option("rule", 1 if args.rule == "weighted" else 0)
+    sp.set_option("jpoly", args.jpoly)
     return sp
 
 
 def roofline_objects(args, sp, n_contact, kernel_ms, world):
     fpp = flops_per_pair(args.lmax, args.nq)
+    fam = sp.kernel_info()["family"]
+    kernels = ("pair_setup_kernel + pair_rotate_lane_kernel + pair_contact_kernel" if fam == 1
+               else "pair_setup_kernel + pair_contact_kernel")
     achieved_gbs = BYTES_PER_PAIR * n_contact / (kernel_ms * 1e-3) / 1e9
     achieved_tf = fpp * n_contact / (kernel_ms * 1e-3) / 1e12
-    traffic, src = pmc_traffic(args) if world == 1 else (None, "N > 1: not measured")
+    traffic, src = pmc_traffic(args, fam) if world == 1 else (None, "N > 1: not measured")
     peak_meas = None
     if args.peak_ms > 0:
         peak_meas = sp.fp64_peak(0, args.peak_ms)[0]
     roof = {
         "bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved_gbs / HBM_PEAK_GBS,
         "traffic": traffic, "traffic_source": src,
-        "kernel": "pair_contact_kernel", "kernel_ms": kernel_ms, "bytes_per_pair": BYTES_PER_PAIR,
+        "kernel": "pair_contact_kernel", "kernels_timed": kernels, "kernel_ms": kernel_ms, "bytes_per_pair": BYTES_PER_PAIR,
         "pairs_per_launch": int(n_contact), "algorithmic_bytes_per_launch": BYTES_PER_PAIR * int(n_contact),
         "note": "north_star asks for the HBM fraction; the kernel is FP64-VALU bound (see valu_f64)",
     }
@@ -130,7 +138,8 @@ def roofline_objects(args, sp, n_contact, kernel_ms, world):
                 "profiles/r02_a_fp64_peak.json)",
     }
     occ = dict(sp.kernel_info(), note="static footprint of pair_contact_kernel as launched: one wave = one pair = one "
-               "workgroup; waves_per_cu = min(4 x VGPR limit, LDS limit) of a gfx950 CU")
+               "workgroup; waves_per_cu = min(4 x VGPR limit, LDS limit) of a gfx950 CU; family 1 = neighbour radius from "
+               "per-azimuth polynomials in the pair's common frame (DESIGN.md 4.7), 0 = body-frame Horner evaluation")
     return roof, valu, occ
 
 

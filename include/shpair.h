@@ -137,7 +137,10 @@ int shpair_compute_device(shpair_ctx *ctx, int nlocal, int nghost, const double 
  * pairs every call), "variant" (1: force the run-time-order loop kernel), "rule" (0: sharp inside
  * test, the default; 1: the covered-fraction weights of docs/SPEC.md §2.8 — `pair_style sh <nq> rule weighted`;
  * needs lmax <= 12 and nq <= 32), "ring_rows" (> 0:
- * override the number of quadrature rings whose tables are LDS resident at a time; tuning). */
+ * override the number of quadrature rings whose tables are LDS resident at a time; tuning), "jpoly" (which kernel
+ * family evaluates the neighbour's radius for the compiled orders lmax <= 12, sharp rule: 1 = per-azimuth
+ * polynomials in the pair's common frame, 0 = body-frame Horner evaluation, -1 (default) = whichever the library's
+ * measured rule picks for (lmax, nq); same results to rounding, ~1e-14 relative). */
 int shpair_set_option(shpair_ctx *ctx, const char *key, int value);
 
 /* Static footprint of the pair kernel the last compute launched (occupancy evidence): registers per lane, LDS
@@ -150,6 +153,8 @@ typedef struct shpair_kernel_info {
   int waves_per_simd_vgpr;    /* limit from registers */
   int waves_per_cu_lds;       /* limit from LDS */
   int waves_per_cu;           /* min(4 x waves_per_simd_vgpr, waves_per_cu_lds) */
+  int family;                 /* 0: particle j evaluated in its body frame (Horner, scalar-fed coefficients);
+                                 1: from per-azimuth polynomials in the pair's common frame (option "jpoly") */
 } shpair_kernel_info;
 int shpair_get_kernel_info(shpair_ctx *ctx, shpair_kernel_info *out);
 

@@ -432,48 +432,54 @@ __global__ void __launch_bounds__(64 * kRotWaves) pair_rotate_kernel(const PairP
 // five table-load / LDS steps per rotation, ~10 000 cycles of latency for 85 instructions: 0.6 ms per launch at the
 // headline however many waves are resident.  Here a wave carries 64 rotations through the same five steps; the
 // rotation is block diagonal in l, so a lane's block of 2l + 1 values lives in LDS as [element][lane] (conflict
-// free), the X matrices are wave-uniform (scalar loads, SGPR operands) and every loop is wave-uniform: ~24
-// instructions per rotation, half of them LDS.  The arithmetic and its order are those of cap_frame_rotate.
+// free) between the steps that gather (X^T, X) and in registers for those that do not (the Z turns; cos/sin(m angle) of
+// the three angles sit in registers too), the X matrices are wave-uniform (scalar loads, SGPR operands) and every
+// loop is wave-uniform: ~20 instructions per rotation.  The arithmetic and its order are those of cap_frame_rotate.
 template <int L>
 struct RotLaneLds {
   static constexpr int NB = 2 * L + 1;
   static constexpr int a() { return 0; }
   static constexpr int b() { return NB * 64; }
-  static constexpr int t() { return 2 * NB * 64; }                       // cos/sin(m angle): [(2 angle + cs) L + m - 1][lane]
-  static constexpr int bytes() { return 8 * (2 * NB * 64 + 6 * (L > 0 ? L : 1) * 64); }
+  static constexpr int bytes() { return 8 * (2 * NB * 64); }
+};
+// cos / sin(m angle), m = 1..L, of a lane's three Euler angles: registers (every index is a compile-time constant)
+template <int L>
+struct RotTrig {
+  double c[3 * (L > 0 ? L : 1)], s[3 * (L > 0 ? L : 1)];
 };
 template <int L, int LB>
 __device__ __forceinline__ void rotate_lane_block(const PairParams& P, double* __restrict__ sm, const int lane,
                                                   const double* __restrict__ cre, double* __restrict__ rot,
-                                                  const int task0, const int ntasks)
+                                                  const int task0, const int ntasks, const RotTrig<L>& T)
 {
   constexpr int ns = (L + 1) * (L + 1), n = 2 * LB + 1, base = LB * LB, XW = L / 2 + 1, XN = LB / 2 + 1;
   double* A = sm + RotLaneLds<L>::a() + lane;
   double* B = sm + RotLaneLds<L>::b() + lane;
-  const double* T = sm + RotLaneLds<L>::t() + lane;
-#pragma unroll
-  for (int r = 0; r < n; ++r) A[64 * r] = cre[base + r];
-  // Z(alpha), in place: the pair (l, +m), (l, -m) turns by m alpha
+  // Z(alpha) on the way in: the pair (l, +m), (l, -m) turns by m alpha
+  A[64 * LB] = cre[base + LB];
 #pragma unroll
   for (int m = 1; m <= LB; ++m) {
-    const double c = T[64 * (0 * L + m - 1)], s = T[64 * (1 * L + m - 1)];
-    const double p = A[64 * (LB + m)], q = A[64 * (LB - m)];
+    const double c = T.c[0 * L + m - 1], s = T.s[0 * L + m - 1];
+    const double p = cre[base + LB + m], q = cre[base + LB - m];
     A[64 * (LB + m)] = fma(c, p, s * q);
     A[64 * (LB - m)] = fma(c, q, -(s * p));
   }
   // X^T: rows ns + e of the ELL table
+  double xb[n];
 #pragma unroll
   for (int r = 0; r < n; ++r) {
     const size_t ro = ((size_t)ns + base + r) * XW;
     double o = 0.0;
 #pragma unroll
     for (int t = 0; t < XN; ++t) o = fma(P.xval[ro + t], A[64 * (P.xcol[ro + t] - base)], o);
-    B[64 * r] = o;
+    xb[r] = o;
   }
+  // Z(beta), in registers
+  B[64 * LB] = xb[LB];
 #pragma unroll
   for (int m = 1; m <= LB; ++m) {
-    const double c = T[64 * (2 * L + m - 1)], s = T[64 * (3 * L + m - 1)];
-    const double p = B[64 * (LB + m)], q = B[64 * (LB - m)];
+    const double c = T.c[1 * L + m - 1], s = T.s[1 * L + m - 1];
+    const double p = xb[LB + m], q = xb[LB - m];
     B[64 * (LB + m)] = fma(c, p, s * q);
     B[64 * (LB - m)] = fma(c, q, -(s * p));
   }
@@ -484,18 +490,18 @@ __device__ __forceinline__ void rotate_lane_block(const PairParams& P, double* _
     double o = 0.0;
 #pragma unroll
     for (int t = 0; t < XN; ++t) o = fma(P.xval[ro + t], B[64 * (P.xcol[ro + t] - base)], o);
-    A[64 * r] = o;
+    xb[r] = o;
   }
-  // Z(gamma) and the ring scale
-  A[64 * LB] *= P.gscale[base + LB];
+  // Z(gamma) and the ring scale, in registers; then the block leaves transposed through LDS: consecutive lanes
+  // write consecutive elements of one rotation
+  A[64 * LB] = xb[LB] * P.gscale[base + LB];
 #pragma unroll
   for (int m = 1; m <= LB; ++m) {
-    const double c = T[64 * (4 * L + m - 1)], s = T[64 * (5 * L + m - 1)];
-    const double p = A[64 * (LB + m)], q = A[64 * (LB - m)];
+    const double c = T.c[2 * L + m - 1], s = T.s[2 * L + m - 1];
+    const double p = xb[LB + m], q = xb[LB - m];
     A[64 * (LB + m)] = fma(c, p, s * q) * P.gscale[base + LB + m];
     A[64 * (LB - m)] = fma(c, q, -(s * p)) * P.gscale[base + LB - m];
   }
-  // the block leaves transposed: consecutive lanes write consecutive elements of one rotation
   wave_lds_sync();
   const double* At = sm + RotLaneLds<L>::a();
 #pragma unroll
@@ -505,7 +511,7 @@ __device__ __forceinline__ void rotate_lane_block(const PairParams& P, double* _
     if (task0 + tk < ntasks) rot[(size_t)(task0 + tk) * ns + base + r] = At[64 * r + tk];
   }
   wave_lds_sync();
-  if constexpr (LB < L) rotate_lane_block<L, LB + 1>(P, sm, lane, cre, rot, task0, ntasks);
+  if constexpr (LB < L) rotate_lane_block<L, LB + 1>(P, sm, lane, cre, rot, task0, ntasks, T);
 }
 template <int L>
 __global__ void __launch_bounds__(64) pair_rotate_lane_kernel(const PairParams P, double* __restrict__ rot)
@@ -520,23 +526,23 @@ __global__ void __launch_bounds__(64) pair_rotate_lane_kernel(const PairParams P
   const bool live = task < ntasks && rid[0] != 0;
   const int shape = live ? rid[1 + which] : 0;   // dead slots rotate shape 0 by the identity: nobody reads the result
   const double* eu = P.rec + (size_t)kRecStride * w + (which ? FR_EULERJ : FR_EULER);
+  RotTrig<L> T;
   if constexpr (L >= 1) {
-    double* T = sm + RotLaneLds<L>::t() + lane;
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
       const double c1 = live ? eu[2 * a] : 1.0, s1 = live ? eu[2 * a + 1] : 0.0;
       double cm = c1, sn = s1;
 #pragma unroll
       for (int m = 1; m <= L; ++m) {
-        T[64 * ((2 * a) * L + m - 1)] = cm;
-        T[64 * ((2 * a + 1) * L + m - 1)] = sn;
+        T.c[a * L + m - 1] = cm;
+        T.s[a * L + m - 1] = sn;
         const double c = fma(cm, c1, -(sn * s1)), s = fma(cm, s1, sn * c1);
         cm = c;
         sn = s;
       }
     }
   }
-  rotate_lane_block<L, 0>(P, sm, lane, P.creal + (size_t)shape * ((L + 1) * (L + 1)), rot, task0, ntasks);
+  rotate_lane_block<L, 0>(P, sm, lane, P.creal + (size_t)shape * ((L + 1) * (L + 1)), rot, task0, ntasks, T);
 }
 
 // Ring tables of rings k0 .. k0 + nrows - 1 from the rotated coefficients.

@@ -826,6 +826,7 @@ int shpair_get_kernel_info(shpair_ctx* c, shpair_kernel_info* out)
   out->waves_per_cu_lds = by_lds;
   const int cu = (4 * w < by_lds) ? 4 * w : by_lds;
   out->waves_per_cu = cu;
+  out->family = (compiled && c->last_jpoly) ? 1 : 0;
   return SHPAIR_OK;
 }
 

@@ -69,6 +69,31 @@ def test_forces_and_torques_match_oracle(oracle, lmax, nq, nshapes, expo, fv):
     sp.close()
 
 
+@pytest.mark.parametrize("lmax,nq,jpoly", [(L, nq, jp) for L, nq in ((0, 5), (1, 8), (2, 7), (3, 16), (4, 9), (5, 12), (6, 8),
+                                                                     (6, 20), (7, 10), (8, 16), (9, 6), (10, 11),
+                                                                     (11, 8), (12, 16)) for jp in (0, 1)])
+def test_both_kernel_families_match_oracle(oracle, lmax, nq, jpoly):
+    """Every compiled order through BOTH kernel families, forced with the "jpoly" option (left alone the library
+    picks one per (lmax, nq)): the body-frame Horner evaluation of the neighbour's radius, and the per-azimuth
+    polynomials in the pair's common frame (rotation kernel + node pairs; odd and even n_q, n_q that do and do not
+    divide 64, ragged last slabs), with the volume path and two shapes."""
+    case = make_case(200, lmax, 2, seed=100 + lmax, rmax_fn=oracle.shape_rmax)
+    K, E = coeff_tables(1, 1000.0, 1.25)
+    sp = make_ctx(case, nq, K, E)
+    sp.set_option("jpoly", jpoly)
+    sp.set_option("count", 1)
+    b = case["bed"]
+    f, tq, eng, vir = sp.compute(case["n"], b["x"], b["quat"], b["type"], b["shtype"], eflag=True, vflag=True)
+    assert sp.kernel_info()["family"] == jpoly
+    st = sp.stats()
+    o = oracle_compute(oracle, case, nq, K, E, eflag=True, vflag=True)
+    check(f, tq, o)
+    assert abs(eng - o["eng_virial"][0]) < TOL * abs(o["eng_virial"][0])
+    assert np.abs(vir - o["eng_virial"][1:]).max() < TOL * np.abs(o["eng_virial"][1:]).max()
+    assert (st["n_candidates"], st["n_contact"], st["n_touching"]) == tuple(o["counts"])
+    sp.close()
+
+
 def test_mixed_types_and_exponents(oracle):
     case = make_case(300, 6, 3, seed=40, ntypes=3, rmax_fn=oracle.shape_rmax)
     K, E = coeff_tables(3, kn=lambda i, j: 300.0 * (i + j), expo=lambda i, j: 1.0 + 0.25 * abs(i - j))
