@@ -269,8 +269,7 @@ static int upload_staged_list(shpair_ctx* c, int inum, size_t tot, int max_index
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipStreamSynchronize(c->stream));
   }
-  HIPCHK(c, c->d_rec.ensure((tot ? tot : 1) * kRecStride));
-  HIPCHK(c, c->d_rec_i.ensure((tot ? tot : 1) * 4));
+  HIPCHK(c, shp_size_pair_buffers(c, tot));
   c->npairs = (int)tot;
   c->max_atom_index = max_index;
   c->have_neighbors = true;
@@ -372,8 +371,7 @@ int shpair_set_neighbors_device(shpair_ctx* c, int inum, const int* ilist, const
                        offsets, jlist, inum, c->d_pair_i.p, c->d_pair_j.p);
     HIPCHK(c, hipGetLastError());
   }
-  HIPCHK(c, c->d_rec.ensure((size_t)(npairs ? npairs : 1) * kRecStride));
-  HIPCHK(c, c->d_rec_i.ensure((size_t)(npairs ? npairs : 1) * 4));
+  HIPCHK(c, shp_size_pair_buffers(c, (size_t)npairs));
   c->npairs = npairs;
   c->max_atom_index = max_atom_index;
   c->have_neighbors = true;
@@ -397,6 +395,31 @@ static bool use_jpoly(const shpair_ctx* c)
   if (L <= 10) return nq >= 16;
   return nq >= 32;
 }
+
+}  // extern "C"
+
+// Sizes the per-slot buffers the pair kernels write (records; rotated coefficient vectors of the JPT family) for a
+// list of `np` slots: called wherever a list is installed, so that a compute — possibly inside a stream capture —
+// allocates nothing.
+hipError_t shp_size_pair_buffers(shpair_ctx* c, size_t np)
+{
+  if (np == 0) np = 1;
+  hipError_t e = c->d_rec.ensure(np * kRecStride);
+  if (e == hipSuccess) e = c->d_rec_i.ensure(np * 4);
+  int L = c->lmax;
+  for (int s = 0; s < c->nshapes; ++s)
+    if (c->shapes[s].lmax > L) L = c->shapes[s].lmax;
+  if (e == hipSuccess && L >= 0 && c->nq > 0) {
+    const int keep = c->lmax;
+    c->lmax = L;
+    const bool jp = use_jpoly(c);
+    c->lmax = keep;
+    if (jp) e = c->d_rot.ensure(np * 2 * (size_t)(L + 1) * (L + 1));
+  }
+  return e;
+}
+
+extern "C" {
 
 static int upload_tables(shpair_ctx* c)
 {
@@ -530,8 +553,7 @@ int shpair_prepare_tables(shpair_ctx* c)
     const int rc = upload_quadrature(c);
     if (rc) return rc;
   }
-  if (use_jpoly(c) && c->npairs > 0)
-    HIPCHK(c, c->d_rot.ensure((size_t)c->npairs * 2 * (c->lmax + 1) * (c->lmax + 1)));
+  HIPCHK(c, shp_size_pair_buffers(c, (size_t)c->npairs));
   return SHPAIR_OK;
 }
 

@@ -132,3 +132,5 @@ int shstep_enqueue_check(shpair_ctx* c, int nlocal, const double* x, int** flag_
       CTX_FAIL(ctx, SHPAIR_EHIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(_e), __FILE__, __LINE__); \
   } while (0)
 
+// shpair_api.hip: sizes the per-slot buffers of the pair kernels for a list of np slots (used by every list install)
+hipError_t shp_size_pair_buffers(shpair_ctx* c, size_t np);

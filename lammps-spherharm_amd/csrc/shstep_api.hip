@@ -446,8 +446,7 @@ int shstep_neighbor_build_device(shpair_ctx* c, int nlocal, int nghost, const do
   if (np < 0) CTX_FAIL(c, SHPAIR_EINVAL, "half list too long (pair count overflowed)");
   HIPCHK(c, c->d_pair_i.ensure(np ? (size_t)np : 1));
   HIPCHK(c, c->d_pair_j.ensure(np ? (size_t)np : 1));
-  HIPCHK(c, c->d_rec.ensure((size_t)(np ? np : 1) * 40));   // per-pair records of the contact kernel (pair_setup.hpp)
-  HIPCHK(c, c->d_rec_i.ensure((size_t)(np ? np : 1) * 4));
+  HIPCHK(c, shp_size_pair_buffers(c, (size_t)np));   // per-slot buffers of the pair kernels (shpair_api.hip)
   if (np > 0)
     hipLaunchKernelGGL(half_list_kernel<true>, dim3(nblk(nlocal, kStepBlock)), dim3(kStepBlock), 0, st, nlocal, nall, b, s->skin,
                        x, shtype, tag, (const int*)s->d_gowner.p, (const double*)s->d_mass.p, c->nshapes,

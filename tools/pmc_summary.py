@@ -1,4 +1,4 @@
-"""Summarises rocprofv3 --pmc counter_collection CSVs for the pair kernels (contact kernel and per-pair set-up kernel).
+"""Summarises rocprofv3 --pmc counter_collection CSVs for the pair kernels (contact kernel, per-pair set-up kernel, rotation kernel).
 usage: python tools/pmc_summary.py <dir> [<dir> ...]"""
 import collections
 import csv
@@ -10,7 +10,7 @@ for d in sys.argv[1:]:
         acc = collections.defaultdict(lambda: collections.defaultdict(list))
         meta = {}
         for r in csv.DictReader(open(f)):
-            for key in ("pair_contact", "pair_setup"):
+            for key in ("pair_contact", "pair_setup", "pair_rotate"):
                 if key in r["Kernel_Name"]:
                     acc[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
                     meta[key] = (r["Kernel_Name"], r["VGPR_Count"], r["Accum_VGPR_Count"], r["SGPR_Count"], r["LDS_Block_Size"],
