@@ -158,8 +158,7 @@ enum { FR_EULERJ = 0, FR_JPJ = 6 /* rho^2 - R_j^2 */, FR_JTOL1 = 7 /* 1e-7 R_j *
 enum { FR_BJ1 = 0, FR_BJ2 = 3, FR_BJC = 6, FR_DJ = 9, FR_E1 = 12, FR_E2 = 15, FR_C = 18, FR_D = 21,
        FR_RJ = 24, FR_RJ2 = 25, FR_RHO2 = 26, FR_HW = 27, FR_HM = 28, FR_WSC = 29,
        FR_EULER = 30 /* cos, sin of alpha, beta, gamma */, FR_RHO = 36,
-       // P.jpoly: the force law's operands, looked up by the set-up kernel (the epilogue's chain of three dependent
-       // table loads — pair_i/j -> type -> kn — ends every pair while the wave holds all its registers and LDS)
+       // the force law's operands, looked up by the set-up kernel (pair_setup.hpp)
        FR_KN = 37, FR_EXPO = 38, FR_IJ = 39 /* i, j as two ints */ };
 
 #ifndef SHP_ALIAS_FROM_L
@@ -1625,25 +1624,10 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
   if (!touched) return;
 
   // SPEC §2.7 force law
-  int i, j;
-  double knij, mij;
-  if constexpr (JP) {   // looked up (and the types range-checked) by the set-up kernel
-    const int* ij = (const int*)(fr + FR_IJ);
-    i = ij[0];
-    j = ij[1];
-    knij = fr[FR_KN];
-    mij = fr[FR_EXPO];
-  } else {
-    i = E.pair_i[w];
-    j = E.pair_j[w];
-    const int ti = E.type[i], tj = E.type[j];
-    if (ti < 1 || ti > E.ntypes || tj < 1 || tj > E.ntypes) {
-      if (lane == 0) atomicOr(E.err, kPairErrType);
-      return;
-    }
-    knij = E.kn[ti * (E.ntypes + 1) + tj];
-    mij = E.expo[ti * (E.ntypes + 1) + tj];
-  }
+  // operands looked up (and the types range-checked) by the set-up kernel
+  const int* ij = (const int*)(fr + FR_IJ);
+  const int i = ij[0], j = ij[1];
+  const double knij = fr[FR_KN], mij = fr[FR_EXPO];
   const double vm1 = (mij == 1.0) ? 1.0 : pow_quarter(aVt, mij - 1.0);  // V^(m-1)
   const double pn = knij * mij * vm1;
   const double Fm = -pn * val;   // lanes 0-2: F_i; lanes 3-5: tau_i

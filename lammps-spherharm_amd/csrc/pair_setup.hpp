@@ -89,6 +89,23 @@ __device__ __forceinline__ void pair_setup_one(const PairParams& P, const int w,
     ri[3] = 0;
     return;
   }
+  // the force law's operands, for the contact kernel's epilogue (read from its frame: looked up there they are a chain
+  // of three dependent table loads — pair_i/j -> type -> kn — at the end of every pair, while the wave still holds
+  // all its registers and LDS)
+  const int ti = P.type[i], tj = P.type[j];
+  if (ti < 1 || ti > P.ntypes || tj < 1 || tj > P.ntypes) {
+    atomicOr(P.err, kPairErrType);
+    ri[0] = 0;
+    ri[3] = 0;
+    return;
+  }
+  o[FR_KN] = P.kn[ti * (P.ntypes + 1) + tj];
+  o[FR_EXPO] = P.expo[ti * (P.ntypes + 1) + tj];
+  {
+    int* ij = (int*)(o + FR_IJ);
+    ij[0] = i;
+    ij[1] = j;
+  }
   ri[0] = 1;
   ri[3] = rho < Rj ? 1 : 0;
 
@@ -149,18 +166,6 @@ __device__ __forceinline__ void pair_setup_one(const PairParams& P, const int w,
     euler_zyz(j1, j2, jc, o + FR_EULERJ);
     // ... and wave-uniform FP64 products of the inner-radius search take the slots of BJC and d_j: computed in the
     // contact kernel they are loop invariants the compiler parks in vector registers (no scalar FP64 unit)
-    // ... and the force law's operands (the contact kernel's epilogue reads them from its frame)
-    const int ti = P.type[i], tj = P.type[j];
-    if (ti < 1 || ti > P.ntypes || tj < 1 || tj > P.ntypes) {
-      atomicOr(P.err, kPairErrType);
-      ri[0] = 0;
-      return;
-    }
-    o[FR_KN] = P.kn[ti * (P.ntypes + 1) + tj];
-    o[FR_EXPO] = P.expo[ti * (P.ntypes + 1) + tj];
-    int* ij = (int*)(o + FR_IJ);
-    ij[0] = i;
-    ij[1] = j;
     o[FR_JPJ] = rho2 - Rj * Rj;
     o[FR_JTOL1] = 1e-7 * Rj;
     o[FR_JTOL3] = SHP_TAU3 * Rj;
