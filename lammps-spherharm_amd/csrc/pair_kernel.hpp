@@ -560,8 +560,10 @@ __global__ void __launch_bounds__(64) pair_rotate_lane_kernel(const PairParams P
 template <int L, bool PRE = false>
 __device__ __forceinline__ void cap_frame_rings(const PairParams& P, double* __restrict__ lw, const WaveLdsLayout& W,
                                                 const int LL, const int lane, const int k0, const int nrows,
-                                                const double hw, const double hm)
+                                                const double hw, const double hm, const bool have_first = false)
 {
+  // have_first (PRE kernels): the Gauss-Legendre node of this lane's ring in the first pass of the first ring group
+  // was requested at the start of the kernel and waits in the (empty) queue at lw[W.qri + 128 + lane]
   const double* ch = lw + W.v0;
   double* ring = lw + W.ring;
   const int lg = (nrows <= 8) ? 3 : (nrows <= 16) ? 2 : (nrows <= 32) ? 1 : 0;   // log2 G, wave-uniform
@@ -570,7 +572,8 @@ __device__ __forceinline__ void cap_frame_rings(const PairParams& P, double* __r
   for (int kr0 = 0; kr0 < nrows; kr0 += (64 >> lg)) {
     const int kr = kr0 + (lane >> lg);
     const bool row_ok = kr < nrows;
-    const double mu = fma(hw, P.glt[k0 + (row_ok ? kr : 0)], hm);
+    const double tk = (PRE && have_first && k0 == 0 && kr0 == 0) ? lw[W.qri + 128 + lane] : P.glt[k0 + (row_ok ? kr : 0)];
+    const double mu = fma(hw, tk, hm);
     const double sig2 = fmax(0.0, fma(-mu, mu, 1.0));
     const double sig = sqrt_nr(sig2);
     double sp = 1.0, sigG = sig;   // sigma^g and sigma^G
@@ -943,6 +946,31 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
 
   // the pair's record (pair_setup.hpp): scalar loads of the four ints, one coalesced vector load of the frame
   const int* rid = P.rec_i + 4 * (size_t)w;
+  // Everything the prologue reads from memory is requested before the slot's status is looked at (a scalar load of
+  // its own: waiting for it first would put two memory round trips in a row at the start of every pair).  The
+  // addresses do not depend on the status; a dead slot's rows are in bounds and never used.
+  constexpr int NSL = (JPT && L >= 0 && !WEIGHTED) ? ((L + 1) * (L + 1) + 63) / 64 : 1;
+  double vi[NSL], vj[NSL];
+  JPolyPre<(JPT && L >= 0 && !WEIGHTED) ? L : 0> pre;
+  const double recv = P.rec[(size_t)kRecStride * w + (lane < kRecUsed ? lane : 0)];
+  if constexpr (JPT && L >= 0 && !WEIGHTED) {
+    constexpr int ns = (L + 1) * (L + 1);
+    const double* rv = P.rot + (size_t)(2 * w) * ns;
+#pragma unroll
+    for (int t = 0; t < NSL; ++t) {
+      const int e = lane + 64 * t;
+      vi[t] = rv[e < ns ? e : 0];
+      vj[t] = rv[ns + (e < ns ? e : 0)];
+    }
+    pre.fetch(P, lane, P.nq);
+  }
+  double glt_first = 0.0;
+  if constexpr (JPT && L >= 0 && L <= 8 && !WEIGHTED) {
+    const int nr0 = P.ring_rows < P.nq ? P.ring_rows : P.nq;   // rings of the first group (cap_frame_rings' lane map)
+    const int lg0 = (nr0 <= 8) ? 3 : (nr0 <= 16) ? 2 : (nr0 <= 32) ? 1 : 0;
+    const int kr = lane >> lg0;
+    glt_first = P.glt[kr < nr0 ? kr : 0];
+  }
   const int status = rid[0];
   if (status == 0) return;   // bounding spheres apart (SPEC §2.1) or a shape index outside the table; wave-uniform
   const int si = rid[1], sj = rid[2];
@@ -962,25 +990,10 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
     s_tiny = rs[FR_JTINY];
   }
   const bool centre_in_bj = rid[3] != 0;  // rho < Rj
-  // compiled orders: both particles' rotated coefficient vectors come from pair_rotate_kernel; everything the
-  // prologue reads from memory is requested here, before the first wait
-  constexpr int NSL = JP ? ((LJ + 1) * (LJ + 1) + 63) / 64 : 1;
-  double vi[NSL], vj[NSL];
-  JPolyPre<LJ> pre;
-  if constexpr (JP) {
-    constexpr int ns = (LJ + 1) * (LJ + 1);
-    const double* rv = P.rot + (size_t)(2 * w) * ns;
-#pragma unroll
-    for (int t = 0; t < NSL; ++t) {
-      const int e = lane + 64 * t;
-      vi[t] = rv[e < ns ? e : 0];
-      vj[t] = rv[ns + (e < ns ? e : 0)];
-    }
-    pre.fetch(P, lane, nq);
-    if constexpr (SHP_GRAD_LDS)
-      for (int t = lane; t < nq; t += 64) lw[W.glw + t] = P.glw[t];
-  }
-  if (lane < kRecUsed) lw[lane] = P.rec[(size_t)kRecStride * w + lane];
+  if constexpr (JP && SHP_GRAD_LDS)
+    for (int t = lane; t < nq; t += 64) lw[W.glw + t] = P.glw[t];
+  if (lane < kRecUsed) lw[lane] = recv;
+  if constexpr (JP && L <= 8) lw[W.qri + 128 + lane] = glt_first;
   if constexpr (JP) {
 #pragma unroll
     for (int t = 0; t < NSL; ++t)
@@ -1082,7 +1095,7 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
     if constexpr (JP) {   // 128 registers: two sums wait in the empty queue (they would be spilled otherwise)
       double* park = lr + W.qri + lane;
       park[0] = aT2; park[64] = NEEDV ? aV : aS0;
-      cap_frame_rings<L, (L <= 8)>(P, lr, W, LL, lane, k0, kend - k0, lr[FR_HW], lr[FR_HM]);
+      cap_frame_rings<L, (L <= 8)>(P, lr, W, LL, lane, k0, kend - k0, lr[FR_HW], lr[FR_HM], true);
       park = SHP_LDS() + W.qri + lane;
       aT2 = park[0];
       if (NEEDV) aV = park[64]; else aS0 = park[64];
