@@ -126,7 +126,7 @@ constexpr int kPairErrType = 2;   // an atom type outside [1, ntypes]
                          // registers of the L = 6 kernel under its 128-register bound (round 2); kept for another try
 #endif
 #ifndef SHP_JMIN_WAVES
-#define SHP_JMIN_WAVES(L, NEEDV) (((L) <= 6) ? 4 : (((L) <= 8) ? 3 : 2))
+#define SHP_JMIN_WAVES(L, NEEDV) (((L) <= 2) ? 5 : ((L) <= 6) ? 4 : (((L) <= 8) ? 3 : 2))
 #endif
 
 // docs/SPEC.md §2.6: residual below which the inverse-quadratic extrapolation is accepted
@@ -438,8 +438,8 @@ template <int L>
 struct RotLaneLds {
   static constexpr int NB = 2 * L + 1;
   static constexpr int a() { return 0; }
-  static constexpr int b() { return NB * 64; }
-  static constexpr int bytes() { return 8 * (2 * NB * 64); }
+  static constexpr int b() { return 0; }   // the second gather reads the block in place: a lane only ever touches its own column
+  static constexpr int bytes() { return 8 * (NB * 64); }
 };
 // cos / sin(m angle), m = 1..L, of a lane's three Euler angles: registers (every index is a compile-time constant)
 template <int L>
