@@ -691,10 +691,10 @@ int shpair_compute_device(shpair_ctx* c, int nlocal, int nghost, const double* x
       wpb = c->opt_wpb < kMaxWavesPerBlock ? c->opt_wpb : kMaxWavesPerBlock;
       if (wpb * wl.bytes > 160 * 1024) wpb = (160 * 1024) / wl.bytes;
     }
-    P.wave_lds_bytes = wl.bytes;
+    P.wave_lds_bytes = wl.bytes + ((c->opt_lds_pad > 0) ? (c->opt_lds_pad & ~15) : 0);   // lds_pad: occupancy experiments
     P.waves_per_block = wpb;
     P.ring_rows = rows;
-    c->last_lds_bytes = wl.bytes;
+    c->last_lds_bytes = P.wave_lds_bytes;
     c->last_ring_rows = rows;
   }
   P.ev = ev; P.pair_out = c->pair_out;
@@ -882,6 +882,7 @@ int shpair_set_option(shpair_ctx* c, const char* key, int value)
   else if (!strcmp(key, "ring_rows")) c->opt_ring_rows = value;
   else if (!strcmp(key, "jpoly")) c->opt_jpoly = value;
   else if (!strcmp(key, "jpoly_rot")) c->opt_jpoly_rot = value;
+  else if (!strcmp(key, "lds_pad")) c->opt_lds_pad = value;
   else if (!strcmp(key, "waves_per_block")) c->opt_wpb = value;
   else CTX_FAIL(c, SHPAIR_EINVAL, "unknown option '%s'", key);
   return SHPAIR_OK;

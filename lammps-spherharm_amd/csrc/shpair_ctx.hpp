@@ -95,6 +95,7 @@ struct shpair_ctx {
   int opt_jpoly = -1;      // 1 / 0: compiled orders evaluate particle j from per-azimuth polynomials or not; -1: by the
                            // measured rule (shpair_api.hip use_jpoly)
   int opt_jpoly_rot = 0;   // 1: rotations by pair_rotate_kernel (diagnostic; default pair_rotate_lane_kernel)
+  int opt_lds_pad = 0;     // diagnostic: unused LDS bytes added to every wave's allocation (fewer resident waves)
   bool last_jpoly = false;
   int last_lds_bytes = 0, last_ring_rows = 0;  // of the last launch (shpair_get_kernel_info)
   bool last_needv = false;
