@@ -119,6 +119,10 @@ constexpr int kPairErrType = 2;   // an atom type outside [1, ntypes]
   ((NEEDV) ? (((L) == 0 || (L) == 1 || (L) == 6) ? 6 : 5) : (((L) >= 0 && (L) <= 6) ? 6 : 5))
 #endif
 // kernels that evaluate particle j from per-azimuth polynomials (JPT): a lane's row sits in 4L + 2 registers
+#ifndef SHP_ROOT_LDS
+#define SHP_ROOT_LDS 1   // 1: phase 1 (once per node pair) and the root loop (once per iteration) read their row of particle j's
+                         // table from LDS; 0: rows held in 4L + 2 registers (one wave per SIMD less)
+#endif
 #ifndef SHP_GRAD_LDS
 #define SHP_GRAD_LDS 2   // JPT kernels: weights and cos/sin(m psi) of the gradient from LDS (1), from LDS with the orders above
                          // 1 by the angle-addition recurrence (2: no table round trip per batch, -1.4 %) or the global tables (0).
@@ -126,7 +130,7 @@ constexpr int kPairErrType = 2;   // an atom type outside [1, ntypes]
                          // registers of the L = 6 kernel under its 128-register bound (round 2); kept for another try
 #endif
 #ifndef SHP_JMIN_WAVES
-#define SHP_JMIN_WAVES(L, NEEDV) (((L) <= 2) ? 5 : ((L) <= 6) ? 4 : (((L) <= 8) ? 3 : 2))
+#define SHP_JMIN_WAVES(L, NEEDV) (((L) <= 6) ? 5 : 4)
 #endif
 
 // docs/SPEC.md §2.6: residual below which the inverse-quadratic extrapolation is accepted
@@ -170,11 +174,16 @@ struct WaveLdsLayout {
   int coef;                                      // SHP_COEF_LDS ablation build only
   int pj, gh;                                    // particle j's polynomials: first-stage scratch, per-azimuth table
   int glw;                                       // JPT kernels: the Gauss-Legendre weights (nqj doubles)
+  int park;                                      // JPT kernels: 2 x 64 parked sums + 64 prefetched Gauss nodes (over the queue)
 };
-// Row of the per-azimuth table: G_l (L + 1 coefficients, descending powers), H_l (L), one pad, then cos(m psi_l) and
-// sin(m psi_l), m = 1..L (phase 1 evaluates r_i with them): 4L + 2 doubles, 16-byte rows.
-__host__ __device__ constexpr int jpoly_row(const int L) { return 4 * L + 2; }
-__host__ __device__ constexpr int jpoly_trig(const int L) { return 2 * L + 2; }   // offset of cos(psi_l) in a row
+// Row of the per-azimuth table: G_l (L + 1 coefficients, descending powers), H_l (L), cos(psi_l), sin(psi_l) (the
+// higher orders follow by the angle-addition recurrence where r_i is evaluated), the Gauss-Legendre weight of the
+// RING with the row's index (n_q rows, n_q rings: the table doubles as the weight table), then padding to 16-byte
+// rows whose stride is 2 mod 4 doubles: sixteen lanes reading sixteen rows with ds_read_b128 then spread over all
+// banks (a 128-byte stride, 2L + 4 = 16 at L = 6, puts every row on the same banks: the kernel ran 3x slower).
+__host__ __device__ constexpr int jpoly_row(const int L) { return ((2 * L + 4) % 4 == 2) ? 2 * L + 4 : 2 * L + 6; }
+__host__ __device__ constexpr int jpoly_trig(const int L) { return 2 * L + 1; }   // offset of cos(psi_l) in a row; sin follows
+__host__ __device__ constexpr int jpoly_glw(const int L) { return 2 * L + 3; }    // offset of the weight of ring `row index`
 // Rows of the first-stage table PJ: (order m, part) for m = 0..L+1 — the order L + 1 is empty (zeros), see jpoly_build.
 __host__ __device__ constexpr int jpoly_rows(const int L) { return 2 * L + 4; }
 __host__ __device__ inline WaveLdsLayout wave_lds_layout(const int L, const int rows, const bool weighted = false,
@@ -191,9 +200,12 @@ __host__ __device__ inline WaveLdsLayout wave_lds_layout(const int L, const int 
   // polynomials of particle j.
   const bool alias = SHP_ALIAS_FROM_L <= L;
   w.trig = kFrame;
+  // JPT kernels with all rings resident (one ring group): the rotated vector lies over the queue (below); with ring
+  // groups particle i's vector has to survive the groups' node loops and keeps a place of its own behind the frame
+  const bool v0_over_queue = nqj > 0 && rows >= nqj;
   w.v0 = (alias || nqj > 0) ? kFrame : w.trig + 6 * (L + 1);
   w.v1 = w.v0 + ns;
-  w.ring = (alias || nqj > 0) ? w.v0 + ns : w.v1 + ns;
+  w.ring = (nqj > 0) ? (v0_over_queue ? kFrame : w.v0 + ns) : (alias ? w.v0 + ns : w.v1 + ns);
   w.ring += w.ring & 1;  // 16-byte aligned rows for ds_read_b128
   // the first stage of particle j's polynomials ((2L+4)(L+1) doubles, +2: a read one past a row's end) lies over the ring rows, which are built later
   int ringsz = 4 * rows * (L + 1);
@@ -203,7 +215,19 @@ __host__ __device__ inline WaveLdsLayout wave_lds_layout(const int L, const int 
   w.qrj = w.qri + kQueue;
   w.qp = w.qrj + kQueue;
   w.qw = w.qp + kQueue / 4;
+  w.park = w.qri;
   w.coef = w.qw + (weighted ? kQueue : 0);
+  if (nqj > 0) {
+    // the rotated vector (of j, then of i) lies over the queue: it is read while the queue is empty (first-stage
+    // table build, ring builds at the start of a ring group); parked sums and the prefetched Gauss node share the
+    // queue's second array meanwhile (the kernel's park / stash offsets)
+    w.park = w.qri;
+    if (v0_over_queue) {
+      w.v0 = w.qri;
+      w.park = w.v0 + ns + (ns & 1);
+    }
+    if (w.park + 192 > w.coef) w.coef = w.park + 192;   // large L: vector + parking lot are longer than the queue
+  }
   if (alias && nqj == 0) {
     w.trig = w.qri;
     w.v1 = w.trig + 6 * (L + 1);
@@ -214,8 +238,8 @@ __host__ __device__ inline WaveLdsLayout wave_lds_layout(const int L, const int 
 #ifdef SHP_COEF_LDS
   w.bytes = 8 * (w.coef + sh_chunk_stride(L));
 #else
-  w.glw = w.gh + nqj * jpoly_row(L);
-  w.bytes = 8 * (w.glw + nqj);
+  w.glw = w.gh + jpoly_glw(L);   // weight of ring k at glw + k * jpoly_row(L)
+  w.bytes = 8 * (w.gh + nqj * jpoly_row(L));
 #endif
   // the epilogue's reduction scratch lies behind the frame, over everything that is dead by then
   if (w.bytes < 8 * (kFrame + kRedDoubles)) w.bytes = 8 * (kFrame + kRedDoubles);
@@ -563,7 +587,7 @@ __device__ __forceinline__ void cap_frame_rings(const PairParams& P, double* __r
                                                 const double hw, const double hm, const bool have_first = false)
 {
   // have_first (PRE kernels): the Gauss-Legendre node of this lane's ring in the first pass of the first ring group
-  // was requested at the start of the kernel and waits in the (empty) queue at lw[W.qri + 128 + lane]
+  // was requested at the start of the kernel and waits in the (empty) queue at lw[W.park + 128 + lane]
   const double* ch = lw + W.v0;
   double* ring = lw + W.ring;
   const int lg = (nrows <= 8) ? 3 : (nrows <= 16) ? 2 : (nrows <= 32) ? 1 : 0;   // log2 G, wave-uniform
@@ -572,7 +596,7 @@ __device__ __forceinline__ void cap_frame_rings(const PairParams& P, double* __r
   for (int kr0 = 0; kr0 < nrows; kr0 += (64 >> lg)) {
     const int kr = kr0 + (lane >> lg);
     const bool row_ok = kr < nrows;
-    const double tk = (PRE && have_first && k0 == 0 && kr0 == 0) ? lw[W.qri + 128 + lane] : P.glt[k0 + (row_ok ? kr : 0)];
+    const double tk = (PRE && have_first && k0 == 0 && kr0 == 0) ? lw[W.park + 128 + lane] : P.glt[k0 + (row_ok ? kr : 0)];
     const double mu = fma(hw, tk, hm);
     const double sig2 = fmax(0.0, fma(-mu, mu, 1.0));
     const double sig = sqrt_nr(sig2);
@@ -794,16 +818,9 @@ __device__ __forceinline__ void jpoly_build(const PairParams& P, double* __restr
         sn[a] = tj[4 * a + 1];
       }
     }
-    if (lok && kq == 0) {   // the row's own cos/sin(m psi_l), m = 1..L: orders of this lane's parity
-      double* tr = gh + l * RS + jpoly_trig(L) - 1;
-#pragma unroll
-      for (int a = 0; a < NM; ++a) {
-        const int m = 2 * a + par;
-        if (m >= 1 && m <= L) {
-          tr[m] = cs[a];
-          tr[L + m] = sn[a];
-        }
-      }
+    if (lok && kq == 0 && par == 1) {   // the row's own cos(psi_l), sin(psi_l): the first order of the odd lanes
+      gh[l * RS + jpoly_trig(L)] = cs[0];
+      gh[l * RS + jpoly_trig(L) + 1] = sn[0];
     }
     // column of the power k in a row: G: L - k; H: 2L - k  (descending powers, Horner order)
     double* out = gh + (lok ? l : 0) * RS + (par ? 2 * L : L) - kq;
@@ -889,6 +906,35 @@ __device__ __forceinline__ void ring_grad_rec(const double* __restrict__ row, co
       sm = s;
     }
   }
+}
+
+// Two evaluations from one pass over the row (phase 1: the two nodes of a lane's pair share it)
+template <int L>
+__device__ __forceinline__ void jpoly_eval2(const double* __restrict__ row, const double mua, const double siga,
+                                            const double mub, const double sigb, double& ra, double& rb)
+{
+  const double c0 = row[0];
+  double ga = c0, gb = c0;
+#pragma unroll
+  for (int t = 1; t <= L; ++t) {
+    const double c = row[t];
+    ga = fma(ga, mua, c);
+    gb = fma(gb, mub, c);
+  }
+  if constexpr (L >= 1) {
+    const double h0 = row[L + 1];
+    double ha = h0, hb = h0;
+#pragma unroll
+    for (int t = L + 2; t <= 2 * L; ++t) {
+      const double c = row[t];
+      ha = fma(ha, mua, c);
+      hb = fma(hb, mub, c);
+    }
+    ga = fma(siga, ha, ga);
+    gb = fma(sigb, hb, gb);
+  }
+  ra = ga;
+  rb = gb;
 }
 
 // A lane's row of the per-azimuth table in registers: phase 1 keeps it from slab to slab when the lanes' azimuths do
@@ -991,9 +1037,9 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
   }
   const bool centre_in_bj = rid[3] != 0;  // rho < Rj
   if constexpr (JP && SHP_GRAD_LDS)
-    for (int t = lane; t < nq; t += 64) lw[W.glw + t] = P.glw[t];
+    for (int t = lane; t < nq; t += 64) lw[W.glw + t * jpoly_row(LJ)] = P.glw[t];
   if (lane < kRecUsed) lw[lane] = recv;
-  if constexpr (JP && L <= 8) lw[W.qri + 128 + lane] = glt_first;
+  if constexpr (JP && L <= 8) lw[W.park + 128 + lane] = glt_first;
   if constexpr (JP) {
 #pragma unroll
     for (int t = 0; t < NSL; ++t)
@@ -1093,10 +1139,10 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
     // the queue is empty between ring groups: four of the seven sums wait there while the ring tables are built
     // (eight registers the build has for its recurrences instead of spilling)
     if constexpr (JP) {   // 128 registers: two sums wait in the empty queue (they would be spilled otherwise)
-      double* park = lr + W.qri + lane;
+      double* park = lr + W.park + lane;
       park[0] = aT2; park[64] = NEEDV ? aV : aS0;
       cap_frame_rings<L, (L <= 8)>(P, lr, W, LL, lane, k0, kend - k0, lr[FR_HW], lr[FR_HM], true);
-      park = SHP_LDS() + W.qri + lane;
+      park = SHP_LDS() + W.park + lane;
       aT2 = park[0];
       if (NEEDV) aV = park[64]; else aS0 = park[64];
       wave_lds_sync();
@@ -1245,20 +1291,32 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
       const bool valid = pp < nq * nq;
       const int k = valid ? (int)(((unsigned)pp * magicr) >> 24) : 0;
       const int l = valid ? pp - k * nq : 0;
-      if (!jaligned || jp_stale) {   // wave-uniform
-        jp.load(fr + W.gh + l * jpoly_row(LJ));
-        jp_stale = false;
+      if constexpr (!SHP_ROOT_LDS) {
+        if (!jaligned || jp_stale) {   // wave-uniform
+          jp.load(fr + W.gh + l * jpoly_row(LJ));
+          jp_stale = false;
+        }
       }
       const double* row = fr + W.ring + (k - k0) * rowlen;
       const double mu = row[1], sig = row[3];
       // r_i at the two azimuths: psi + pi changes the sign of the odd orders
-      const double* tg = fr + W.gh + l * jpoly_row(LJ) + jpoly_trig(LJ) - 1;   // cos(m psi_l) at tg[m], sin at tg[L + m]
+      // cos/sin(m psi_l): the first order from the lane's row of particle j's table, the rest by angle addition
+      const double* gr = fr + W.gh + l * jpoly_row(LJ);
       double re = row[0], ro = 0.0;
+      if constexpr (LJ >= 1) {
+        const double c1 = gr[jpoly_trig(LJ)], s1 = gr[jpoly_trig(LJ) + 1];
+        double cm = c1, sm = s1;
 #pragma unroll
-      for (int m = 1; m <= LJ; ++m) {
-        const double A = row[4 * m], B = row[4 * m + 1];
-        if (m & 1) ro = fma(A, tg[m], fma(B, tg[LJ + m], ro));
-        else re = fma(A, tg[m], fma(B, tg[LJ + m], re));
+        for (int m = 1; m <= LJ; ++m) {
+          const double A = row[4 * m], B = row[4 * m + 1];
+          if (m & 1) ro = fma(A, cm, fma(B, sm, ro));
+          else re = fma(A, cm, fma(B, sm, re));
+          if (m < LJ) {
+            const double c = fma(cm, c1, -(sm * s1)), s = fma(cm, s1, sm * c1);
+            cm = c;
+            sm = s;
+          }
+        }
       }
       const double ria = re + ro, rib = re - ro;
       const double rho = s_rho, rj2 = s_rj2;
@@ -1269,7 +1327,13 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
       if (!__any(canda || candb)) continue;   // wave-uniform: all 128 nodes miss B_j
       const bool za = !(sa2 > 0.0), zb = !(sb2 > 0.0);
       const double inva = rsqrt_nr1(fmax(sa2, 1e-300)), invb = rsqrt_nr1(fmax(sb2, 1e-300));
-      const double rjae = jp.eval(qa0 * inva, qa1 * inva), rjbe = jp.eval(qb0 * invb, qb1 * invb);
+      double rjae, rjbe;
+      if constexpr (SHP_ROOT_LDS) {
+        jpoly_eval2<LJ>(fr + W.gh + l * jpoly_row(LJ), qa0 * inva, qa1 * inva, qb0 * invb, qb1 * invb, rjae, rjbe);
+      } else {
+        rjae = jp.eval(qa0 * inva, qa1 * inva);
+        rjbe = jp.eval(qb0 * invb, qb1 * invb);
+      }
       const double Rjl = s_rj;
       const double rja = za ? Rjl : rjae, rjb = zb ? Rjl : rjbe;
       const bool ina = canda && (za || sa2 * inva < rja), inb = candb && (zb || sb2 * invb < rjb);
@@ -1364,7 +1428,7 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
     double ri = fr[W.qri + e];
     int k = (int)(((unsigned)p * magic) >> 24);
     int l = p - k * npsi;
-    double omi = active ? fr[FR_WSC] * ((JP && SHP_GRAD_LDS) ? fr[W.glw + k] : P.glw[k]) : 0.0;   // the node's plain weight
+    double omi = active ? fr[FR_WSC] * ((JP && SHP_GRAD_LDS) ? fr[W.glw + k * jpoly_row(LJ)] : P.glw[k]) : 0.0;   // the node's plain weight
     bool outside = false;    // WEIGHTED: a node with g~ >= 0 has no ray segment inside j
     if (WEIGHTED) outside = !(fr[W.qw + e] > 0.0);
     double c1 = P.cpsi[l], s1 = P.spsi[l];
@@ -1382,9 +1446,12 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
       // the node's ray seen from x_j: compiled orders (axial, signed radial) = (lambda mu - rho, +-lambda sigma) in the
       // common frame; run-time-order kernel lambda u_j - d_j in j's body frame
       double uj0, uj1, uj2 = 0.0;
+      const int ghrow_ = W.gh + (l >= nq ? l - nq : l) * jpoly_row(LJ);
       if constexpr (JP) {
-        jp.load(fr + W.gh + (l >= nq ? l - nq : l) * jpoly_row(LJ));   // this node's row of particle j's table
-        jp_stale = true;
+        if constexpr (!SHP_ROOT_LDS) {
+          jp.load(fr + ghrow_);   // this node's row of particle j's table
+          jp_stale = true;
+        }
         uj0 = mu;
         uj1 = (l >= nq) ? -sig : sig;
       } else {
@@ -1437,7 +1504,8 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
         const bool z0 = !(ss2 > 0.0);
         const double iv = rsqrt_nr1(fmax(ss2, 1e-300));
         double rj;
-        if constexpr (JP) rj = jp.eval(y0 * iv, y1 * iv);
+        if constexpr (JP && SHP_ROOT_LDS) rj = jpoly_eval<LJ>(fr + ghrow_, y0 * iv, y1 * iv);
+        else if constexpr (JP) rj = jp.eval(y0 * iv, y1 * iv);
         else rj = sh_eval<L>(rc, cwj, lrt, y0 * iv, y1 * iv, y2 * iv);
         const double Rjl = JP ? s_rj : fr[FR_RJ];
         const double gl = z0 ? -Rjl : ss2 * iv - rj;
@@ -1508,7 +1576,7 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
         p = (int)launder_u32((unsigned)p);
         k = (int)(((unsigned)p * magic) >> 24);
         l = p - k * npsi;
-        omi = active ? fr[FR_WSC] * (SHP_GRAD_LDS ? fr[W.glw + k] : P.glw[k]) : 0.0;
+        omi = active ? fr[FR_WSC] * (SHP_GRAD_LDS ? fr[W.glw + k * jpoly_row(LJ)] : P.glw[k]) : 0.0;
         if constexpr (!SHP_GRAD_LDS) {
           c1 = P.cpsi[l];
           s1 = P.spsi[l];
@@ -1542,10 +1610,10 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
     double r2, rmu, rpsi;
     if constexpr (JP && SHP_GRAD_LDS == 2) {
       const double sg = (l >= nq) ? -1.0 : 1.0;
-      const double* tg = fr + W.gh + (l >= nq ? l - nq : l) * jpoly_row(LJ) + jpoly_trig(LJ) - 1;
+      const double* tg = fr + W.gh + (l >= nq ? l - nq : l) * jpoly_row(LJ) + jpoly_trig(LJ);
       if constexpr (LJ >= 1) {
-        c1 = sg * tg[1];
-        s1 = sg * tg[LJ + 1];
+        c1 = sg * tg[0];
+        s1 = sg * tg[1];
       }
       ring_grad_rec<LJ>(fr + W.ring + (k - k0) * rowlen, c1, s1, rmu, rpsi);
       (void)r2;

@@ -51,7 +51,7 @@ def test_register_budgets_match_the_wave_targets():
         checked += 1
         L, needv, weighted, jpoly = int(m.group(1)), m.group(2) == "1", m.group(3) == "1", m.group(4) == "1"
         if jpoly:
-            waves = 5 if L <= 2 else (4 if L <= 6 else (3 if L <= 8 else 2))
+            waves = 5 if L <= 6 else 4
         elif weighted:
             waves = 5 if (L <= 6 and L != 3) else 4
         elif needv:
