@@ -119,16 +119,6 @@ constexpr int kPairErrType = 2;   // an atom type outside [1, ntypes]
   ((NEEDV) ? (((L) == 0 || (L) == 1 || (L) == 6) ? 6 : 5) : (((L) >= 0 && (L) <= 6) ? 6 : 5))
 #endif
 // kernels that evaluate particle j from per-azimuth polynomials (JPT): a lane's row sits in 4L + 2 registers
-#ifndef SHP_ROOT_LDS
-#define SHP_ROOT_LDS 1   // 1: phase 1 (once per node pair) and the root loop (once per iteration) read their row of particle j's
-                         // table from LDS; 0: rows held in 4L + 2 registers (one wave per SIMD less)
-#endif
-#ifndef SHP_GRAD_LDS
-#define SHP_GRAD_LDS 2   // JPT kernels: weights and cos/sin(m psi) of the gradient from LDS (1), from LDS with the orders above
-                         // 1 by the angle-addition recurrence (2: no table round trip per batch, -1.4 %) or the global tables (0).
-                         // 1 is correct and saves a table round trip per batch, but the register allocator then spills 130
-                         // registers of the L = 6 kernel under its 128-register bound (round 2); kept for another try
-#endif
 #ifndef SHP_JMIN_WAVES
 #define SHP_JMIN_WAVES(L, NEEDV) (((L) <= 6) ? 5 : 4)
 #endif
@@ -858,34 +848,8 @@ __device__ __forceinline__ double jpoly_eval(const double* __restrict__ row, con
   return g;
 }
 
-// mu- and psi-derivative of r_i at a node of ring row `row` for the JPT kernels: cos/sin(m psi) come from the node's
-// row of particle j's table (tg[m], tg[L + m]; the row of azimuth l - n_q serves l >= n_q with sg = -1 on the odd orders)
-template <int L>
-__device__ __forceinline__ void ring_grad_jp(const double* __restrict__ row, const double* __restrict__ tg, const double sg,
-                                             double& rmu, double& rpsi)
-{
-  double mue = row[2], muo = 0.0, pse = 0.0, pso = 0.0;
-#pragma unroll
-  for (int m = 1; m <= L; ++m) {
-    const double A = row[4 * m], B = row[4 * m + 1], Am = row[4 * m + 2], Bm = row[4 * m + 3];
-    const double c = tg[m], s = tg[L + m], dm = (double)m;
-    if (m & 1) {
-      muo = fma(Am, c, fma(Bm, s, muo));
-      pso = fma(dm * B, c, fma(-dm * A, s, pso));
-    } else {
-      mue = fma(Am, c, fma(Bm, s, mue));
-      pse = fma(dm * B, c, fma(-dm * A, s, pse));
-    }
-    // two orders' operands in flight at a time: left alone the scheduler requests all 6 L values first, and the
-    // kernel spills a hundred registers around the root loop
-    if ((m & 1) == 0) __builtin_amdgcn_sched_barrier(0);
-  }
-  rmu = fma(sg, muo, mue);
-  rpsi = fma(sg, pso, pse);
-}
-
-// The same from (cos psi, sin psi) alone, the higher orders by the angle-addition recurrence (4 v_fma_f64 per order):
-// no table is read, at 4 (L - 1) more instructions per batch.
+// mu- and psi-derivative of r_i at a node of ring row `row` for the JPT kernels, from (cos psi, sin psi) alone: the
+// higher orders by the angle-addition recurrence (4 v_fma_f64 per order), no table is read.
 template <int L>
 __device__ __forceinline__ void ring_grad_rec(const double* __restrict__ row, const double c1, const double s1, double& rmu,
                                               double& rpsi)
@@ -936,31 +900,6 @@ __device__ __forceinline__ void jpoly_eval2(const double* __restrict__ row, cons
   ra = ga;
   rb = gb;
 }
-
-// A lane's row of the per-azimuth table in registers: phase 1 keeps it from slab to slab when the lanes' azimuths do
-// not change (n_q divides 64), the inner-radius search across its iterations.
-template <int L>
-struct JPoly {
-  double c[2 * L + 1];
-  __device__ __forceinline__ void load(const double* __restrict__ row)
-  {
-#pragma unroll
-    for (int t = 0; t < 2 * L + 1; ++t) c[t] = row[t];
-  }
-  __device__ __forceinline__ double eval(const double mu, const double sig) const
-  {
-    double g = c[0];
-#pragma unroll
-    for (int t = 1; t <= L; ++t) g = fma(g, mu, c[t]);
-    if constexpr (L >= 1) {
-      double h = c[L + 1];
-#pragma unroll
-      for (int t = L + 2; t <= 2 * L; ++t) h = fma(h, mu, c[t]);
-      g = fma(sig, h, g);
-    }
-    return g;
-  }
-};
 
 // WEIGHTED (SPEC §2.8): phase 1 keeps the residuals g~ of three consecutive slabs in registers, so that a
 // node's azimuth and ring neighbours are a cross-lane read away, and queues every node with a positive
@@ -1036,7 +975,7 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
     s_tiny = rs[FR_JTINY];
   }
   const bool centre_in_bj = rid[3] != 0;  // rho < Rj
-  if constexpr (JP && SHP_GRAD_LDS)
+  if constexpr (JP)
     for (int t = lane; t < nq; t += 64) lw[W.glw + t * jpoly_row(LJ)] = P.glw[t];
   if (lane < kRecUsed) lw[lane] = recv;
   if constexpr (JP && L <= 8) lw[W.park + 128 + lane] = glt_first;
@@ -1114,10 +1053,6 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
   double wg1 = 0.0, wg2 = 0.0, wri1 = 0.0, wrj1 = 0.0;  // WEIGHTED: residuals of slabs t-1, t-2; r_i, r_j of slab t-1
   bool win1 = false;
   const bool aligned = (npsi <= 64) && ((64 % npsi) == 0);  // wave-uniform
-  // JPT: a lane's azimuth is the same in every slab when n_q divides 64; its rows then stay in registers
-  const bool jaligned = (nq <= 64) && ((64 % nq) == 0);
-  bool jp_stale = true;          // wave-uniform: `jp` does not hold this lane's phase-1 row
-  JPoly<LJ> jp;
   // the second node of a lane's pair waits here while a full batch is drained (the queue holds 128)
   bool pend = false, pend_in = false;   // pend: wave-uniform
   int pend_p = 0;
@@ -1291,12 +1226,6 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
       const bool valid = pp < nq * nq;
       const int k = valid ? (int)(((unsigned)pp * magicr) >> 24) : 0;
       const int l = valid ? pp - k * nq : 0;
-      if constexpr (!SHP_ROOT_LDS) {
-        if (!jaligned || jp_stale) {   // wave-uniform
-          jp.load(fr + W.gh + l * jpoly_row(LJ));
-          jp_stale = false;
-        }
-      }
       const double* row = fr + W.ring + (k - k0) * rowlen;
       const double mu = row[1], sig = row[3];
       // r_i at the two azimuths: psi + pi changes the sign of the odd orders
@@ -1327,13 +1256,8 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
       if (!__any(canda || candb)) continue;   // wave-uniform: all 128 nodes miss B_j
       const bool za = !(sa2 > 0.0), zb = !(sb2 > 0.0);
       const double inva = rsqrt_nr1(fmax(sa2, 1e-300)), invb = rsqrt_nr1(fmax(sb2, 1e-300));
-      double rjae, rjbe;
-      if constexpr (SHP_ROOT_LDS) {
-        jpoly_eval2<LJ>(fr + W.gh + l * jpoly_row(LJ), qa0 * inva, qa1 * inva, qb0 * invb, qb1 * invb, rjae, rjbe);
-      } else {
-        rjae = jp.eval(qa0 * inva, qa1 * inva);
-        rjbe = jp.eval(qb0 * invb, qb1 * invb);
-      }
+      double rjae, rjbe;   // one pass over the lane's row of particle j's table serves both nodes
+      jpoly_eval2<LJ>(fr + W.gh + l * jpoly_row(LJ), qa0 * inva, qa1 * inva, qb0 * invb, qb1 * invb, rjae, rjbe);
       const double Rjl = s_rj;
       const double rja = za ? Rjl : rjae, rjb = zb ? Rjl : rjbe;
       const bool ina = canda && (za || sa2 * inva < rja), inb = candb && (zb || sb2 * invb < rjb);
@@ -1428,7 +1352,7 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
     double ri = fr[W.qri + e];
     int k = (int)(((unsigned)p * magic) >> 24);
     int l = p - k * npsi;
-    double omi = active ? fr[FR_WSC] * ((JP && SHP_GRAD_LDS) ? fr[W.glw + k * jpoly_row(LJ)] : P.glw[k]) : 0.0;   // the node's plain weight
+    double omi = active ? fr[FR_WSC] * (JP ? fr[W.glw + k * jpoly_row(LJ)] : P.glw[k]) : 0.0;   // the node's plain weight
     bool outside = false;    // WEIGHTED: a node with g~ >= 0 has no ray segment inside j
     if (WEIGHTED) outside = !(fr[W.qw + e] > 0.0);
     double c1 = P.cpsi[l], s1 = P.spsi[l];
@@ -1448,10 +1372,6 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
       double uj0, uj1, uj2 = 0.0;
       const int ghrow_ = W.gh + (l >= nq ? l - nq : l) * jpoly_row(LJ);
       if constexpr (JP) {
-        if constexpr (!SHP_ROOT_LDS) {
-          jp.load(fr + ghrow_);   // this node's row of particle j's table
-          jp_stale = true;
-        }
         uj0 = mu;
         uj1 = (l >= nq) ? -sig : sig;
       } else {
@@ -1504,8 +1424,7 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
         const bool z0 = !(ss2 > 0.0);
         const double iv = rsqrt_nr1(fmax(ss2, 1e-300));
         double rj;
-        if constexpr (JP && SHP_ROOT_LDS) rj = jpoly_eval<LJ>(fr + ghrow_, y0 * iv, y1 * iv);
-        else if constexpr (JP) rj = jp.eval(y0 * iv, y1 * iv);
+        if constexpr (JP) rj = jpoly_eval<LJ>(fr + ghrow_, y0 * iv, y1 * iv);   // the node's row, read at every iteration
         else rj = sh_eval<L>(rc, cwj, lrt, y0 * iv, y1 * iv, y2 * iv);
         const double Rjl = JP ? s_rj : fr[FR_RJ];
         const double gl = z0 ? -Rjl : ss2 * iv - rj;
@@ -1576,11 +1495,7 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
         p = (int)launder_u32((unsigned)p);
         k = (int)(((unsigned)p * magic) >> 24);
         l = p - k * npsi;
-        omi = active ? fr[FR_WSC] * (SHP_GRAD_LDS ? fr[W.glw + k * jpoly_row(LJ)] : P.glw[k]) : 0.0;
-        if constexpr (!SHP_GRAD_LDS) {
-          c1 = P.cpsi[l];
-          s1 = P.spsi[l];
-        }
+        omi = active ? fr[FR_WSC] * fr[W.glw + k * jpoly_row(LJ)] : 0.0;
         const double* row = fr + W.ring + (k - k0) * rowlen;
         mu = row[1];
         sig = row[3];
@@ -1608,7 +1523,7 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
     //   u = (sigma c, sigma s, mu), gamma^ = (mu c, mu s, -sigma), psi^ = (-s, c, 0)
     fr = SHP_LDS();
     double r2, rmu, rpsi;
-    if constexpr (JP && SHP_GRAD_LDS == 2) {
+    if constexpr (JP) {
       const double sg = (l >= nq) ? -1.0 : 1.0;
       const double* tg = fr + W.gh + (l >= nq ? l - nq : l) * jpoly_row(LJ) + jpoly_trig(LJ);
       if constexpr (LJ >= 1) {
@@ -1616,15 +1531,6 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
         s1 = sg * tg[1];
       }
       ring_grad_rec<LJ>(fr + W.ring + (k - k0) * rowlen, c1, s1, rmu, rpsi);
-      (void)r2;
-    } else if constexpr (JP && SHP_GRAD_LDS == 1) {
-      const double sg = (l >= nq) ? -1.0 : 1.0;
-      const double* tg = fr + W.gh + (l >= nq ? l - nq : l) * jpoly_row(LJ) + jpoly_trig(LJ) - 1;
-      if constexpr (LJ >= 1) {
-        c1 = sg * tg[1];
-        s1 = sg * tg[LJ + 1];
-      }
-      ring_grad_jp<LJ>(fr + W.ring + (k - k0) * rowlen, tg, sg, rmu, rpsi);
       (void)r2;
     } else {
       ring_eval<L, true>(fr + W.ring + (k - k0) * rowlen, LL, c1, s1, P.trig + (trig_lmajor(L) ? (size_t)P.trig_stride * l : (size_t)(2 * l)), P.trig_stride, r2, rmu, rpsi);

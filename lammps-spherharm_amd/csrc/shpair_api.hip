@@ -382,18 +382,17 @@ int shpair_set_neighbors_device(shpair_ctx* c, int inum, const int* ilist, const
 
 // Which kernel family evaluates particle j (pair_kernel.hpp): per-azimuth polynomials in the pair's common frame
 // (JPT kernels + rotation kernel) or the body-frame Horner evaluation.  The first trades ~170 instructions and a
-// table build per pair for 60 fewer per radius evaluation, at 4 (L <= 6), 3 or 2 resident waves per SIMD instead of
-// 5-6: it wins when a pair has enough cap nodes.  Option "jpoly": 1 / 0 force, -1 (default) the measured rule
-// (interleaved A/B over L = 2..12 x n_q = 8..32, profiles/r02_w_jpoly_matrix.txt).
+// table build per pair for 60 fewer per radius evaluation: it wins unless a pair has very few cap nodes.  Option
+// "jpoly": 1 / 0 force, -1 (default) the measured rule (interleaved A/B over L = 0..12 x n_q = 4..32,
+// profiles/r02_y_jpoly_matrix.txt: the body-frame family is faster only at n_q = 4 from L = 6 and at n_q <= 8 from L = 9).
 static bool use_jpoly(const shpair_ctx* c)
 {
   if (c->lmax > kMaxUnrolledL || c->opt_variant == 1 || c->opt_rule) return false;
   if (c->opt_jpoly >= 0) return c->opt_jpoly == 1;
   const int L = c->lmax, nq = c->nq;
-  if (L <= 4) return true;
-  if (L <= 6) return nq >= 12;
-  if (L <= 10) return nq >= 16;
-  return nq >= 32;
+  if (L <= 5) return true;
+  if (L <= 8) return nq >= 6;
+  return nq >= 12;
 }
 
 }  // extern "C"
