@@ -140,7 +140,9 @@ int shpair_compute_device(shpair_ctx *ctx, int nlocal, int nghost, const double 
  * override the number of quadrature rings whose tables are LDS resident at a time; tuning), "jpoly" (which kernel
  * family evaluates the neighbour's radius for the compiled orders lmax <= 12, sharp rule: 1 = per-azimuth
  * polynomials in the pair's common frame, 0 = body-frame Horner evaluation, -1 (default) = whichever the library's
- * measured rule picks for (lmax, nq); same results to rounding, ~1e-14 relative). */
+ * measured rule picks for (lmax, nq); same results to rounding, ~1e-14 relative); diagnostics: "jpoly_rot" (1: the
+ * rotations of the "jpoly" family by a wave per rotation instead of a lane per rotation), "lds_pad" (unused LDS bytes
+ * added to every wave of the contact kernel: fewer resident waves, for occupancy experiments). */
 int shpair_set_option(shpair_ctx *ctx, const char *key, int value);
 
 /* Static footprint of the pair kernel the last compute launched (occupancy evidence): registers per lane, LDS

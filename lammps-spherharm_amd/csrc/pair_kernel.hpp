@@ -24,6 +24,11 @@
 // T_n) are reduced with cross-lane shuffles and lane 0 applies the force law and
 // issues the FP64 atomics.  One wave per workgroup.
 // No MFMA: the work is polynomial evaluation per node, FP64 VALU bound.
+// Two kernel families differ in how particle j's radius is evaluated (template parameter JPT, chosen per (L, n_q) by
+// shpair_api.hip use_jpoly): 0 in j's body frame from scalar-fed monomial coefficients (sh_device.hpp); 1 — the
+// default almost everywhere — from per-azimuth polynomials in the pair's common frame, with the coefficient rotations
+// of both particles in a kernel of their own (pair_rotate_lane_kernel) and node PAIRS per lane in phase 1: see the
+// block comment above jpoly_build.
 //
 // Reference: PairSH::compute() of the reference is ABSENT FROM MOUNT
 // (/root/reference/README.md:1 is the whole mount).

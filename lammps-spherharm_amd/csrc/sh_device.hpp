@@ -1,7 +1,9 @@
 // sh_device.hpp — device-side spherical-harmonic radius evaluation for gfx950.
 //
-// Used for particle j (whose evaluation points have no ring structure; particle
-// i is evaluated from the ring tables of pair_kernel.hpp).
+// The body-frame evaluation of particle j (kernel family 0 of pair_kernel.hpp: very small n_q, the weighted rule, the
+// run-time orders; particle i is evaluated from the ring tables there).  The default family for the compiled orders
+// does not come through here: all points a pair evaluates r_j at lie on the rule's azimuths about the line of
+// centres, and r_j becomes a pair of polynomials per azimuth (pair_kernel.hpp, jpoly_build).
 //
 // docs/SPEC.md §1 in the angle-free polynomial form: for a unit vector (x,y,z)
 //   r = sum_m Re[ W_m(z) (x+iy)^m ],  W_m(z) = sum_n (2-delta_m0) a_nm Pi_n^m(z),
