@@ -71,12 +71,12 @@ def test_forces_and_torques_match_oracle(oracle, lmax, nq, nshapes, expo, fv):
 
 @pytest.mark.parametrize("lmax,nq,jpoly", [(L, nq, jp) for L, nq in ((0, 5), (1, 8), (2, 7), (3, 16), (4, 9), (5, 12), (6, 8),
                                                                      (6, 20), (7, 10), (8, 16), (9, 6), (10, 11),
-                                                                     (11, 8), (12, 16)) for jp in (0, 1)])
+                                                                     (11, 8), (12, 16), (2, 1), (3, 2), (4, 3), (6, 40), (5, 64), (12, 40)) for jp in (0, 1)])
 def test_both_kernel_families_match_oracle(oracle, lmax, nq, jpoly):
     """Every compiled order through BOTH kernel families, forced with the "jpoly" option (left alone the library
     picks one per (lmax, nq)): the body-frame Horner evaluation of the neighbour's radius, and the per-azimuth
     polynomials in the pair's common frame (rotation kernel + node pairs; odd and even n_q, n_q that do and do not
-    divide 64, ragged last slabs), with the volume path and two shapes."""
+    divide 64, ragged last slabs, one to three rings, 64 rings, ring groups), with the volume path and two shapes."""
     case = make_case(200, lmax, 2, seed=100 + lmax, rmax_fn=oracle.shape_rmax)
     K, E = coeff_tables(1, 1000.0, 1.25)
     sp = make_ctx(case, nq, K, E)
