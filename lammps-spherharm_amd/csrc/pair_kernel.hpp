@@ -935,6 +935,10 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
   double* lw = SHP_LDS();
 
   // the pair's record (pair_setup.hpp): scalar loads of the four ints, one coalesced vector load of the frame
+  // Wave priority: the prologue, the table builds and the epilogue are chains of dependent memory / LDS round trips
+  // with a few instructions in between; they issue ahead of the waves that are in their node loops (priority 0), so
+  // that a pair's latency-bound stretches are as short as the memory system allows (-1.8 % at the headline).
+  __builtin_amdgcn_s_setprio(3);
   const int* rid = P.rec_i + 4 * (size_t)w;
   // Everything the prologue reads from memory is requested before the slot's status is looked at (a scalar load of
   // its own: waiting for it first would put two memory round trips in a row at the start of every pair).  The
@@ -1074,6 +1078,7 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
   const int kend = (k0 + P.ring_rows < nq) ? k0 + P.ring_rows : nq;
   const int slab_end = (kend == nq) ? (WEIGHTED ? nslabs + 1 : nslabs) : ((kend * per_ring) >> 6);
   if (slab_end <= slab) return;  // cannot happen with the host's ring_rows; never spin
+  __builtin_amdgcn_s_setprio(3);
   {
     double* lr = SHP_LDS();
     // the queue is empty between ring groups: four of the seven sums wait there while the ring tables are built
@@ -1101,6 +1106,7 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
 #endif
   }
 
+  __builtin_amdgcn_s_setprio(0);
   for (;;) {
     // ---------------------------------------------------------------- phase 1
     // classify slabs of 64 cap nodes until 64 inside nodes are queued
@@ -1567,6 +1573,7 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
   // dead) and added in two levels of 8; the force law runs with one COMPONENT per lane — lanes 0-2 the force, 3-5
   // the torque — so the rotation is 3 FMAs instead of 18 and the scatter is ONE 6-lane global_atomic_add_f64 per
   // atom (f[3i..3i+2] and torque[3i..3i+2] are contiguous: 2 memory-side operations per atom instead of 6).
+  __builtin_amdgcn_s_setprio(3);
   lane = fresh_lane();
   {
     double* red = SHP_LDS() + kFrame;   // [7][kRedStride] partial sums | [56] | [7] totals | [6] force components
