@@ -103,7 +103,6 @@ int shpair_create(shpair_ctx** out, int device_id)
   shpair_ctx* c = new (std::nothrow) shpair_ctx();
   if (!c) return SHPAIR_ENOMEM;
   c->device = device_id;
-  if (const char* e = getenv("SHPAIR_JPOLY")) c->opt_jpoly = atoi(e);   // test hook: default of the "jpoly" option
   if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
       hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess ||
       hipEventCreate(&c->evA) != hipSuccess || hipEventCreate(&c->evB) != hipSuccess ||
