@@ -1264,6 +1264,12 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
       const double qb0 = fma(rib, mu, -rho), qb1 = -rib * sig;
       const double sa2 = fma(qa0, qa0, qa1 * qa1), sb2 = fma(qb0, qb0, qb1 * qb1);
       const bool canda = valid && (sa2 < rj2), candb = valid && (sb2 < rj2);
+#ifdef SHP_STATS   // a slab of this family is 128 nodes: counted as two, so that the counters compare across families
+      if (lane == 0) atomicAdd(&P.dbg[0], 2ULL);
+      if (canda) atomicAdd(&P.dbg[1], 1ULL);
+      if (candb) atomicAdd(&P.dbg[1], 1ULL);
+      { const bool a_ = __any(canda || candb); if (lane == 0 && a_) atomicAdd(&P.dbg[2], 2ULL); }
+#endif
       if (!__any(canda || candb)) continue;   // wave-uniform: all 128 nodes miss B_j
       const bool za = !(sa2 > 0.0), zb = !(sb2 > 0.0);
       const double inva = rsqrt_nr1(fmax(sa2, 1e-300)), invb = rsqrt_nr1(fmax(sb2, 1e-300));
@@ -1273,6 +1279,10 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
       const double rja = za ? Rjl : rjae, rjb = zb ? Rjl : rjbe;
       const bool ina = canda && (za || sa2 * inva < rja), inb = candb && (zb || sb2 * invb < rjb);
       const int pa = k * npsi + l;
+#ifdef SHP_STATS
+      if (ina) atomicAdd(&P.dbg[3], 1ULL);
+      if (inb) atomicAdd(&P.dbg[3], 1ULL);
+#endif
       SHP_PUSH(ina, pa, ria, rja);
       if (qcount >= 64) {   // wave-uniform: a batch is ready; the second nodes wait in registers
         pend = __any(inb);

@@ -384,15 +384,16 @@ int shpair_set_neighbors_device(shpair_ctx* c, int inum, const int* ilist, const
 // table build per pair for 60 fewer per radius evaluation: it wins unless a pair has very few cap nodes.  Option
 // "jpoly": 1 / 0 force, -1 (default) the measured rule (interleaved A/B over L = 0..12 x n_q = 4..32,
 // profiles/r02_y_jpoly_matrix.txt: the body-frame family is faster only at n_q = 4 from L = 6 and at n_q <= 8 from L = 9).
-static bool use_jpoly(const shpair_ctx* c)
+static bool use_jpoly_at(const shpair_ctx* c, const int L)
 {
-  if (c->lmax > kMaxUnrolledL || c->opt_variant == 1 || c->opt_rule) return false;
+  if (L > kMaxUnrolledL || c->opt_variant == 1 || c->opt_rule) return false;
   if (c->opt_jpoly >= 0) return c->opt_jpoly == 1;
-  const int L = c->lmax, nq = c->nq;
+  const int nq = c->nq;
   if (L <= 5) return true;
   if (L <= 8) return nq >= 6;
   return nq >= 12;
 }
+static bool use_jpoly(const shpair_ctx* c) { return use_jpoly_at(c, c->lmax); }
 
 }  // extern "C"
 
@@ -408,11 +409,7 @@ hipError_t shp_size_pair_buffers(shpair_ctx* c, size_t np)
   for (int s = 0; s < c->nshapes; ++s)
     if (c->shapes[s].lmax > L) L = c->shapes[s].lmax;
   if (e == hipSuccess && L >= 0 && c->nq > 0) {
-    const int keep = c->lmax;
-    c->lmax = L;
-    const bool jp = use_jpoly(c);
-    c->lmax = keep;
-    if (jp) e = c->d_rot.ensure(np * 2 * (size_t)(L + 1) * (L + 1));
+    if (use_jpoly_at(c, L)) e = c->d_rot.ensure(np * 2 * (size_t)(L + 1) * (L + 1));
   }
   return e;
 }
