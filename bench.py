@@ -16,6 +16,14 @@ test over all ranks [-> atom migration, ghost plan, list build] -> forward halo 
 halo -> gravity -> final_integrate; every byte between GPUs travels as ncclSend/ncclRecv issued by libshpair.so
 (RCCL over xGMI).  torch.distributed (gloo) only hands out the ncclUniqueId and reduces the timings.
 `--transport local` rehearses the same N ranks as threads of one process on one GPU (tests).
+`--gpus 1 --multi` runs that N > 1 body with ONE rank (grid 1x1x1, self-periodic, RCCL self-communicator), also
+under `python -m torch.distributed.run --nproc-per-node 1`: the code path of the driver's 8-GPU run, rehearsed on the
+one GPU of a box (tests/test_bench_contract.py launches it as a fresh child process).
+The N = 1 default line carries the same workload on one rank as `scale_ref` (125k particles, whole timesteps through
+shhalo_run_device): parallel efficiency of N GPUs = value(N) / (N x scale_ref.value) compares like with like — the
+N = 1 headline `value` is BASELINE configs[1] (static 100k bed, pair compute inside the two integrator half-steps).
+Every wait on another rank is bounded (gloo rendezvous, ncclCommInitRank, the whole run): a rank that does not come
+back ends the process with a message and exit code 4, never a hang and never a re-exec.
 
 Prints ONE JSON line on rank 0 (fields: DESIGN.md §7).
 """
@@ -77,8 +85,16 @@ def parse():
     ap.add_argument("--transport", default="rccl", choices=["rccl", "local"],
                     help="N > 1: rccl = one process per GPU, ncclSend/ncclRecv over xGMI (the product path); local = "
                          "rehearsal: the N ranks are threads of this one process on GPU 0 (no torch.distributed.run)")
-    ap.add_argument("--verify", action="store_true",
-                    help="N > 1 with --transport local: compare the decomposed forces with a single-domain compute")
+    ap.add_argument("--verify", dest="verify", action="store_true", default=None,
+                    help="N > 1: compare the decomposed initial forces with a single-domain compute on rank 0 (untimed; the "
+                         "default with --transport rccl: the first thing to know about a run between GPUs is whether its "
+                         "forces are right)")
+    ap.add_argument("--no-verify", dest="verify", action="store_false")
+    ap.add_argument("--multi", action="store_true", help="with --gpus 1: run the N > 1 body (configs[3] workload, shhalo_run_device, "
+                    "RCCL self-communicator) instead of the configs[1] headline")
+    ap.add_argument("--scale-ref", type=int, default=1, help="N = 1 default line: add the `scale_ref` object (0 = skip)")
+    ap.add_argument("--wait-s", type=float, default=240.0, help="bound of every wait on another rank (rendezvous, "
+                    "ncclCommInitRank, barriers); the whole multi-rank run is bounded by 6 x this")
     ap.add_argument("--ramp", type=int, default=8, help="extra untimed passes before the W warm-up steps: the first "
                     "~8 launches of a fresh process run up to 25 %% slower while the GPU clock ramps (rocprof per-launch "
                     "durations in profiles/); they are never part of the K timed steps")
@@ -92,9 +108,51 @@ def parse():
     ap.add_argument("--one-device", action="store_true", help="N > 1 with --transport rccl: every rank uses GPU 0 (only to probe "
                     "what RCCL does with several ranks on one device; RCCL normally refuses)")
     a = ap.parse_args()
+    multi = a.gpus > 1 or a.multi
     if a.particles <= 0:
-        a.particles = 100000 if a.gpus == 1 else 125000
+        a.particles = 125000 if multi else 100000
+    if a.verify is None:
+        a.verify = multi and a.transport == "rccl"
     return a
+
+
+class Watchdog:
+    """Bounded waits: a daemon thread that ends the process (message on stderr, exit code 4) when the phase that was
+    declared with `phase(what, seconds)` has not been left in time.  The calls it guards sit in C (ncclCommInitRank,
+    gloo collectives, hipStreamSynchronize behind an ncclRecv whose sender died) and cannot be interrupted from
+    Python; RCCL itself has no timeout.  os._exit, not an exec: the GPU is initialised."""
+
+    def __init__(self):
+        self._lock = threading.Lock()
+        self._deadline, self._what = None, ""
+        t = threading.Thread(target=self._loop, daemon=True)
+        t.start()
+
+    def _loop(self):
+        while True:
+            time.sleep(0.5)
+            with self._lock:
+                d, w = self._deadline, self._what
+            if d is not None and time.monotonic() > d:
+                rank = os.environ.get("RANK", "0")
+                print(f"bench.py: rank {rank}: '{w}' did not finish in time (another rank lost, or RCCL / gloo cannot "
+                      "reach its peers); giving up with exit code 4", file=sys.stderr, flush=True)
+                os._exit(4)
+
+    def phase(self, what, seconds):
+        wd = self
+
+        class _P:
+            def __enter__(self_inner):
+                with wd._lock:
+                    self_inner.prev = (wd._deadline, wd._what)
+                    wd._deadline, wd._what = time.monotonic() + seconds, what
+
+            def __exit__(self_inner, *exc):
+                with wd._lock:
+                    wd._deadline, wd._what = self_inner.prev
+                return False
+        return _P()
 
 
 def make_ctx(args, shp, device):
@@ -239,6 +297,8 @@ def main_single(args):
     }
     if args.ts_steps > 0:
         out["timestep"] = timestep_leg(args, shp)
+    if args.scale_ref:
+        out["scale_ref"] = scale_ref_leg(args)
     if args.cpu_seconds > 0:
         out["cpu_baseline"] = cpu_baseline(args, shp, rmax, gbed, il, of, jl)
     print(json.dumps(out), flush=True)
@@ -290,6 +350,33 @@ def timestep_leg(args, shp):
                    "all arrays resident in HBM (shpair.run.DeviceRun over include/shpair.h + include/shstep.h)"}
     sp.close()
     return out
+
+
+def scale_ref_leg(args):
+    """The N > 1 workload (BASELINE configs[3]: 125k particles per GPU, box periodic in x and y on a frozen floor,
+    gravity, thermal start, whole timesteps of shhalo_run_device with rebuild tests, migration bookkeeping and ghost
+    exchange) on ONE rank through the same code as `bench.py --gpus N`: RCCL self-communicator, grid 1x1x1.  The
+    like-for-like N = 1 point of the scaling curve: efficiency(N) = value(N) / (N x scale_ref.value)."""
+    import copy
+    a = copy.copy(args)
+    a.particles, a.gpus, a.multi, a.transport, a.verify, a.peak_ms = 125000, 1, True, "rccl", False, 0.0
+    result = {}
+    try:
+        from shpair import mrank
+        uid = mrank.unique_id()
+        multi_rank_body(a, 0, 1, 0, _Collective(1), None, uid, result, Watchdog())
+        ln = result["line"]
+        return {"value": ln["value"], "unit": ln["unit"], "ms_per_step": ln["ms_per_step"], "timesteps_per_sec": ln["timesteps_per_sec"],
+                "steps": ln["steps"], "particles": ln["config"]["particles_all_ranks"],
+                "contact_pairs": ln["config"]["contact_pairs_all_ranks"], "ghost_atoms": ln["config"]["ghost_atoms_rank0"],
+                "pair_kernel_ms": ln["roofline"]["kernel_ms"],
+                "transport": ln["halo"]["transport"], "ranks_reported_by_transport": ln["halo"]["ranks_reported_by_transport"],
+                "rebuilds_in_timed_steps": ln["halo"]["rebuilds_in_timed_steps"][0], "workload": ln["config"]["workload"],
+                "use": "the N = 1 reference of the scaling curve: parallel efficiency of `bench.py --gpus N` = value(N) / (N x "
+                       "scale_ref.value) — same workload per GPU, same C++ loop, same transport code; the headline `value` of "
+                       "this line is BASELINE configs[1] (static bed, no halo) and is NOT that reference"}
+    except Exception as e:  # noqa: BLE001 — the headline line must not die with this leg
+        return {"error": repr(e)}
 
 
 # ======================================================================================================== N > 1
@@ -353,9 +440,10 @@ class _Collective:
         return out
 
 
-def multi_rank_body(args, rank, world, device, coll, hub, uid, result):
+def multi_rank_body(args, rank, world, device, coll, hub, uid, result, wd=None):
     import torch
     from shpair import shapes, bed, mrank
+    wd = wd or Watchdog()
     torch.cuda.set_device(device)
     shp = [shapes.random_shape(args.lmax, bed.SEED0 + 2 + s) for s in range(args.nshapes)]
     sp = make_ctx(args, shp, device)
@@ -366,15 +454,18 @@ def multi_rank_body(args, rank, world, device, coll, hub, uid, result):
     geo = mrank.plan_geometry(grid, cfg["lo"], cfg["hi"], cfg["periodic"], cut, rank)
     xw, owner = mrank.plan_owner(geo, cfg["x"])
     mine = owner == rank
-    halo = mrank.Halo(sp, rank, world, grid, cfg["lo"], cfg["hi"], cfg["periodic"], skin, hub=hub, unique_id_bytes=uid)
+    with wd.phase("ncclCommInitRank (shhalo_create_rccl)" if uid is not None else "shhalo_create_local", args.wait_s):
+        halo = mrank.Halo(sp, rank, world, grid, cfg["lo"], cfg["hi"], cfg["periodic"], skin, hub=hub, unique_id_bytes=uid)
     dt = 1.0e-3
-    run = mrank.RankRun(sp, halo, xw[mine], cfg["quat"][mine], cfg["shtype"][mine], cfg["tag"][mine], v=cfg["v"][mine],
-                        mask=cfg["mask"][mine], dt=dt, gravity=(0.0, 0.0, -1.0), device=f"cuda:{device}",
-                        capacity=int(1.5 * mine.sum()) + 4096)
+    with wd.phase("first migration + ghost plan + list build + forces (RankRun)", args.wait_s):
+        run = mrank.RankRun(sp, halo, xw[mine], cfg["quat"][mine], cfg["shtype"][mine], cfg["tag"][mine], v=cfg["v"][mine],
+                            mask=cfg["mask"][mine], dt=dt, gravity=(0.0, 0.0, -1.0), device=f"cuda:{device}",
+                            capacity=int(1.5 * mine.sum()) + 4096)
     verify_err = None
     if args.verify:
-        t, _, _, _, f0, tq0 = run.owned()
-        parts = coll.gather(rank, (t, f0, tq0))
+        with wd.phase("gather of the initial forces (verify)", args.wait_s):
+            t, _, _, _, f0, tq0 = run.owned()
+            parts = coll.gather(rank, (t, f0, tq0))
         if rank == 0:
             from shpair.run import DeviceRun
             ref_sp = make_ctx(args, shp, device)
@@ -390,8 +481,10 @@ def multi_rank_body(args, rank, world, device, coll, hub, uid, result):
                 fg[t_] = f_
                 tg[t_] = q_
             verify_err = float(max(np.abs(fg - fr).max(), np.abs(tg - tr).max()) / np.abs(fr).max())
-            assert verify_err < 1e-9, f"decomposed forces differ from single-domain forces: {verify_err}"
+            if not verify_err < 1e-9:   # reported in the line (verify_ok) and by the exit code; the run goes on so that every rank ends together
+                print(f"bench.py: decomposed forces differ from single-domain forces: rel err {verify_err}", file=sys.stderr, flush=True)
             ref_sp.close()
+            del ref
 
     def count_contacts():
         sp.set_option("count", 1)
@@ -400,26 +493,29 @@ def multi_rank_body(args, rank, world, device, coll, hub, uid, result):
         sp.set_option("count", 0)
         return st["n_contact"], st["n_touching"]
 
-    for _ in range(max(1, (args.ramp + args.warmup) // 4)):   # clock ramp and warm-up, in chunks so that rebuilds happen too
-        run.run(4)
-    c0, t0_ = count_contacts()
+    with wd.phase("warm-up timesteps", 2 * args.wait_s):
+        for _ in range(max(1, (args.ramp + args.warmup) // 4)):   # clock ramp and warm-up, in chunks so that rebuilds happen too
+            run.run(4)
+        c0, t0_ = count_contacts()
     b0, k0 = run.builds, run.kernel_ms
     s0 = halo.stats()
-    run.sync()
-    coll.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    run.run(args.steps, timed=True)
-    torch.cuda.synchronize()
-    coll.barrier()
-    elapsed = time.perf_counter() - t0
-    c1, t1_ = count_contacts()
-    s1 = halo.stats()
-    n_end = run.n
-    mine_out = dict(elapsed=elapsed, contact=0.5 * (c0 + c1), touching=0.5 * (t0_ + t1_), kernel_ms=(run.kernel_ms - k0) / args.steps,
-                    rebuilds=run.builds - b0, migrated=s1["migrated_out"] - s0["migrated_out"], nlocal=n_end, nghost=run.nghost,
-                    npairs=run.npairs, stats=s1)
-    allr = coll.gather(rank, mine_out)
+    with wd.phase("timed timesteps", 3 * args.wait_s):
+        run.sync()
+        coll.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run.run(args.steps, timed=True)
+        torch.cuda.synchronize()
+        coll.barrier()
+        elapsed = time.perf_counter() - t0
+    with wd.phase("contact count + gather of the results", args.wait_s):
+        c1, t1_ = count_contacts()
+        s1 = halo.stats()
+        n_end = run.n
+        mine_out = dict(elapsed=elapsed, contact=0.5 * (c0 + c1), touching=0.5 * (t0_ + t1_), kernel_ms=(run.kernel_ms - k0) / args.steps,
+                        rebuilds=run.builds - b0, migrated=s1["migrated_out"] - s0["migrated_out"], nlocal=n_end, nghost=run.nghost,
+                        npairs=run.npairs, stats=s1)
+        allr = coll.gather(rank, mine_out)
     if rank == 0:
         el = max(r["elapsed"] for r in allr)
         contact_all = sum(r["contact"] for r in allr)
@@ -454,10 +550,13 @@ def multi_rank_body(args, rank, world, device, coll, hub, uid, result):
                         "ncclGroupEnd on the compute stream, one unpack kernel; no host wait except at the rebuild test",
             },
             "value_note": "contact pairs of all ranks (mean of the counts before and after the timed steps) x K / max-over-ranks time",
-            "verify_rel_err": verify_err,
+            "verify_rel_err": verify_err, "verify_ok": (None if verify_err is None else bool(verify_err < 1e-9)),
+            "verify_note": "decomposed forces and torques of the initial configuration against a single-domain compute of the "
+                           "whole bed on rank 0 (max abs difference / max |F|), untimed; bar 1e-9",
             "roofline": roof, "occupancy": occ, "valu_f64": valu,
         }
-    coll.barrier()
+    with wd.phase("final barrier", args.wait_s):
+        coll.barrier()
     halo.close()
     sp.close()
 
@@ -504,21 +603,44 @@ def main_multi(args):
             print(f"bench.py: --gpus {world} but WORLD_SIZE={wsz}; launch with torch.distributed.run (or --transport local)",
                   file=sys.stderr)
         sys.exit(2)
+    import datetime
     import torch.distributed as dist
     from shpair import mrank
+    wd = Watchdog()
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if world == 1 and "MASTER_PORT" not in os.environ:   # `--gpus 1 --multi` without a launcher
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
     if args.one_device:
         local_rank = 0
+    ndev = torch.cuda.device_count()
+    if local_rank >= ndev:
+        print(f"bench.py: rank {rank}: LOCAL_RANK {local_rank} but only {ndev} GPU(s) visible", file=sys.stderr, flush=True)
+        sys.exit(3)
     torch.cuda.set_device(local_rank)
-    dist.init_process_group("gloo", rank=rank, world_size=world)   # control plane only: id broadcast, barriers, timings
-    box = [mrank.unique_id() if rank == 0 else None]
-    dist.broadcast_object_list(box, src=0)
+    with wd.phase("gloo rendezvous (torch.distributed.init_process_group)", args.wait_s):
+        # control plane only: id broadcast, barriers, timings
+        dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=args.wait_s))
+        box = [mrank.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
     coll = _Collective(world, dist)
-    multi_rank_body(args, rank, world, local_rank, coll, None, box[0], result)
+    rc = 0
+    try:
+        multi_rank_body(args, rank, world, local_rank, coll, None, box[0], result, wd)
+    except BaseException:  # noqa: BLE001 — a rank that failed must not leave the others in a collective for ever: say why, then end
+        import traceback
+        print(f"bench.py: rank {rank} failed:\n{traceback.format_exc()}", file=sys.stderr, flush=True)
+        os._exit(1)
     if rank == 0:
         print(json.dumps(result["line"]), flush=True)
-    dist.barrier()
-    dist.destroy_process_group()
+        if result["line"].get("verify_ok") is False:
+            rc = 1
+    with wd.phase("shutdown barrier", args.wait_s):
+        dist.barrier()
+        dist.destroy_process_group()
+    sys.exit(rc)
 
 
 def cpu_baseline(args, shp, rmax, gbed, il, of, jl):
@@ -579,7 +701,7 @@ def cpu_baseline(args, shp, rmax, gbed, il, of, jl):
 
 if __name__ == "__main__":
     _args = parse()
-    if _args.gpus == 1:
+    if _args.gpus == 1 and not _args.multi:
         main_single(_args)
     else:
         main_multi(_args)

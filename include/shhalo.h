@@ -16,6 +16,14 @@
  * The plan (who sends which rows to whom, and where they land) is rebuilt on the device at every reneighbouring;
  * the same plan logic is exported as pure host functions (shhalo_plan_*) so that it can be tested without a GPU.
  *
+ * Errors across ranks: exchange / borders / run are collective calls.  Rank-local failures that are found between
+ * two exchanges — a lost atom, nmax too small for the arrivals or the ghosts, a type or shape index outside its
+ * table — are AGREED ON with one max-all-reduce of an error word before any further message is posted, so that every
+ * rank returns a non-zero code from the same call (the failing rank its own code and message, the others
+ * SHPAIR_ESTATE naming it) and none is left waiting inside ncclRecv, which has no timeout.  Any non-zero return of
+ * any rank is fatal for the communicator: destroy the contexts (a HIP or RCCL call that failed in the middle of a
+ * step — SHPAIR_EHIP — cannot be agreed on, the peers are already inside their exchanges; treat it like a lost rank).
+ *
  * Transports: RCCL (the product; librccl is bound at run time with dlopen, so a single-GPU host does not need
  * it), and an in-process hub that moves the same messages between the contexts of several host THREADS of one
  * process with device copies — for rehearsing N ranks on fewer than N GPUs (tests) and for self-periodic
@@ -118,7 +126,7 @@ typedef struct shhalo_arrays {
 /* Comm::exchange: wraps the owned rows into the periodic box, sends those that left the brick to their new owner
  * (one message per peer) and takes in the arrivals; a->nlocal is updated.  Blocks (counts are read back).
  * Fails with SHPAIR_ESTATE if an atom left the brick AND its 26 neighbours (lost atom), SHPAIR_ENOMEM if nmax is
- * too small. */
+ * too small — on EVERY rank, before any row travels (see "Errors across ranks" above). */
 int shhalo_exchange_device(shhalo_ctx *h, shhalo_arrays *a, void *stream);
 
 /* Comm::borders: selects the ghosts for all 26 directions, exchanges counts, builds the send lists on the device

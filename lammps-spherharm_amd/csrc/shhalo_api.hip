@@ -438,6 +438,31 @@ int exchange_counts(shhalo_ctx* h, int nslots, hipStream_t st)
   return SHPAIR_OK;
 }
 
+// The decision to fail is COLLECTIVE wherever a rank-local condition (a lost atom, a capacity that is too small, an
+// index outside a table) is found between two exchanges: a rank that simply returned would leave its peers inside
+// ncclRecv for rows that are never sent — RCCL has no timeout.  Every rank contributes its code (0 or -SHPAIR_E*) to
+// one max-all-reduce and all of them return an error if any did: the failing rank its own code and message, the
+// others SHPAIR_ESTATE naming the code.  One rank: nothing to agree on.
+int agree(shhalo_ctx* h, int local_rc, hipStream_t st)
+{
+  if (h->tr->size() <= 1) return local_rc;
+  const std::string mine = h->err;
+  h->h_ints[kPinFlags + 3] = local_rc ? -local_rc : 0;
+  H_HIP(h, hipMemcpyAsync(h->d_flags.p + 3, h->h_ints + kPinFlags + 3, sizeof(int), hipMemcpyHostToDevice, st));
+  H_TR(h, h->tr->allreduce_max_i32(h->d_flags.p + 3, 1, st));
+  H_HIP(h, hipMemcpyAsync(h->h_ints + kPinFlags + 3, h->d_flags.p + 3, sizeof(int), hipMemcpyDeviceToHost, st));
+  H_HIP(h, hipStreamSynchronize(st));
+  if (local_rc) {
+    h->err = mine;
+    return local_rc;
+  }
+  const int worst = h->h_ints[kPinFlags + 3];
+  if (worst > 0)
+    H_FAIL(h, SHPAIR_ESTATE, "rank %d stops because another rank failed (%s); its own state was consistent", h->geo.rank,
+           shpair_strerror(-worst));
+  return SHPAIR_OK;
+}
+
 int check_arrays(shhalo_ctx* h, const shhalo_arrays* a)
 {
   if (!a) H_FAIL(h, SHPAIR_EINVAL, "null arrays");
@@ -669,11 +694,6 @@ int shhalo_exchange_device(shhalo_ctx* h, shhalo_arrays* a, void* stream)
   }
   H_RC(h, partition_count<1>(h, h->mig_slots, n, a->x, st));
   H_RC(h, exchange_counts(h, h->mig_slots.nslots, st));
-  if (h->h_ints[kPinFlags] & kHaloErrLost) {
-    H_HIP(h, hipMemsetAsync(h->d_flags.p, 0, sizeof(int), st));
-    H_FAIL(h, SHPAIR_ESTATE, "rank %d: an owned atom left its brick and the 26 neighbouring bricks since the last exchange "
-           "(lost atom: the timestep or the skin is too large)", h->geo.rank);
-  }
   const int* tot = h->h_ints + kPinTotals;
   const int nstay = tot[0];
   int nleave = 0, narr = 0;
@@ -681,10 +701,25 @@ int shhalo_exchange_device(shhalo_ctx* h, shhalo_arrays* a, void* stream)
     nleave += tot[1 + k];
     narr += h->h_ints[kPinMsgIn + 27 * k];
   }
-  if (nstay + nleave != n) H_FAIL(h, SHPAIR_EHIP, "internal: partition of %d rows gave %d + %d", n, nstay, nleave);
+  // rank-local failures, decided by all ranks together BEFORE the rows travel (agree() above)
+  int local_rc = SHPAIR_OK;
+  char why[320] = "";
+  if (h->h_ints[kPinFlags] & kHaloErrLost) {
+    H_HIP(h, hipMemsetAsync(h->d_flags.p, 0, sizeof(int), st));
+    local_rc = SHPAIR_ESTATE;
+    snprintf(why, sizeof(why), "rank %d: an owned atom left its brick and the 26 neighbouring bricks since the last exchange "
+             "(lost atom: the timestep or the skin is too large)", h->geo.rank);
+  } else if (nstay + nleave != n) {
+    local_rc = SHPAIR_EHIP;
+    snprintf(why, sizeof(why), "internal: partition of %d rows gave %d + %d", n, nstay, nleave);
+  } else if ((long long)nstay + narr > a->nmax) {
+    local_rc = SHPAIR_ENOMEM;
+    snprintf(why, sizeof(why), "rank %d: %d owned atoms after migration exceed the capacity nmax = %d", h->geo.rank,
+             nstay + narr, a->nmax);
+  }
+  h->err = why;
+  H_RC(h, agree(h, local_rc, st));
   if (nleave == 0 && narr == 0) return SHPAIR_OK;
-  if ((long long)nstay + narr > a->nmax)
-    H_FAIL(h, SHPAIR_ENOMEM, "rank %d: %d owned atoms after migration exceed the capacity nmax = %d", h->geo.rank, nstay + narr, a->nmax);
   const HaloArrays da = dev_arrays(a);
   std::vector<Msg> sends, recvs;
   if (nleave > 0) {
@@ -752,8 +787,17 @@ int shhalo_borders_device(shhalo_ctx* h, const shhalo_arrays* a, int* nghost, vo
   if (shhalo_plan_layout(&h->geo, send_cnt, recv_cnt, &h->lay)) H_FAIL(h, SHPAIR_EINVAL, "internal: message layout");
   const shhalo_layout& L = h->lay;
   *nghost = L.nghost;
-  if ((long long)n + L.nghost > a->nmax)
-    H_FAIL(h, SHPAIR_ENOMEM, "rank %d: %d owned + %d ghost rows exceed the capacity nmax = %d", h->geo.rank, n, L.nghost, a->nmax);
+  {
+    int local_rc = SHPAIR_OK;
+    char why[256] = "";
+    if ((long long)n + L.nghost > a->nmax) {
+      local_rc = SHPAIR_ENOMEM;
+      snprintf(why, sizeof(why), "rank %d: %d owned + %d ghost rows exceed the capacity nmax = %d", h->geo.rank, n, L.nghost,
+               a->nmax);
+    }
+    h->err = why;
+    H_RC(h, agree(h, local_rc, st));   // before the ghost rows travel: every rank returns, or none
+  }
   H_HIP(h, h->d_send_idx.ensure((size_t)(L.nsend > 0 ? L.nsend : 1)));
   H_HIP(h, h->d_send_code.ensure((size_t)(L.nsend > 0 ? L.nsend : 1)));
   H_HIP(h, h->d_sendbuf.ensure((size_t)(L.nsend > 0 ? L.nsend : 1) * kBorderWidth));
@@ -949,8 +993,12 @@ int shhalo_run_device(shhalo_ctx* h, shhalo_arrays* a, const shhalo_run_params* 
         rc = shhalo_exchange_device(h, a, st);
         if (!rc) rc = shhalo_borders_device(h, a, &nghost, st);
         if (!rc) {
-          rc = shstep_neighbor_build_device(sp, a->nlocal, nghost, a->x, a->shtype, a->tag, &np, st);
-          if (rc) h->err = sp->err;
+          // the list build reports shape indices outside the table (they may have arrived with migrated atoms): a
+          // rank-local failure in the middle of the step, so the ranks agree on it before the forward exchange
+          const int lrc = shstep_neighbor_build_device(sp, a->nlocal, nghost, a->x, a->shtype, a->tag, &np, st);
+          if (lrc) h->err = sp->err;
+          else h->err.clear();
+          rc = agree(h, lrc, st);
         }
         if (rc) break;
         ++nreb;
@@ -997,6 +1045,13 @@ int shhalo_run_device(shhalo_ctx* h, shhalo_arrays* a, const shhalo_run_params* 
   if (rebuilds) *rebuilds = nreb;
   if (rc) return rc;
   if (es != hipSuccess) H_FAIL(h, SHPAIR_EHIP, "hipStreamSynchronize failed: %s", hipGetErrorString(es));
+  // the kernels' error bits (a type or shape index outside its table — such rows arrive from other ranks packed
+  // into 64-bit words — makes a kernel skip the pair / particle and raise a bit instead of reading out of bounds):
+  // read once per call, and agreed on by all ranks like the failures of a reneighbouring
+  int local_rc = shpair_check_device_errors(sp, st);
+  if (local_rc) h->err = sp->err;
+  else h->err.clear();
+  H_RC(h, agree(h, local_rc, st));
   return SHPAIR_OK;
 }
 

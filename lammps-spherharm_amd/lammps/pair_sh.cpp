@@ -302,7 +302,10 @@ void PairSH::compute(int eflag, int vflag)
     quat_is_custom = 1;
   }
   if (!quat) error->one(FLERR, "pair sh: per-atom quaternions disappeared");
-  if (quat_is_custom && atom->nghost > 0) {
+  // Collective: every rank calls it whenever the orientations live in a custom property — also a rank without
+  // ghosts (or without atoms), whose owned atoms may be ghosts of a neighbour that waits for them.  Comm handles
+  // zero-length swaps.
+  if (quat_is_custom) {
     quat_comm = quat;
 #ifdef SHPAIR_LAMMPS_OLD_API
     comm->forward_comm_pair(this);

@@ -158,7 +158,9 @@ SYMBOLS = {
 
 
 def library_path():
-    return os.path.join(_HERE, "libshpair.so")
+    """libshpair.so beside this file.  SHPAIR_LIB=<file name in this directory> selects a diagnostic build (ablation /
+    statistics libraries made by `make abl` / `make stats`) for profiling runs; there is no other fallback."""
+    return os.path.join(_HERE, os.environ.get("SHPAIR_LIB", "libshpair.so"))
 
 
 def load_library():

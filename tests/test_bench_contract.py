@@ -42,6 +42,55 @@ def test_single_gpu_line_has_the_contract_fields():
     assert d["occupancy"]["waves_per_cu"] >= 16 and d["occupancy"]["scratch_bytes"] == 0
     ts = d["timestep"]
     assert ts["timesteps_per_s"] > 0 and ts["steps"] == 10 and ts["particles"] > 15000
+    # the like-for-like N = 1 point of the scaling curve: the N > 1 workload and code path on one rank
+    sr = d["scale_ref"]
+    assert "error" not in sr, sr
+    assert sr["transport"] == "rccl" and sr["ranks_reported_by_transport"] == 1 and sr["particles"] > 120000
+    assert sr["value"] > 1e7 and sr["steps"] == 5 and "configs[3]" in sr["workload"] and sr["ghost_atoms"] > 0
+    assert abs(sr["value"] * sr["ms_per_step"] * 1e-3 - sr["contact_pairs"]) < 1e-6 * sr["contact_pairs"]
+
+
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def test_rccl_body_at_world_1_under_torch_distributed_run():
+    """The code that produces the driver's 8-GPU line — torch.distributed.run -> gloo rendezvous -> ncclGetUniqueId
+    broadcast -> ncclCommInitRank -> shhalo_run_device -> gathered JSON — run end to end as a FRESH child process with
+    one rank (grid 1x1x1, self-periodic in x and y, RCCL self-communicator): everything but the bytes between two
+    devices.  The decomposed forces are verified against a single-domain compute inside the run (verify_ok)."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--multi", "--particles", "30000",
+           "--steps", "12", "--warmup", "1", "--ramp", "3", "--peak-ms", "0"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = _last_json(r.stdout)
+    assert d["n_gpus"] == 1 and d["steps"] == 12 and d["config"]["proc_grid"] == [1, 1, 1] and d["config"]["backend"] == "rccl"
+    h = d["halo"]
+    assert h["transport"] == "rccl" and h["ranks_reported_by_transport"] == 1 and h["rccl_version"] > 20000
+    assert h["owned_atoms"] == [d["config"]["particles_all_ranks"]] and h["ghost_atoms"][0] > 0     # no atom lost
+    assert d["verify_ok"] is True and d["verify_rel_err"] < 1e-12
+    assert d["value"] > 1e6 and h["rebuilds_in_timed_steps"][0] >= 1
+    # the same without a launcher (bench.py picks its own rendezvous port)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--multi", "--particles", "8000", "--steps", "4",
+                        "--warmup", "1", "--ramp", "1", "--peak-ms", "0"], capture_output=True, text=True, timeout=600, cwd=ROOT,
+                       env={k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")})
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert _last_json(r.stdout)["halo"]["transport"] == "rccl"
+
+
+def test_a_rank_that_never_arrives_ends_the_run_with_a_message():
+    """Bounded waits: WORLD_SIZE = 2 but only rank 0 exists.  The gloo rendezvous must give up within --wait-s with a
+    message and a non-zero exit code instead of hanging (RCCL and the launcher have no timeout of their own here)."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="2", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--particles", "4000", "--steps", "2", "--wait-s", "8"],
+                       capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
+    assert r.returncode != 0
+    assert "did not finish in time" in r.stderr or "imeout" in r.stderr, r.stderr[-2000:]
 
 
 def test_multi_rank_line_rehearsed_as_rank_threads():

@@ -265,9 +265,12 @@ def test_config4_one_million_particles_eight_ranks():
 
 
 def test_rccl_self_communicator_through_the_c_abi():
-    """RCCL itself (ncclCommInitRank, grouped ncclSend/ncclRecv, ncclAllReduce) behind shhalo_create_rccl: one rank,
-    which is all a one-GPU box can hold (RCCL refuses two ranks on one device).  Periodic box: every direction leads
-    back to the rank, so the exchange is local copies; the all-reduce and the rebuild decision go through RCCL."""
+    """RCCL itself behind shhalo_create_rccl with one rank, which is all a one-GPU box can hold (RCCL refuses two ranks
+    on one device): ncclGetUniqueId, ncclCommInitRank, ncclCommCount and ncclAllReduce (thermo sums, the rebuild
+    decision) are EXECUTED.  ncclSend/ncclRecv are NOT: in a periodic box every direction leads back to the rank, the
+    blocks are copied by the pack kernels and RcclTransport::exchange returns at its empty-message early-out.  The
+    point-to-point path over RCCL (peer order, ncclChar byte counts) has never run on this pool (one GPU per box); its
+    first run is `bench.py --gpus N` with the forces verified against a single-domain compute (verify_rel_err)."""
     import torch
     from shpair import shapes, mrank
     from shpair.run import DeviceRun
@@ -394,5 +397,63 @@ def test_failure_modes_are_loud():
         return res
     out = _run_ranks(world, body)
     hub.close()
+    # the decision is collective (one max-all-reduce of an error word before any row travels): the rank that lost the
+    # atom says so, every other rank returns too — naming the failure — instead of waiting for rows that never come
     assert out[0][0] is not None and out[0][0][0] == -4 and "lost atom" in out[0][0][1]
-    assert all(o[0] is None and o[1] == o[2] for o in out[1:])       # the other ranks are untouched
+    assert all(o[0] is not None and o[0][0] == -4 and "another rank failed" in o[0][1] and o[1] == o[2] for o in out[1:])
+
+
+def test_rank_local_failure_stops_every_rank():
+    """one rank's capacity runs out at a reneighbouring inside the C++ loop.  Over RCCL the peers would
+    wait for ever inside ncclRecv for ghost rows that are never sent; the ranks therefore agree on an error word before
+    the rows travel.  Here (hub transport, whose waits time out after 120 s) both ranks must come back within seconds:
+    the short rank with SHPAIR_ENOMEM, the other with SHPAIR_ESTATE naming it.  The same for a shape index outside
+    the table that arrives in a migrated row (found by the list build)."""
+    import time
+    import torch
+    from shpair import shapes, mrank, ShPairError
+    lmax, nq, skin = 4, 8, 0.2
+    shp = [shapes.random_shape(lmax, 400 + s, amp=0.2) for s in range(2)]
+    world, grid, per = 2, (2, 1, 1), (1, 1, 1)
+    x, quat, sht, tag, lo, hi, rng = _bed(2400, per)
+    sp0 = _ctx(lmax, shp, nq)
+    cut = 2.0 * max(sp0.rmax(s) for s in range(2)) + skin
+    sp0.close()
+    xw, owner = _distribute(grid, lo, hi, per, cut, x)
+    v = 0.5 * rng.normal(size=x.shape)
+
+    for mode in ("capacity", "shape"):
+        hub = mrank.Hub(world)
+
+        def body(rank):
+            sp = _ctx(lmax, shp, nq)
+            halo = mrank.Halo(sp, rank, world, grid, lo, hi, per, skin, hub=hub)
+            mine = owner == rank
+            n = int(mine.sum())
+            run = mrank.RankRun(sp, halo, xw[mine], quat[mine], sht[mine], tag[mine], v=v[mine], dt=2e-3)
+            ng0 = run.nghost
+            if mode == "capacity" and rank == 1:
+                run.a.nmax = n + ng0 - 5          # declared capacity (the tensors are larger): short at the next reneighbouring
+            if mode == "shape" and rank == 0:
+                run.sh[:n] = torch.where(run.x[:n, 0] > float(run.x[:n, 0].max()) - 0.3, 7, run.sh[:n].long()).int()
+                torch.cuda.synchronize()
+            msg, t0 = None, time.perf_counter()
+            try:
+                for _ in range(60):
+                    run.run(5)
+            except ShPairError as err:
+                msg = (err.code, str(err))
+            el = time.perf_counter() - t0
+            halo.close()
+            sp.close()
+            return msg, el
+        out = _run_ranks(world, body)
+        hub.close()
+        assert all(o[0] is not None for o in out), (mode, out)
+        assert max(o[1] for o in out) < 60.0, (mode, out)                # nobody sat in a 120 s hub timeout
+        bad, other = (1, 0) if mode == "capacity" else (0, 1)
+        if mode == "capacity":
+            assert out[bad][0][0] == -5 and "capacity" in out[bad][0][1]
+        else:
+            assert out[bad][0][0] == -1 and "shape index" in out[bad][0][1]
+        assert out[other][0][0] == -4 and "another rank failed" in out[other][0][1]
