@@ -177,8 +177,8 @@ struct WaveLdsLayout {
 // rows whose stride is 2 mod 4 doubles: sixteen lanes reading sixteen rows with ds_read_b128 then spread over all
 // banks (a 128-byte stride, 2L + 4 = 16 at L = 6, puts every row on the same banks: the kernel ran 3x slower).
 __host__ __device__ constexpr int jpoly_row(const int L) { return ((2 * L + 4) % 4 == 2) ? 2 * L + 4 : 2 * L + 6; }
-__host__ __device__ constexpr int jpoly_trig(const int L) { return 2 * L + 1; }   // offset of cos(psi_l) in a row; sin follows
-__host__ __device__ constexpr int jpoly_glw(const int L) { return 2 * L + 3; }    // offset of the weight of ring `row index`
+__host__ __device__ constexpr int jpoly_trig(const int L) { return 2 * L + 2; }   // offset of cos(psi_l) in a row; sin follows (one 16-byte pair)
+__host__ __device__ constexpr int jpoly_glw(const int L) { return 2 * L + 1; }    // offset of the weight of ring `row index` (the odd slot behind the 2L + 1 coefficients)
 // Rows of the first-stage table PJ: (order m, part) for m = 0..L+1 — the order L + 1 is empty (zeros), see jpoly_build.
 __host__ __device__ constexpr int jpoly_rows(const int L) { return 2 * L + 4; }
 __host__ __device__ inline WaveLdsLayout wave_lds_layout(const int L, const int rows, const bool weighted = false,
@@ -240,6 +240,25 @@ __host__ __device__ inline WaveLdsLayout wave_lds_layout(const int L, const int 
   if (w.bytes < 8 * (kFrame + kRedDoubles)) w.bytes = 8 * (kFrame + kRedDoubles);
   w.bytes = (w.bytes + 15) & ~15;
   return w;
+}
+
+// 16-byte LDS reads.  Rows of the ring tables and of particle j's table are 16-byte aligned (wave_lds_layout), but the
+// compiler only knows that a double* is 8-byte aligned and reads adjacent doubles with ds_read2_b64 — two 8-byte
+// accesses per lane, serviced at HALF the rate of ds_read_b128 (128 against 256 B/clk/CU) and banked modulo 32 instead
+// of 64 dwords, where the 36-dword row stride of particle j's table (chosen for ds_read_b128) puts rows l and l + 8 on
+// the same banks.  Measured on the round-2 kernel (profiles/r03_b_lds_sites.txt): 9 LDS-array cycles per LDS
+// instruction in the node loops, 27 % of them bank conflicts, the LDS pipe 83 % busy beside an 80 % busy VALU.
+typedef double v2d __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2d lds2(const double* p) { return *(const v2d*)__builtin_assume_aligned(p, 16); }
+// experiment switches (bit mask SHP_X): 1 eval2, 2 eval, 4 phase-1 ring, 8 grad — read as two doubles instead
+#ifndef SHP_X
+#define SHP_X 0
+#endif
+template <int BIT>
+__device__ __forceinline__ v2d lds2x(const double* p)
+{
+  if constexpr ((SHP_X & BIT) != 0) { v2d r; r[0] = p[0]; r[1] = p[1]; return r; }
+  else return lds2(p);
 }
 
 __device__ __forceinline__ unsigned launder_u32(unsigned v)
@@ -689,12 +708,14 @@ __device__ __forceinline__ void ring_eval(const double* __restrict__ row, const 
       cm = tr[trig_lmajor(L) ? 2 * (m - 2) : (m - 2) * tstride];
       sm = tr[(trig_lmajor(L) ? 2 * (m - 2) : (m - 2) * tstride) + 1];
     }
-    const double A = row[4 * m], B = row[4 * m + 1];
+    const v2d ab = lds2(row + 4 * m);   // (A_km, B_km): one ds_read_b128
+    const double A = ab[0], B = ab[1];
     r = fma(A, cm, r);
     r = fma(B, sm, r);
     if (GRAD) {
-      rmu = fma(row[4 * m + 2], cm, rmu);
-      rmu = fma(row[4 * m + 3], sm, rmu);
+      const v2d dab = lds2(row + 4 * m + 2);
+      rmu = fma(dab[0], cm, rmu);
+      rmu = fma(dab[1], sm, rmu);
       const double dm = (double)m;
       rpsi = fma(dm * B, cm, rpsi);
       rpsi = fma(-dm * A, sm, rpsi);
@@ -841,13 +862,17 @@ __device__ __forceinline__ void jpoly_build(const PairParams& P, double* __restr
 template <int L>
 __device__ __forceinline__ double jpoly_eval(const double* __restrict__ row, const double mu, const double sig)
 {
-  double g = row[0];
+  // 2L + 1 coefficients in L + 1 aligned 16-byte pairs (the second half of the last pair is the ring weight)
+  v2d c[L + 1];
 #pragma unroll
-  for (int t = 1; t <= L; ++t) g = fma(g, mu, row[t]);
+  for (int t = 0; t <= L; ++t) c[t] = lds2x<2>(row + 2 * t);
+  double g = c[0][0];
+#pragma unroll
+  for (int t = 1; t <= L; ++t) g = fma(g, mu, c[t >> 1][t & 1]);
   if constexpr (L >= 1) {
-    double h = row[L + 1];
+    double h = c[(L + 1) >> 1][(L + 1) & 1];
 #pragma unroll
-    for (int t = L + 2; t <= 2 * L; ++t) h = fma(h, mu, row[t]);
+    for (int t = L + 2; t <= 2 * L; ++t) h = fma(h, mu, c[t >> 1][t & 1]);
     g = fma(sig, h, g);
   }
   return g;
@@ -864,9 +889,10 @@ __device__ __forceinline__ void ring_grad_rec(const double* __restrict__ row, co
   double cm = c1, sm = s1;
 #pragma unroll
   for (int m = 1; m <= L; ++m) {
-    const double A = row[4 * m], B = row[4 * m + 1], dm = (double)m;
-    rmu = fma(row[4 * m + 2], cm, rmu);
-    rmu = fma(row[4 * m + 3], sm, rmu);
+    const v2d ab = lds2x<8>(row + 4 * m), dab = lds2x<8>(row + 4 * m + 2);   // two ds_read_b128 per order
+    const double A = ab[0], B = ab[1], dm = (double)m;
+    rmu = fma(dab[0], cm, rmu);
+    rmu = fma(dab[1], sm, rmu);
     rpsi = fma(dm * B, cm, rpsi);
     rpsi = fma(-dm * A, sm, rpsi);
     if (m < L) {
@@ -882,20 +908,23 @@ template <int L>
 __device__ __forceinline__ void jpoly_eval2(const double* __restrict__ row, const double mua, const double siga,
                                             const double mub, const double sigb, double& ra, double& rb)
 {
-  const double c0 = row[0];
+  v2d cc[L + 1];
+#pragma unroll
+  for (int t = 0; t <= L; ++t) cc[t] = lds2x<1>(row + 2 * t);
+  const double c0 = cc[0][0];
   double ga = c0, gb = c0;
 #pragma unroll
   for (int t = 1; t <= L; ++t) {
-    const double c = row[t];
+    const double c = cc[t >> 1][t & 1];
     ga = fma(ga, mua, c);
     gb = fma(gb, mub, c);
   }
   if constexpr (L >= 1) {
-    const double h0 = row[L + 1];
+    const double h0 = cc[(L + 1) >> 1][(L + 1) & 1];
     double ha = h0, hb = h0;
 #pragma unroll
     for (int t = L + 2; t <= 2 * L; ++t) {
-      const double c = row[t];
+      const double c = cc[t >> 1][t & 1];
       ha = fma(ha, mua, c);
       hb = fma(hb, mub, c);
     }
@@ -1062,10 +1091,6 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
   double wg1 = 0.0, wg2 = 0.0, wri1 = 0.0, wrj1 = 0.0;  // WEIGHTED: residuals of slabs t-1, t-2; r_i, r_j of slab t-1
   bool win1 = false;
   const bool aligned = (npsi <= 64) && ((64 % npsi) == 0);  // wave-uniform
-  // the second node of a lane's pair waits here while a full batch is drained (the queue holds 128)
-  bool pend = false, pend_in = false;   // pend: wave-uniform
-  int pend_p = 0;
-  double pend_ri = 0.0, pend_rj = 0.0;
 
   // Ring groups: the tables of P.ring_rows consecutive rings are resident at a time (all nq of
   // them unless that would starve the CU of waves); the queue is drained at the end of a group.
@@ -1210,10 +1235,13 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
       win1 = in0;
     }
     } else if constexpr (JP) {
-    // queue append of one node per lane flagged `in` (ballot + prefix count)
-#define SHP_PUSH(in, pn, rin_, rjn_)                                                                                  \
+    // Queue append of the lanes flagged `in` (mask m_, prefix count).  A slab of node pairs may bring up to 128 inside
+    // nodes to a queue that holds 128: when the two halves do not both fit (qcount + n_a + n_b > 128 — more than 64
+    // inside nodes in one slab, i.e. a deeply overlapping pair; rare), the slab is NOT consumed: what is queued is
+    // drained as a (short) batch first and the slab is classified again with the queue empty.  (Until round 3 the
+    // second half waited in five registers that were live through phase 2, which the kernel does not have.)
+#define SHP_PUSH(in, m_, pn, rin_, rjn_)                                                                              \
     {                                                                                                                  \
-      const unsigned long long m_ = __ballot(in);                                                                      \
       if (m_ != 0ULL) {                                                                                                \
         if (in) {                                                                                                      \
           const int pos_ = (qhead + qcount + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m_ >> 32),                      \
@@ -1226,29 +1254,27 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
         qcount += __builtin_popcountll(m_);                                                                            \
       }                                                                                                                \
     }
-    if (pend) {   // wave-uniform
-      SHP_PUSH(pend_in, pend_p, pend_ri, pend_rj);
-      pend = false;
-    }
     while (qcount < 64 && slab < slab_end) {
       fr = SHP_LDS();
       const int pp = (slab << 6) + lane;   // node pair: ring k, azimuths l and l + n_q
-      ++slab;
       const bool valid = pp < nq * nq;
       const int k = valid ? (int)(((unsigned)pp * magicr) >> 24) : 0;
       const int l = valid ? pp - k * nq : 0;
       const double* row = fr + W.ring + (k - k0) * rowlen;
-      const double mu = row[1], sig = row[3];
+      const v2d r01 = lds2x<16>(row);   // (A_k0, mu_k)
+      const double mu = r01[1], sig = row[3];
       // r_i at the two azimuths: psi + pi changes the sign of the odd orders
       // cos/sin(m psi_l): the first order from the lane's row of particle j's table, the rest by angle addition
       const double* gr = fr + W.gh + l * jpoly_row(LJ);
-      double re = row[0], ro = 0.0;
+      double re = r01[0], ro = 0.0;
       if constexpr (LJ >= 1) {
-        const double c1 = gr[jpoly_trig(LJ)], s1 = gr[jpoly_trig(LJ) + 1];
+        const v2d cs1 = lds2x<32>(gr + jpoly_trig(LJ));
+        const double c1 = cs1[0], s1 = cs1[1];
         double cm = c1, sm = s1;
 #pragma unroll
         for (int m = 1; m <= LJ; ++m) {
-          const double A = row[4 * m], B = row[4 * m + 1];
+          const v2d ab = lds2x<4>(row + 4 * m);
+          const double A = ab[0], B = ab[1];
           if (m & 1) ro = fma(A, cm, fma(B, sm, ro));
           else re = fma(A, cm, fma(B, sm, re));
           if (m < LJ) {
@@ -1264,13 +1290,13 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
       const double qb0 = fma(rib, mu, -rho), qb1 = -rib * sig;
       const double sa2 = fma(qa0, qa0, qa1 * qa1), sb2 = fma(qb0, qb0, qb1 * qb1);
       const bool canda = valid && (sa2 < rj2), candb = valid && (sb2 < rj2);
+      if (!__any(canda || candb)) {   // wave-uniform: all 128 nodes miss B_j
 #ifdef SHP_STATS   // a slab of this family is 128 nodes: counted as two, so that the counters compare across families
-      if (lane == 0) atomicAdd(&P.dbg[0], 2ULL);
-      if (canda) atomicAdd(&P.dbg[1], 1ULL);
-      if (candb) atomicAdd(&P.dbg[1], 1ULL);
-      { const bool a_ = __any(canda || candb); if (lane == 0 && a_) atomicAdd(&P.dbg[2], 2ULL); }
+        if (lane == 0) atomicAdd(&P.dbg[0], 2ULL);
 #endif
-      if (!__any(canda || candb)) continue;   // wave-uniform: all 128 nodes miss B_j
+        ++slab;
+        continue;
+      }
       const bool za = !(sa2 > 0.0), zb = !(sb2 > 0.0);
       const double inva = rsqrt_nr1(fmax(sa2, 1e-300)), invb = rsqrt_nr1(fmax(sb2, 1e-300));
       double rjae, rjbe;   // one pass over the lane's row of particle j's table serves both nodes
@@ -1279,20 +1305,19 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
       const double rja = za ? Rjl : rjae, rjb = zb ? Rjl : rjbe;
       const bool ina = canda && (za || sa2 * inva < rja), inb = candb && (zb || sb2 * invb < rjb);
       const int pa = k * npsi + l;
+      const unsigned long long ma = __ballot(ina), mb = __ballot(inb);
+      if (qcount + __builtin_popcountll(ma) + __builtin_popcountll(mb) > kQueue) break;   // wave-uniform; qcount > 0 here
 #ifdef SHP_STATS
+      if (lane == 0) atomicAdd(&P.dbg[0], 2ULL);
+      if (canda) atomicAdd(&P.dbg[1], 1ULL);
+      if (candb) atomicAdd(&P.dbg[1], 1ULL);
+      if (lane == 0) atomicAdd(&P.dbg[2], 2ULL);
       if (ina) atomicAdd(&P.dbg[3], 1ULL);
       if (inb) atomicAdd(&P.dbg[3], 1ULL);
 #endif
-      SHP_PUSH(ina, pa, ria, rja);
-      if (qcount >= 64) {   // wave-uniform: a batch is ready; the second nodes wait in registers
-        pend = __any(inb);
-        pend_in = inb;
-        pend_p = pa + nq;
-        pend_ri = rib;
-        pend_rj = rjb;
-        break;
-      }
-      SHP_PUSH(inb, pa + nq, rib, rjb);
+      ++slab;
+      SHP_PUSH(ina, ma, pa, ria, rja);
+      SHP_PUSH(inb, mb, pa + nq, rib, rjb);
     }
 #undef SHP_PUSH
     } else {
@@ -1348,8 +1373,7 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
       qcount += __builtin_popcountll(m);
     }
     }
-    if (qcount == 0 && !pend) break;
-    if (qcount == 0) continue;   // only the waiting second nodes are left: queue them
+    if (qcount == 0) break;   // the group's slabs are classified and its queue is drained
 #if defined(SHP_ABL) && SHP_ABL == 3   // timing-only build: phase 1 only, the queue is discarded
     qhead = (qhead + qcount) & (kQueue - 1);
     qcount = 0;
@@ -1548,8 +1572,9 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
       const double sg = (l >= nq) ? -1.0 : 1.0;
       const double* tg = fr + W.gh + (l >= nq ? l - nq : l) * jpoly_row(LJ) + jpoly_trig(LJ);
       if constexpr (LJ >= 1) {
-        c1 = sg * tg[0];
-        s1 = sg * tg[1];
+        const v2d cs1 = lds2x<64>(tg);
+        c1 = sg * cs1[0];
+        s1 = sg * cs1[1];
       }
       ring_grad_rec<LJ>(fr + W.ring + (k - k0) * rowlen, c1, s1, rmu, rpsi);
       (void)r2;
