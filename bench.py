@@ -52,9 +52,10 @@ def flops_per_pair(lmax, nq):
     return (60 + 6 * lmax + 9 * T) * 2 * nq * nq
 
 
-def pmc_traffic(args, family=0):
-    """(bytes per launch, source) of the HBM-side traffic measured with rocprofv3 PMC passes for this exact workload
-    and kernel variant, or (None, reason).  A static table: counters cannot be read from inside the timed run."""
+def pmc_entry(args, family=0):
+    """(entry, source) of profiles/pmc_traffic.json for this exact workload and kernel family, or (None, reason): HBM-side
+    bytes per launch and utilisation figures measured with rocprofv3 PMC passes (tools/pmc_run.sh, tools/pmc_table.py).
+    A static table: counters cannot be read from inside the timed run."""
     path = os.path.join("profiles", "pmc_traffic.json")
     key = f"{args.particles}:{args.lmax}:{args.nq}:{args.nshapes}:{args.exponent:g}:{args.rule}"
     if family == 1:   # the table's plain keys are the body-frame kernels
@@ -66,7 +67,7 @@ def pmc_traffic(args, family=0):
     if key not in tab:
         return None, f"no PMC measurement of workload {key} in {path}"
     e = tab[key]
-    return e["traffic_bytes"], f"{path}[{key}] (static; rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, {e.get('files', '')})"
+    return e, f"{path}[{key}] (static; separate rocprofv3 --pmc passes, {e.get('files', '')})"
 
 
 def parse():
@@ -175,13 +176,18 @@ def roofline_objects(args, sp, n_contact, kernel_ms, world):
                else "pair_setup_kernel + pair_contact_kernel")
     achieved_gbs = BYTES_PER_PAIR * n_contact / (kernel_ms * 1e-3) / 1e9
     achieved_tf = fpp * n_contact / (kernel_ms * 1e-3) / 1e12
-    traffic, src = pmc_traffic(args, fam) if world == 1 else (None, "N > 1: not measured")
+    ent, src = pmc_entry(args, fam) if (world == 1 and not getattr(args, "multi", False)) else (None, "N > 1 workload: not measured")
+    traffic = ent["traffic_bytes"] if ent else None
     peak_meas = None
     if args.peak_ms > 0:
         peak_meas = sp.fp64_peak(0, args.peak_ms)[0]
     roof = {
         "bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved_gbs / HBM_PEAK_GBS,
         "traffic": traffic, "traffic_source": src,
+        "traffic_all_pair_kernels": (ent.get("traffic_all_pair_kernels_bytes") if ent else None),
+        "traffic_note": "traffic = pair_contact_kernel alone (the dominant kernel); traffic_all_pair_kernels adds the set-up and "
+                        "rotation kernels that kernel_ms also covers (pair records and rotated coefficient vectors: a deliberate "
+                        "trade of HBM bytes for VALU instructions, DESIGN.md 4.5)",
         "kernel": "pair_contact_kernel", "kernels_timed": kernels, "kernel_ms": kernel_ms, "bytes_per_pair": BYTES_PER_PAIR,
         "pairs_per_launch": int(n_contact), "algorithmic_bytes_per_launch": BYTES_PER_PAIR * int(n_contact),
         "note": "north_star asks for the HBM fraction; the kernel is FP64-VALU bound (see valu_f64)",
@@ -190,7 +196,10 @@ def roofline_objects(args, sp, n_contact, kernel_ms, world):
         "bound": "valu_f64", "achieved": achieved_tf, "peak": F64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
         "frac": achieved_tf / F64_VALU_PEAK_TFLOPS, "peak_measured": peak_meas,
         "frac_of_measured": (achieved_tf / peak_meas) if peak_meas else None, "flop_per_pair": fpp,
-        "note": "algorithmic FLOP (SURVEY §8d formula) / kernel time. peak = spec; peak_measured = independent v_fma_f64 "
+        "note": "naive-algorithm FLOP (SURVEY §8d formula: every cap node evaluated with the full expansion) / kernel time / "
+                "peak: a SPEED RATIO against that algorithm at the FP64 peak, not a utilisation — the kernels execute a "
+                "different, cheaper algorithm (DESIGN.md 4.3, 4.7), so it can exceed 1; executed work is in `utilisation`. "
+                "peak = spec; peak_measured = independent v_fma_f64 "
                 "chains on every SIMD of this box, run beside the bench (shpair_fp64_peak). No MFMA: measured on MI355X, "
                 "v_mfma_f64 and v_fma_f64 share one FP64 datapath (side by side they add up to the single-pipe rate, "
                 "profiles/r02_a_fp64_peak.json)",
@@ -198,7 +207,21 @@ def roofline_objects(args, sp, n_contact, kernel_ms, world):
     occ = dict(sp.kernel_info(), note="static footprint of pair_contact_kernel as launched: one wave = one pair = one "
                "workgroup; waves_per_cu = min(4 x VGPR limit, LDS limit) of a gfx950 CU; family 1 = neighbour radius from "
                "per-azimuth polynomials in the pair's common frame (DESIGN.md 4.7), 0 = body-frame Horner evaluation")
-    return roof, valu, occ
+    util = {"source": src}
+    if ent:
+        for k in ("valu_busy", "lds_busy", "lds_bank_conflict_share", "fp64_instr_share", "int32_instr_share", "valu_instr_per_pair",
+                  "fp64_flop_per_pair_executed", "kernel_ms_of_the_profiled_run"):
+            util[k] = ent.get(k)
+        if ent.get("fp64_flop_per_pair_executed"):
+            ex = ent["fp64_flop_per_pair_executed"] * n_contact / (kernel_ms * 1e-3) / 1e12
+            util["fp64_executed_tflops"] = ex
+            util["fp64_executed_frac_of_peak"] = ex / F64_VALU_PEAK_TFLOPS
+        util["note"] = ("pair_contact_kernel, from PMC passes of this workload (static table): valu_busy = SQ_ACTIVE_INST_VALU x 4 / "
+                        "(GRBM_GUI_ACTIVE / 8 x 1024 SIMDs); lds_busy = SQ_LDS_IDX_ACTIVE / (GRBM_GUI_ACTIVE / 8 x 256 CUs); "
+                        "lds_bank_conflict_share = SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE; fp64_instr_share = FP64 FMA + MUL + ADD + "
+                        "TRANS instructions / SQ_INSTS_VALU; fp64_executed_* = executed FP64 FLOP (FMA = 2) per pair x pairs / this "
+                        "run's kernel time")
+    return roof, valu, occ, util
 
 
 # ======================================================================================================== N = 1
@@ -273,7 +296,7 @@ def main_single(args):
     fh = f[:nlocal].cpu().numpy()
     assert np.all(np.isfinite(fh)) and np.abs(fh).max() > 0
 
-    roof, valu, occ = roofline_objects(args, sp, n_contact, kernel_ms, 1)
+    roof, valu, occ, util = roofline_objects(args, sp, n_contact, kernel_ms, 1)
     out = {
         "metric": "contact_pairs_per_sec", "value": n_contact * args.steps / elapsed, "unit": "contact-pairs/s",
         "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ramp_passes": args.ramp,
@@ -293,7 +316,7 @@ def main_single(args):
         "timestep_note": "one step = initial_integrate + clear + pair compute + final_integrate, "
                          f"dt = {dt:g} from rest, no list rebuild inside the timed steps (see the `timestep` object for whole "
                          "steps with rebuilds)",
-        "roofline": roof, "occupancy": occ, "valu_f64": valu,
+        "roofline": roof, "occupancy": occ, "valu_f64": valu, "utilisation": util,
     }
     if args.ts_steps > 0:
         out["timestep"] = timestep_leg(args, shp)
@@ -520,7 +543,7 @@ def multi_rank_body(args, rank, world, device, coll, hub, uid, result, wd=None):
         el = max(r["elapsed"] for r in allr)
         contact_all = sum(r["contact"] for r in allr)
         assert sum(r["nlocal"] for r in allr) == cfg["n"], "atoms lost"
-        roof, valu, occ = roofline_objects(args, sp, allr[0]["contact"], allr[0]["kernel_ms"], world)
+        roof, valu, occ, util = roofline_objects(args, sp, allr[0]["contact"], allr[0]["kernel_ms"], world)
         st = allr[0]["stats"]
         result["line"] = {
             "metric": "contact_pairs_per_sec", "value": contact_all * args.steps / el, "unit": "contact-pairs/s",
@@ -553,7 +576,7 @@ def multi_rank_body(args, rank, world, device, coll, hub, uid, result, wd=None):
             "verify_rel_err": verify_err, "verify_ok": (None if verify_err is None else bool(verify_err < 1e-9)),
             "verify_note": "decomposed forces and torques of the initial configuration against a single-domain compute of the "
                            "whole bed on rank 0 (max abs difference / max |F|), untimed; bar 1e-9",
-            "roofline": roof, "occupancy": occ, "valu_f64": valu,
+            "roofline": roof, "occupancy": occ, "valu_f64": valu, "utilisation": util,
         }
     with wd.phase("final barrier", args.wait_s):
         coll.barrier()

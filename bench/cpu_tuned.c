@@ -189,6 +189,7 @@ static int tpair(const tshape *si, const tshape *sj, const double xi[3], const d
   const double d[3] = {xj[0] - xi[0], xj[1] - xi[1], xj[2] - xi[2]};
   const double rho2 = d[0] * d[0] + d[1] * d[1] + d[2] * d[2], rho = sqrt(rho2);
   if (rho >= Ri + Rj) return 0;
+  if (!(rho > 0.0)) return 0;   /* docs/SPEC.md §2 step 1: coincident centres (no line of centres): nothing */
   double cosa;
   if (rho <= Rj) cosa = -1.0;
   else if (rho2 - Rj * Rj <= Ri * Ri) cosa = sqrt(rho2 - Rj * Rj) / rho;

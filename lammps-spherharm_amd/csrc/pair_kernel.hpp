@@ -109,6 +109,7 @@ struct PairParams {
 constexpr int kMaxWavesPerBlock = 4;
 constexpr int kPairErrShape = 1;  // a shape index outside [0, nshapes) reached the kernel: the pair was skipped
 constexpr int kPairErrType = 2;   // an atom type outside [1, ntypes]
+constexpr int kPairErrCoincident = 4;   // two centres coincide (rho = 0) or their separation is not a number: SPEC §2 step 1
 // Waves per SIMD the register allocator must leave room for, chosen per kernel so that NO kernel spills a vector
 // register or touches scratch (tests/test_kernel_resources.py reads the code objects):
 //   forces-only kernels (no root finder) fit 80 VGPRs = 6 waves up to L = 6;

@@ -89,6 +89,12 @@ __device__ __forceinline__ void pair_setup_one(const PairParams& P, const int w,
     ri[3] = 0;
     return;
   }
+  if (!(rho > 0.0)) {   // SPEC §2 step 1: coincident centres (or a separation that is not a number): no line of centres,
+    atomicOr(P.err, kPairErrCoincident);   // the pair contributes nothing and is reported
+    ri[0] = 0;
+    ri[3] = 0;
+    return;
+  }
   // the force law's operands, for the contact kernel's epilogue (read from its frame: looked up there they are a chain
   // of three dependent table loads — pair_i/j -> type -> kn — at the end of every pair, while the wave still holds
   // all its registers and LDS)

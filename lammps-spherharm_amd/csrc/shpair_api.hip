@@ -185,7 +185,9 @@ int shpair_set_shape(shpair_ctx* c, int ishape, int lmax, const double* anm, dou
   // the maximum between the samples is found by a local search from the best nodes, and a radius below it is refused.
   const double rtrue = refined_max_radius(lmax, anm);
   const double rdef = default_rmax(lmax, anm);
-  if (rmax > 0.0 && rmax < rtrue)
+  // rtrue is itself a rounded host evaluation: an exactly tight user bound (a sphere's a00 / sqrt(4 pi), say) may land an
+  // ulp below it, and a shortfall of 1e-12 relative cannot drop a contact
+  if (rmax > 0.0 && rmax < rtrue * (1.0 - 1e-12))
     CTX_FAIL(c, SHPAIR_EINVAL, "shape %d: the bounding radius %.17g is below the shape's largest radius %.17g", ishape, rmax, rtrue);
   if (!(rmax > 0.0) && rdef < rtrue)
     CTX_FAIL(c, SHPAIR_EINVAL, "shape %d: the default bounding radius %.17g (1.01 x the sampled maximum) is below the largest "
@@ -561,8 +563,11 @@ int shpair_check_device_errors(shpair_ctx* c, void* stream)
   if (*c->h_err) {
     const int bits = *c->h_err;
     HIPCHK(c, hipMemsetAsync(c->d_err.p, 0, sizeof(int), st));
-    CTX_FAIL(c, SHPAIR_EINVAL, "an atom %s outside its table reached the pair kernel; the pairs of those atoms were skipped",
-             (bits & kPairErrShape) ? "shape index (shtype)" : "type");
+    if (bits & (kPairErrShape | kPairErrType))
+      CTX_FAIL(c, SHPAIR_EINVAL, "an atom %s outside its table reached the pair kernel; the pairs of those atoms were skipped",
+               (bits & kPairErrShape) ? "shape index (shtype)" : "type");
+    CTX_FAIL(c, SHPAIR_EINVAL, "coincident centres: a listed pair has separation 0 (or a position that is not a number); it was "
+             "skipped (docs/SPEC.md 2, step 1)");
   }
   return SHPAIR_OK;
 }
@@ -811,8 +816,11 @@ int shpair_compute(shpair_ctx* c, int nlocal, int nghost, const double* x, const
   if (*c->h_err) {
     const int bits = *c->h_err;
     HIPCHK(c, hipMemsetAsync(c->d_err.p, 0, sizeof(int), st));
-    CTX_FAIL(c, SHPAIR_EINVAL, "an atom %s outside its table reached the pair kernel (those pairs were skipped): types or shape "
-             "indices changed without a new neighbour list?", (bits & kPairErrShape) ? "shape index" : "type");
+    if (bits & (kPairErrShape | kPairErrType))
+      CTX_FAIL(c, SHPAIR_EINVAL, "an atom %s outside its table reached the pair kernel (those pairs were skipped): types or shape "
+               "indices changed without a new neighbour list?", (bits & kPairErrShape) ? "shape index" : "type");
+    CTX_FAIL(c, SHPAIR_EINVAL, "coincident centres: a listed pair has separation 0 (or a position that is not a number); it was "
+             "skipped (docs/SPEC.md 2, step 1)");
   }
   if (eflag) *eng_vdwl += c->h_ev[0];
   if (vflag)

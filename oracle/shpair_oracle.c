@@ -221,6 +221,7 @@ int sho_pair(int Li, const double *anmi, double Ri, int Lj, const double *anmj, 
   const double d[3] = { xj[0] - xi[0], xj[1] - xi[1], xj[2] - xi[2] };
   const double rho2 = dot3(d, d), rho = sqrt(rho2);
   if (rho >= Ri + Rj) return 0;
+  if (!(rho > 0.0)) return 0;   /* docs/SPEC.md §2 step 1: coincident centres (no line of centres): nothing */
 
   double cosa;
   if (rho <= Rj) cosa = -1.0;
@@ -310,6 +311,7 @@ static int sho_pair_weighted(int Li, const double *anmi, double Ri, int Lj, cons
   const double d[3] = { xj[0] - xi[0], xj[1] - xi[1], xj[2] - xi[2] };
   const double rho2 = dot3(d, d), rho = sqrt(rho2);
   if (rho >= Ri + Rj) return 0;
+  if (!(rho > 0.0)) return 0;   /* docs/SPEC.md §2 step 1: coincident centres (no line of centres): nothing */
   double cosa;
   if (rho <= Rj) cosa = -1.0;
   else if (rho2 - Rj * Rj <= Ri * Ri) cosa = sqrt(rho2 - Rj * Rj) / rho;

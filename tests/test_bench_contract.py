@@ -33,7 +33,8 @@ def test_single_gpu_line_has_the_contract_fields():
     assert "workload" in d["config"] and "model" not in d["config"]
     rf = d["roofline"]
     assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
-    assert "traffic" in rf and rf["traffic_source"]
+    assert "traffic" in rf and rf["traffic_source"] and "traffic_all_pair_kernels" in rf
+    assert "speed ratio" in d["valu_f64"]["note"].lower() and "source" in d["utilisation"]
     vf = d["valu_f64"]
     assert 60.0 < vf["peak_measured"] < 80.0 and abs(vf["frac_of_measured"] - vf["achieved"] / vf["peak_measured"]) < 1e-12
     assert abs(d["value"] * d["ms_per_step"] * 1e-3 - d["config"]["contact_pairs_all_ranks"]) < 1e-6 * d["config"]["contact_pairs_all_ranks"]

@@ -75,6 +75,21 @@ def test_separated_and_barely_bounding_pairs_are_exact_zero(oracle):
     assert hit == 1 and not out.any() and np.all(np.isfinite(out))
 
 
+def test_coincident_centres_contribute_nothing(oracle):
+    """docs/SPEC.md 2, step 1: rho = 0 (or a separation that is not a number) has no line of centres; the pair is not a
+    contact pair and contributes exact zeros (both rules) instead of 0/0."""
+    a = shapes.random_shape(6, 3)
+    rm = oracle.shape_rmax(6, a)
+    for rule in ("sharp", "weighted"):
+        oracle.set_rule(rule)
+        try:
+            for xj in ([0.0, 0.0, 0.0], [np.nan, 0.0, 0.0]):
+                hit, out, _ = oracle.pair(6, a, rm, 6, a, rm, [0, 0, 0], Q0, xj, Q0, 12)
+                assert hit == 0 and not out.any()
+        finally:
+            oracle.set_rule("sharp")
+
+
 def test_translation_invariance(oracle):
     a, b = shapes.random_shape(6, 3, amp=0.3), shapes.random_shape(4, 4, amp=0.3)
     ra, rb = oracle.shape_rmax(6, a), oracle.shape_rmax(4, b)
