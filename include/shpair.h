@@ -140,7 +140,10 @@ int shpair_compute_device(shpair_ctx *ctx, int nlocal, int nghost, const double 
  * override the number of quadrature rings whose tables are LDS resident at a time; tuning), "jpoly" (which kernel
  * family evaluates the neighbour's radius for the compiled orders lmax <= 12, sharp rule: 1 = per-azimuth
  * polynomials in the pair's common frame, 0 = body-frame Horner evaluation, -1 (default) = whichever the library's
- * measured rule picks for (lmax, nq); same results to rounding, ~1e-14 relative); diagnostics: "jpoly_rot" (1: the
+ * measured rule picks for (lmax, nq); same results to rounding, ~1e-14 relative), "split" (1: two waves per pair — the
+ * pair's tables are shared by a 128-lane workgroup, each wave integrates half of the azimuths — for the "jpoly" family
+ * at lmax >= 7 and even nq; 0: one wave per pair; -1 (default): two where one wave's private tables would leave a CU
+ * fewer than 16 waves); diagnostics: "jpoly_rot" (1: the
  * rotations of the "jpoly" family by a wave per rotation instead of a lane per rotation), "lds_pad" (unused LDS bytes
  * added to every wave of the contact kernel: fewer resident waves, for occupancy experiments). */
 int shpair_set_option(shpair_ctx *ctx, const char *key, int value);
@@ -157,6 +160,8 @@ typedef struct shpair_kernel_info {
   int waves_per_cu;           /* min(4 x waves_per_simd_vgpr, waves_per_cu_lds) */
   int family;                 /* 0: particle j evaluated in its body frame (Horner, scalar-fed coefficients);
                                  1: from per-azimuth polynomials in the pair's common frame (option "jpoly") */
+  int waves_per_pair;         /* 1: one wave = one pair = one workgroup; 2: two waves share a pair's tables (option
+                                 "split"); lds_bytes_per_wave is then the pair's LDS / 2 */
 } shpair_kernel_info;
 int shpair_get_kernel_info(shpair_ctx *ctx, shpair_kernel_info *out);
 

@@ -77,6 +77,7 @@ struct PairParams {
                          // particles (which 0: i, 1: j), written by pair_rotate_kernel
   int rot_by_wave;       // 1: pair_rotate_kernel (a wave per rotation) instead of pair_rotate_lane_kernel (diagnostic)
   int jpoly;             // 1: the pair records carry the Euler angles of j's frame in the slots of FR_BJ1 / FR_BJ2
+  int split;             // 1: two waves per pair (pair_contact_kernel<..., WPP = 2>); wave_lds_bytes is then the PAIR's LDS
   // per-pair records written by pair_setup_kernel (pair_setup.hpp), read here instead of redoing the scalar set-up on
   // 64 lanes: rec[kRecStride * w] = the pair frame FR_* and the Euler cos/sin; rec_i[4 w] = status, shape i, shape j,
   // [rho < R_j]
@@ -171,6 +172,7 @@ struct WaveLdsLayout {
   int pj, gh;                                    // particle j's polynomials: first-stage scratch, per-azimuth table
   int glw;                                       // JPT kernels: the Gauss-Legendre weights (nqj doubles)
   int park;                                      // JPT kernels: 2 x 64 parked sums + 64 prefetched Gauss nodes (over the queue)
+  int qstride;                                   // two waves per pair: doubles between the waves' private queue regions
 };
 // Row of the per-azimuth table: G_l (L + 1 coefficients, descending powers), H_l (L), cos(psi_l), sin(psi_l) (the
 // higher orders follow by the angle-addition recurrence where r_i is evaluated), the Gauss-Legendre weight of the
@@ -240,6 +242,36 @@ __host__ __device__ inline WaveLdsLayout wave_lds_layout(const int L, const int 
   // the epilogue's reduction scratch lies behind the frame, over everything that is dead by then
   if (w.bytes < 8 * (kFrame + kRedDoubles)) w.bytes = 8 * (kFrame + kRedDoubles);
   w.bytes = (w.bytes + 15) & ~15;
+  w.qstride = 0;
+  return w;
+}
+constexpr int kRedPerWave = (7 * kRedStride + 56 + 7 + 6 + 1) & ~1;   // epilogue scratch of one wave, even
+__host__ __device__ inline WaveLdsLayout pair_lds_layout2(const int L, const int rows, const int nq)
+{
+  WaveLdsLayout w;
+  const int ns = (L + 1) * (L + 1);
+  w.trig = w.v1 = w.qw = w.coef = 0;   // not used by the JPT kernels
+  w.v0 = kFrame;
+  w.ring = w.v0 + ns;
+  w.ring += w.ring & 1;
+  int ringsz = 4 * rows * (L + 1);
+  if (ringsz < jpoly_rows(L) * (L + 1) + 2) ringsz = jpoly_rows(L) * (L + 1) + 2;
+  ringsz += ringsz & 1;
+  w.pj = w.ring;
+  w.gh = w.ring + ringsz;
+  w.glw = w.gh + jpoly_glw(L);
+  int shared_end = w.gh + nq * jpoly_row(L);
+  // the epilogue's scratch (one block per wave) lies over everything behind the frame, the queues included: wave 0's
+  // from the frame on, wave 1's at the end of the pair's LDS
+  const int qs = 2 * kQueue + kQueue / 4;
+  if (shared_end + 2 * qs < kFrame + 2 * kRedPerWave) shared_end = kFrame + 2 * kRedPerWave - 2 * qs;
+  shared_end += shared_end & 1;
+  w.qri = shared_end;
+  w.qrj = w.qri + kQueue;
+  w.qp = w.qrj + kQueue;
+  w.park = w.qri;                          // 2 x 64 parked sums while the ring rows are built (the queue is empty then)
+  w.qstride = 2 * kQueue + kQueue / 4;     // 288
+  w.bytes = (8 * (shared_end + 2 * w.qstride) + 15) & ~15;
   return w;
 }
 
@@ -261,6 +293,16 @@ __device__ __forceinline__ v2d lds2x(const double* p)
   if constexpr ((SHP_X & BIT) != 0) { v2d r; r[0] = p[0]; r[1] = p[1]; return r; }
   else return lds2(p);
 }
+
+// TWO WAVES PER PAIR (template parameter WPP = 2 of pair_contact_kernel; JPT kernels): the workgroup is one pair, the
+// tables — frame, particle i's rotated vector, the ring rows, particle j's per-azimuth polynomials — are shared and
+// built by all 128 lanes, each wave classifies and integrates HALF of the azimuths (wave h the node pairs l, l + n_q
+// with h n_q / 2 <= l < (h + 1) n_q / 2) with a node queue of its own.  For the orders and rules where one wave's
+// private copy of the tables leaves a CU too few waves: L = 12, n_q = 32 needs 14.6 KB per one-wave pair (11 waves per
+// CU, VALU 66 % busy, profiles/r03_e_L12_pmc.txt), 17.3 KB per two-wave pair (18 waves' worth; the registers allow 16).
+//   frame | v0 (particle i; stays for the ring groups) | ring rows (first: first stage of j's table) | j's table |
+//   [epilogue scratch of both waves over everything behind the frame] | queue of wave 0 | queue of wave 1
+__host__ __device__ inline WaveLdsLayout pair_lds_layout2(const int L, const int rows, const int nq);
 
 __device__ __forceinline__ unsigned launder_u32(unsigned v)
 {
@@ -299,6 +341,14 @@ __device__ __forceinline__ void wave_lds_sync()
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// ... and between the waves of a pair (WPP = 2): a workgroup barrier
+template <int WPP>
+__device__ __forceinline__ void pair_sync()
+{
+  if constexpr (WPP == 1) wave_lds_sync();
+  else __syncthreads();
 }
 
 // 1/sqrt(x) to the last ulp or two: v_rsq_f64 (2^-26) + two Newton steps.
@@ -596,7 +646,9 @@ __global__ void __launch_bounds__(64) pair_rotate_lane_kernel(const PairParams P
 // PRE (the JPT kernels, which have the registers): the recurrence constants of ALL steps of a
 // pass are requested before the first step instead of inside each step's divergent branch — a pass then waits for
 // one table load, not for one per step (six dependent ~1000-cycle round trips at L = 6).
-template <int L, bool PRE = false>
+// WPP = 2: `lane` is the thread index within the pair's two waves (0..127); with 128 lanes a group of <= 8 rings gets
+// 16 lanes per ring — at L <= 15 one order per lane, a single pass.
+template <int L, bool PRE = false, int WPP = 1>
 __device__ __forceinline__ void cap_frame_rings(const PairParams& P, double* __restrict__ lw, const WaveLdsLayout& W,
                                                 const int LL, const int lane, const int k0, const int nrows,
                                                 const double hw, const double hm, const bool have_first = false)
@@ -605,10 +657,12 @@ __device__ __forceinline__ void cap_frame_rings(const PairParams& P, double* __r
   // was requested at the start of the kernel and waits in the (empty) queue at lw[W.park + 128 + lane]
   const double* ch = lw + W.v0;
   double* ring = lw + W.ring;
-  const int lg = (nrows <= 8) ? 3 : (nrows <= 16) ? 2 : (nrows <= 32) ? 1 : 0;   // log2 G, wave-uniform
+  constexpr int NT = 64 * WPP;
+  const int lg1 = (nrows <= 8) ? 3 : (nrows <= 16) ? 2 : (nrows <= 32) ? 1 : 0;
+  const int lg = lg1 + (WPP == 2 ? 1 : 0);   // log2 G: as many lanes per ring as the NT lanes give the group's rows; uniform
   const int G = 1 << lg;
   const int g = lane & (G - 1);
-  for (int kr0 = 0; kr0 < nrows; kr0 += (64 >> lg)) {
+  for (int kr0 = 0; kr0 < nrows; kr0 += (NT >> lg)) {
     const int kr = kr0 + (lane >> lg);
     const bool row_ok = kr < nrows;
     const double tk = (PRE && have_first && k0 == 0 && kr0 == 0) ? lw[W.park + 128 + lane] : P.glt[k0 + (row_ok ? kr : 0)];
@@ -680,7 +734,7 @@ __device__ __forceinline__ void cap_frame_rings(const PairParams& P, double* __r
       sp *= sigG;
     }
   }
-  wave_lds_sync();
+  pair_sync<WPP>();
 }
 
 // Layout of the cos/sin(m psi_l) table (host: upload_quadrature).  Up to L = 6 l-major: the orders of one azimuth are
@@ -780,16 +834,18 @@ struct JPolyPre {
   }
 };
 
-template <int L>
+// WPP = 2 (two waves per pair): both waves take rows of the first stage (stride 128) and azimuth passes of the second
+// (wave h the passes h, h + 2, ...); `half` is the wave's index within the pair.
+template <int L, int WPP = 1>
 __device__ __forceinline__ void jpoly_build(const PairParams& P, double* __restrict__ lw, const WaveLdsLayout& W,
-                                            const int lane, const int nq, const JPolyPre<L>& pre)
+                                            const int lane, const int nq, const JPolyPre<L>& pre, const int half = 0)
 {
   // K powers per polynomial; the tables carry one order more than exist (m = L + 1: empty rows of PJ, a real
   // cos/sin pair) so that the azimuth stage below needs no guard on its reads
   constexpr int K = L + 1, NR = jpoly_rows(L) * K, XW = L / 2 + 1, RS = jpoly_row(L);
   const double* v0 = lw + W.v0;
   double* pj = lw + W.pj;
-  if constexpr (JPolyPre<L>::on) {
+  if constexpr (JPolyPre<L>::on && WPP == 1) {
 #pragma unroll
     for (int ps = 0; ps < JPolyPre<L>::NP; ++ps) {
       const int o = lane + 64 * ps;
@@ -799,7 +855,7 @@ __device__ __forceinline__ void jpoly_build(const PairParams& P, double* __restr
       if (o < NR) pj[o] = acc;
     }
   } else {
-    for (int o = lane; o < NR; o += 64) {
+    for (int o = lane + 64 * half; o < NR; o += 64 * WPP) {
       const double* val = P.jval + (size_t)o * XW;
       const int* col = P.jcol + (size_t)o * XW;
       double acc = 0.0;
@@ -808,7 +864,7 @@ __device__ __forceinline__ void jpoly_build(const PairParams& P, double* __restr
       pj[o] = acc;
     }
   }
-  wave_lds_sync();
+  pair_sync<WPP>();
   // Azimuth stage.  Lanes are (azimuth l, parity of m, parity of k), 16 azimuths per pass: a lane loads the
   // cos/sin(m psi_l) of its orders m = par, par + 2, ... once and walks its powers k = kq, kq + 2, ...; every LDS
   // address is the lane's base plus an immediate.  G (par = 0) has the powers 0..L, H (par = 1) the powers 0..L-1.
@@ -817,7 +873,7 @@ __device__ __forceinline__ void jpoly_build(const PairParams& P, double* __restr
   const int par = (lane >> 4) & 1, kq = lane >> 5;
   const int kmax = L - par;
   const double* pjl = pj + (2 * par) * K + kq;   // PJ[2 (2a + par) + part][kq + 2 b] at pjl[(4 a + part) K + 2 b]
-  for (int l0 = 0; l0 < nq; l0 += 16) {
+  for (int l0 = 16 * half; l0 < nq; l0 += 16 * WPP) {
     const int l = l0 + (lane & 15);
     const bool lok = l < nq;
     double cs[NM], sn[NM];
@@ -852,7 +908,7 @@ __device__ __forceinline__ void jpoly_build(const PairParams& P, double* __restr
       if (lok && kq + 2 * b <= kmax) out[-2 * b] = acc;
     }
   }
-  wave_lds_sync();
+  pair_sync<WPP>();
 }
 
 // r_j at polar angle (mu, sigma) of the common frame from a lane's row of the per-azimuth table; `sig` carries the
@@ -940,13 +996,21 @@ __device__ __forceinline__ void jpoly_eval2(const double* __restrict__ row, cons
 // node's azimuth and ring neighbours are a cross-lane read away, and queues every node with a positive
 // covered fraction together with that fraction; phase 2 scales the node's weight by it.  n_q <= 32 (a ring
 // neighbour is at most one slab away) and ring groups of at least two slabs' worth of rings: checked on the host.
-template <int L, bool NEEDV, bool WEIGHTED = false, bool JPT = false>
+// WPP = 2 (JPT kernels): two waves per pair, see pair_lds_layout2 — the workgroup is the pair, `half` the wave's half
+// of the azimuths; every table build runs on 128 lanes and every hand-over between the waves is a workgroup barrier
+// that BOTH waves reach the same number of times (the ring-group loop advances identically in both).
+template <int L, bool NEEDV, bool WEIGHTED = false, bool JPT = false, int WPP = 1>
 __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L, NEEDV) : (WEIGHTED ? SHP_WMIN_WAVES(L) : SHP_MIN_WAVES(L, NEEDV))) pair_contact_kernel(const PairParams P)
 {
+  static_assert(WPP == 1 || (WPP == 2 && JPT && L >= 0 && !WEIGHTED), "two waves per pair: compiled-order JPT kernels only");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   int lane = threadIdx.x & 63;
   const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int w = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * P.waves_per_block)) + wib;
+  const int w = (WPP == 2) ? (int)blockIdx.x : __builtin_amdgcn_readfirstlane((int)(blockIdx.x * P.waves_per_block)) + wib;
+  const int half = (WPP == 2) ? wib : 0;      // wave-uniform
+  const int tid = lane + 64 * half;           // lane within the pair's waves
+  constexpr int NT = 64 * WPP;
+  (void)tid;
   if (w >= P.npairs) return;
   const int LL = (L >= 0) ? L : P.lmax;
   const int nq = P.nq;
@@ -954,13 +1018,19 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
   // run-time-order kernel keeps the body-frame evaluation sh_eval_rt
   constexpr bool JP = JPT && (L >= 0) && !WEIGHTED;
   constexpr int LJ = JP ? L : 0;
-  const WaveLdsLayout W = wave_lds_layout(LL, P.ring_rows, WEIGHTED, JP ? nq : 0);
+  WaveLdsLayout W = (WPP == 2) ? pair_lds_layout2(LL, P.ring_rows, nq) : wave_lds_layout(LL, P.ring_rows, WEIGHTED, JP ? nq : 0);
+  if constexpr (WPP == 2) {   // this wave's queue
+    W.qri += half * W.qstride;
+    W.qrj += half * W.qstride;
+    W.qp += half * W.qstride;
+    W.park += half * W.qstride;
+  }
   // The frame and ring tables are loop invariant: a plain LDS load would be
   // hoisted out of the node loops and pinned in VGPRs, which is what they are
   // in LDS to avoid.  Each loop iteration therefore re-derives its base pointer
   // from a byte offset laundered through an empty asm (an integer, so that the
   // compiler still sees an LDS address and emits ds_read, not flat loads).
-  const unsigned wave_off = (unsigned)(wib * P.wave_lds_bytes);
+  const unsigned wave_off = (WPP == 2) ? 0u : (unsigned)(wib * P.wave_lds_bytes);
 #define SHP_LDS() ((double*)(smem_raw + launder_u32(wave_off)))
   double* lw = SHP_LDS();
 
@@ -973,7 +1043,7 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
   // Everything the prologue reads from memory is requested before the slot's status is looked at (a scalar load of
   // its own: waiting for it first would put two memory round trips in a row at the start of every pair).  The
   // addresses do not depend on the status; a dead slot's rows are in bounds and never used.
-  constexpr int NSL = (JPT && L >= 0 && !WEIGHTED) ? ((L + 1) * (L + 1) + 63) / 64 : 1;
+  constexpr int NSL = (JPT && L >= 0 && !WEIGHTED) ? ((L + 1) * (L + 1) + NT - 1) / NT : 1;
   double vi[NSL], vj[NSL];
   JPolyPre<(JPT && L >= 0 && !WEIGHTED) ? L : 0> pre;
   const double recv = P.rec[(size_t)kRecStride * w + (lane < kRecUsed ? lane : 0)];
@@ -982,14 +1052,14 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
     const double* rv = P.rot + (size_t)(2 * w) * ns;
 #pragma unroll
     for (int t = 0; t < NSL; ++t) {
-      const int e = lane + 64 * t;
+      const int e = tid + NT * t;
       vi[t] = rv[e < ns ? e : 0];
       vj[t] = rv[ns + (e < ns ? e : 0)];
     }
     pre.fetch(P, lane, P.nq);
   }
   double glt_first = 0.0;
-  if constexpr (JPT && L >= 0 && L <= 8 && !WEIGHTED) {
+  if constexpr (JPT && L >= 0 && L <= 8 && !WEIGHTED && WPP == 1) {
     const int nr0 = P.ring_rows < P.nq ? P.ring_rows : P.nq;   // rings of the first group (cap_frame_rings' lane map)
     const int lg0 = (nr0 <= 8) ? 3 : (nr0 <= 16) ? 2 : (nr0 <= 32) ? 1 : 0;
     const int kr = lane >> lg0;
@@ -1015,26 +1085,26 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
   }
   const bool centre_in_bj = rid[3] != 0;  // rho < Rj
   if constexpr (JP)
-    for (int t = lane; t < nq; t += 64) lw[W.glw + t * jpoly_row(LJ)] = P.glw[t];
-  if (lane < kRecUsed) lw[lane] = recv;
-  if constexpr (JP && L <= 8) lw[W.park + 128 + lane] = glt_first;
+    for (int t = tid; t < nq; t += NT) lw[W.glw + t * jpoly_row(LJ)] = P.glw[t];
+  if (tid < kRecUsed) lw[tid] = recv;
+  if constexpr (JP && L <= 8 && WPP == 1) lw[W.park + 128 + lane] = glt_first;
   if constexpr (JP) {
 #pragma unroll
     for (int t = 0; t < NSL; ++t)
-      if (lane + 64 * t < (LJ + 1) * (LJ + 1)) lw[W.v0 + lane + 64 * t] = vj[t];
+      if (tid + NT * t < (LJ + 1) * (LJ + 1)) lw[W.v0 + tid + NT * t] = vj[t];
   }
-  wave_lds_sync();
+  pair_sync<WPP>();
 #if defined(SHP_ABL) && SHP_ABL == 1   // timing-only build: stop after the pair prologue
   asm volatile("" ::"v"(lw[lane & 31]));
   return;
 #endif
   if constexpr (JP) {
     // particle j first: its vector shares the place of particle i's, which has to stay for the ring groups
-    jpoly_build<LJ>(P, lw, W, lane, nq, pre);
+    jpoly_build<LJ, WPP>(P, lw, W, lane, nq, pre, half);
 #pragma unroll
     for (int t = 0; t < NSL; ++t)
-      if (lane + 64 * t < (LJ + 1) * (LJ + 1)) lw[W.v0 + lane + 64 * t] = vi[t];
-    wave_lds_sync();
+      if (tid + NT * t < (LJ + 1) * (LJ + 1)) lw[W.v0 + tid + NT * t] = vi[t];
+    pair_sync<WPP>();
   } else {
     cap_frame_rotate<L>(P, lw, W, LL, si, lane);
   }
@@ -1082,7 +1152,8 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
   const unsigned magic = ((1u << 24) + (unsigned)npsi - 1u) / (unsigned)npsi;
   // lanes per ring in phase 1: the JPT kernels give a lane the node PAIR (k, l), (k, l + n_q) — the two azimuths of
   // a row of particle j's table, and r_i at both from one pass over the ring row (even orders + / - odd orders)
-  const int per_ring = JP ? nq : npsi;
+  // (two waves per pair: each wave half of them, the azimuths half n_q / 2 ... (half + 1) n_q / 2 - 1; n_q is even there)
+  const int per_ring = JP ? nq / WPP : npsi;
   const unsigned magicr = ((1u << 24) + (unsigned)per_ring - 1u) / (unsigned)per_ring;
   const int nslabs = (nq * per_ring + 63) >> 6;
   const int rowlen = 4 * (LL + 1);
@@ -1112,7 +1183,8 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
     if constexpr (JP) {   // 128 registers: two sums wait in the empty queue (they would be spilled otherwise)
       double* park = lr + W.park + lane;
       park[0] = aT2; park[64] = NEEDV ? aV : aS0;
-      cap_frame_rings<L, (L <= 8)>(P, lr, W, LL, lane, k0, kend - k0, lr[FR_HW], lr[FR_HM], true);
+      if constexpr (WPP == 2) __syncthreads();   // the other wave has left the node loops of the previous group: its rows may go
+      cap_frame_rings<L, (L <= 8 && WPP == 1), WPP>(P, lr, W, LL, tid, k0, kend - k0, lr[FR_HW], lr[FR_HM], WPP == 1);
       park = SHP_LDS() + W.park + lane;
       aT2 = park[0];
       if (NEEDV) aV = park[64]; else aS0 = park[64];
@@ -1258,9 +1330,9 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
     while (qcount < 64 && slab < slab_end) {
       fr = SHP_LDS();
       const int pp = (slab << 6) + lane;   // node pair: ring k, azimuths l and l + n_q
-      const bool valid = pp < nq * nq;
-      const int k = valid ? (int)(((unsigned)pp * magicr) >> 24) : 0;
-      const int l = valid ? pp - k * nq : 0;
+      const bool valid = pp < nq * per_ring;
+      const int k = valid ? (int)(((unsigned)pp * magicr) >> 24) : k0;   // idle lanes read a resident row
+      const int l = (valid ? pp - k * per_ring : 0) + half * per_ring;
       const double* row = fr + W.ring + (k - k0) * rowlen;
       const v2d r01 = lds2x<16>(row);   // (A_k0, mu_k)
       const double mu = r01[1], sig = row[3];
@@ -1611,8 +1683,10 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
   // atom (f[3i..3i+2] and torque[3i..3i+2] are contiguous: 2 memory-side operations per atom instead of 6).
   __builtin_amdgcn_s_setprio(3);
   lane = fresh_lane();
+  if constexpr (WPP == 2) __syncthreads();   // both waves are through their node loops: the shared tables are dead
   {
-    double* red = SHP_LDS() + kFrame;   // [7][kRedStride] partial sums | [56] | [7] totals | [6] force components
+    // [7][kRedStride] partial sums | [56] | [7] totals | [6] force components; two waves per pair: one such block each
+    double* red = SHP_LDS() + ((WPP == 2 && half) ? (int)(P.wave_lds_bytes >> 3) - kRedPerWave : kFrame);
     red[0 * kRedStride + lane] = aS0; red[1 * kRedStride + lane] = aS1; red[2 * kRedStride + lane] = aS2;
     red[3 * kRedStride + lane] = aT0; red[4 * kRedStride + lane] = aT1; red[5 * kRedStride + lane] = aT2;
     red[6 * kRedStride + lane] = NEEDV ? aV : 0.0;
@@ -1629,6 +1703,12 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
       tot[lane] = ((src[0] + src[1]) + (src[2] + src[3])) + ((src[4] + src[5]) + (src[6] + src[7]));
     }
     wave_lds_sync();
+    if constexpr (WPP == 2) {   // wave 0 adds the other half's totals and finishes the pair
+      __syncthreads();
+      if (half != 0) return;
+      if (lane < 7) tot[lane] += SHP_LDS()[(int)(P.wave_lds_bytes >> 3) - kRedPerWave + 7 * kRedStride + 56 + lane];
+      wave_lds_sync();
+    }
   }
   if (lane >= 6) return;
   fr = SHP_LDS();
@@ -1716,11 +1796,20 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
 // Host-callable launcher, one per compiled order (pair_kernels_L*.hip).
 typedef void (*pair_launch_fn)(const PairParams&, bool needv, hipStream_t);
 // Register / LDS footprint of the kernel that launch would pick (occupancy evidence for bench.py).
-typedef hipError_t (*pair_attr_fn)(bool needv, bool weighted, hipFuncAttributes*, bool jpoly);
+typedef hipError_t (*pair_attr_fn)(bool needv, bool weighted, hipFuncAttributes*, bool jpoly, bool split);
+
+// Orders for which the two-waves-per-pair kernels are compiled (they pay where one wave's private tables starve the CU
+// of waves: large L with large n_q; the host's rule is use_split in shpair_api.hip)
+__host__ __device__ constexpr bool split_compiled(int L) { return L >= 7; }
 
 template <int L>
-hipError_t pair_contact_attributes(bool needv, bool weighted, hipFuncAttributes* a, bool jpoly = false)
+hipError_t pair_contact_attributes(bool needv, bool weighted, hipFuncAttributes* a, bool jpoly = false, bool split = false)
 {
+  if constexpr (split_compiled(L)) {
+    if (split && jpoly && !weighted)
+      return needv ? hipFuncGetAttributes(a, (const void*)pair_contact_kernel<L, true, false, true, 2>)
+                   : hipFuncGetAttributes(a, (const void*)pair_contact_kernel<L, false, false, true, 2>);
+  }
   if (weighted) {
     if constexpr (L >= 0) return hipFuncGetAttributes(a, (const void*)pair_contact_kernel<L, true, true>);
     return hipErrorInvalidValue;
@@ -1763,6 +1852,14 @@ void launch_pair_contact(const PairParams& P, bool needv, hipStream_t st)
       else
         hipLaunchKernelGGL((pair_rotate_lane_kernel<L>), dim3((2 * (unsigned)P.npairs + 63) / 64), dim3(64),
                            RotLaneLds<L>::bytes(), st, P, const_cast<double*>(P.rot));
+      if constexpr (split_compiled(L)) {
+        if (P.split) {   // two waves per pair: the workgroup is the pair
+          const dim3 grid2(P.npairs), block2(128);
+          if (needv) launch_contact_one(pair_contact_kernel<L, true, false, true, 2>, grid2, block2, (size_t)P.wave_lds_bytes, st, P);
+          else launch_contact_one(pair_contact_kernel<L, false, false, true, 2>, grid2, block2, (size_t)P.wave_lds_bytes, st, P);
+          return;
+        }
+      }
       if (needv) launch_contact_one(pair_contact_kernel<L, true, false, true>, grid, block, lds, st, P);
       else launch_contact_one(pair_contact_kernel<L, false, false, true>, grid, block, lds, st, P);
       return;

@@ -19,5 +19,5 @@
 
 namespace shp {
 void SHP_FN(const PairParams& P, bool needv, hipStream_t st) { launch_pair_contact<SHP_L>(P, needv, st); }
-hipError_t SHP_AFN(bool needv, bool weighted, hipFuncAttributes* a, bool jpoly) { return pair_contact_attributes<SHP_L>(needv, weighted, a, jpoly); }
+hipError_t SHP_AFN(bool needv, bool weighted, hipFuncAttributes* a, bool jpoly, bool split) { return pair_contact_attributes<SHP_L>(needv, weighted, a, jpoly, split); }
 }  // namespace shp

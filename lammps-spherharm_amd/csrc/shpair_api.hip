@@ -24,12 +24,12 @@
 
 namespace shp {
 #define SHP_DECL(L) void shp_launch_L##L(const PairParams&, bool, hipStream_t); \
-  hipError_t shp_attr_L##L(bool, bool, hipFuncAttributes*, bool);
+  hipError_t shp_attr_L##L(bool, bool, hipFuncAttributes*, bool, bool);
 SHP_DECL(0) SHP_DECL(1) SHP_DECL(2) SHP_DECL(3) SHP_DECL(4) SHP_DECL(5) SHP_DECL(6)
 SHP_DECL(7) SHP_DECL(8) SHP_DECL(9) SHP_DECL(10) SHP_DECL(11) SHP_DECL(12)
 #undef SHP_DECL
 void shp_launch_Lrt(const PairParams&, bool, hipStream_t);
-hipError_t shp_attr_Lrt(bool, bool, hipFuncAttributes*, bool);
+hipError_t shp_attr_Lrt(bool, bool, hipFuncAttributes*, bool, bool);
 
 constexpr int kMaxUnrolledL = 12;
 static const pair_launch_fn kLaunch[kMaxUnrolledL + 1] = {
@@ -397,6 +397,20 @@ static bool use_jpoly_at(const shpair_ctx* c, const int L)
 }
 static bool use_jpoly(const shpair_ctx* c) { return use_jpoly_at(c, c->lmax); }
 
+// Two waves per pair (pair_kernel.hpp pair_lds_layout2): the JPT kernels of the orders it is compiled for, even n_q.
+// Pays where one wave's private copy of the tables leaves a CU too few waves for its dependent FP64 chains — large L
+// with large n_q (L = 12, n_q = 32: 14.6 KB per one-wave pair = 11 waves per CU, 17.3 KB per two-wave pair = the
+// 16 the registers allow).  Option "split": 1 / 0 force, -1 (default) the measured rule (profiles/r03_*_split_matrix.txt).
+static bool use_split(const shpair_ctx* c, const bool jpoly)
+{
+  if (!jpoly || !split_compiled(c->lmax) || c->lmax > kMaxUnrolledL || (c->nq & 1) || c->nq < 8) return false;
+  if (c->opt_split >= 0) return c->opt_split == 1;
+  // measured (interleaved A/B over L = 7..12 x n_q = 8..32, profiles/r03_g_split_matrix.txt, r03_h_split_matrix.txt; the
+  // boxes' noise is +-3 %): two waves win by 4-13 % at n_q = 32 from L = 8 on and at L = 12 from n_q = 16 on, lose
+  // below (at n_q = 8 half of each wave's lanes have no node pair: +40 %)
+  return (c->lmax >= 8 && c->nq >= 32) || (c->lmax >= 12 && c->nq >= 16);
+}
+
 }  // extern "C"
 
 // Sizes the per-slot buffers the pair kernels write (records; rotated coefficient vectors of the JPT family) for a
@@ -643,6 +657,9 @@ int shpair_compute_device(shpair_ctx* c, int nlocal, int nghost, const double* x
   c->last_jpoly = jpoly;
   P.jpoly = jpoly ? 1 : 0;
   P.rot_by_wave = (c->opt_jpoly_rot == 1) ? 1 : 0;
+  const bool split = use_split(c, jpoly);
+  c->last_split = split;
+  P.split = split ? 1 : 0;
   const int nqj = jpoly ? nq : 0;   // rows of the per-azimuth table in a wave's LDS
   {
     // Resident ring rows: all nq if a wave then needs <= 8 KB of LDS (five 4-wave workgroups per CU,
@@ -652,7 +669,7 @@ int shpair_compute_device(shpair_ctx* c, int nlocal, int nghost, const double* x
     const int npsi = 2 * nq;
     // lanes per ring in phase 1: 2 n_q nodes, or n_q node pairs in the per-azimuth-polynomial kernels, whose table of
     // particle j comes on top of the 8 KB
-    const int per_ring = jpoly ? nq : npsi;
+    const int per_ring = jpoly ? (split ? nq / 2 : nq) : npsi;
     const int rows_min = 1 + (63 + per_ring - 1) / per_ring;
     int rows = nq;
     if (c->opt_ring_rows > 0) rows = c->opt_ring_rows;
@@ -679,7 +696,30 @@ int shpair_compute_device(shpair_ctx* c, int nlocal, int nghost, const double* x
       if (rows < rows_min_w) rows = rows_min_w;
       if (rows > nq) rows = nq;
     }
-    const WaveLdsLayout wl = wave_lds_layout(c->lmax, rows, c->opt_rule != 0, nqj);
+    if (split && c->opt_ring_rows <= 0) {
+      // two waves per pair: a slab of one wave spans 64 / per_ring rings; two slabs' worth of rings per group, all of
+      // them if the pair then stays within 20 KB (8 pairs = 16 waves per CU)
+      // ... as many slabs' worth of rings per group as keep the pair within the LDS share of the waves its registers
+      // allow (all rings if they fit), never fewer than two slabs' worth
+      const int per_slab = (64 + per_ring - 1) / per_ring;
+      int wsimd = 4;
+      {
+        hipFuncAttributes fa;
+        if (kAttr[c->lmax](true, false, &fa, true, true) == hipSuccess && fa.numRegs > 0) {
+          wsimd = 512 / (((fa.numRegs + 7) / 8) * 8);
+          if (wsimd > 8) wsimd = 8;
+          if (wsimd < 1) wsimd = 1;
+        }
+      }
+      const int budget = (160 * 1024) / (2 * wsimd);   // bytes per pair: 4 wsimd waves per CU, two per pair
+      rows = 2 * per_slab;
+      if (pair_lds_layout2(c->lmax, nq, nq).bytes <= budget) rows = nq;
+      else
+        while (rows + per_slab <= nq && pair_lds_layout2(c->lmax, rows + per_slab, nq).bytes <= budget) rows += per_slab;
+      if (rows < rows_min) rows = rows_min;
+      if (rows > nq) rows = nq;
+    }
+    const WaveLdsLayout wl = split ? pair_lds_layout2(c->lmax, rows, nq) : wave_lds_layout(c->lmax, rows, c->opt_rule != 0, nqj);
     if (wl.bytes > 160 * 1024)
       CTX_FAIL(c, SHPAIR_ELMAX, "lmax %d with nq %d needs %d bytes of LDS per pair, more than a CU has", c->lmax, nq,
                wl.bytes);
@@ -691,6 +731,7 @@ int shpair_compute_device(shpair_ctx* c, int nlocal, int nghost, const double* x
       wpb = c->opt_wpb < kMaxWavesPerBlock ? c->opt_wpb : kMaxWavesPerBlock;
       if (wpb * wl.bytes > 160 * 1024) wpb = (160 * 1024) / wl.bytes;
     }
+    if (split) wpb = 1;   // the workgroup is the pair; wave_lds_bytes its whole LDS
     P.wave_lds_bytes = wl.bytes + ((c->opt_lds_pad > 0) ? (c->opt_lds_pad & ~15) : 0);   // lds_pad: occupancy experiments
     P.waves_per_block = wpb;
     P.ring_rows = rows;
@@ -835,18 +876,21 @@ int shpair_get_kernel_info(shpair_ctx* c, shpair_kernel_info* out)
   HIPCHK(c, hipSetDevice(c->device));
   hipFuncAttributes a;
   const bool compiled = c->lmax <= kMaxUnrolledL && c->opt_variant != 1;
-  HIPCHK(c, compiled ? kAttr[c->lmax](c->last_needv, c->opt_rule != 0, &a, c->last_jpoly) : shp_attr_Lrt(c->last_needv, false, &a, false));
+  HIPCHK(c, compiled ? kAttr[c->lmax](c->last_needv, c->opt_rule != 0, &a, c->last_jpoly, c->last_split)
+                     : shp_attr_Lrt(c->last_needv, false, &a, false, false));
   out->lmax = c->lmax;
   out->compiled_order = compiled ? 1 : 0;
   out->vgprs = a.numRegs;
   out->scratch_bytes = (int)a.localSizeBytes;
-  out->lds_bytes_per_wave = c->last_lds_bytes;
+  const int wpp = (compiled && c->last_split) ? 2 : 1;   // waves per pair
+  out->lds_bytes_per_wave = c->last_lds_bytes / wpp;
+  out->waves_per_pair = wpp;
   out->ring_rows = c->last_ring_rows;
   // gfx950: 512 VGPRs per SIMD lane in blocks of 8, at most 8 waves per SIMD, 160 KiB LDS per CU of 4 SIMDs
   const int vg = ((a.numRegs + 7) / 8) * 8;
   int w = vg > 0 ? 512 / vg : 8;
   if (w > 8) w = 8;
-  const int by_lds = (160 * 1024) / c->last_lds_bytes;  // one wave per workgroup: workgroups per CU
+  const int by_lds = wpp * ((160 * 1024) / c->last_lds_bytes);  // workgroups (= pairs) per CU x waves per pair
   out->waves_per_simd_vgpr = w;
   out->waves_per_cu_lds = by_lds;
   const int cu = (4 * w < by_lds) ? 4 * w : by_lds;
@@ -884,6 +928,7 @@ int shpair_set_option(shpair_ctx* c, const char* key, int value)
   }
   else if (!strcmp(key, "ring_rows")) c->opt_ring_rows = value;
   else if (!strcmp(key, "jpoly")) c->opt_jpoly = value;
+  else if (!strcmp(key, "split")) c->opt_split = value;
   else if (!strcmp(key, "jpoly_rot")) c->opt_jpoly_rot = value;
   else if (!strcmp(key, "lds_pad")) c->opt_lds_pad = value;
   else if (!strcmp(key, "waves_per_block")) c->opt_wpb = value;

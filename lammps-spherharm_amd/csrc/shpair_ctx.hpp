@@ -97,6 +97,8 @@ struct shpair_ctx {
   int opt_jpoly_rot = 0;   // 1: rotations by pair_rotate_kernel (diagnostic; default pair_rotate_lane_kernel)
   int opt_lds_pad = 0;     // diagnostic: unused LDS bytes added to every wave's allocation (fewer resident waves)
   bool last_jpoly = false;
+  int opt_split = -1;      // 1 / 0: two waves per pair (pair_kernel.hpp WPP = 2) or one; -1: by the rule use_split
+  bool last_split = false;
   int last_lds_bytes = 0, last_ring_rows = 0;  // of the last launch (shpair_get_kernel_info)
   bool last_needv = false;
   double* pair_out = nullptr;

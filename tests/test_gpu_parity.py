@@ -94,6 +94,57 @@ def test_both_kernel_families_match_oracle(oracle, lmax, nq, jpoly):
     sp.close()
 
 
+@pytest.mark.parametrize("lmax,nq,rows,expo", [(7, 8, 0, 1.25), (7, 16, 4, 1.25), (8, 12, 0, 1.0), (9, 16, 0, 1.25), (9, 20, 8, 1.25),
+                                                (10, 24, 0, 1.25), (11, 16, 8, 1.5), (12, 16, 0, 1.25), (12, 32, 0, 1.25),
+                                                (12, 32, 4, 1.0), (12, 64, 0, 1.25), (8, 10, 0, 1.25)])
+def test_two_waves_per_pair_match_oracle(oracle, lmax, nq, rows, expo):
+    """The two-waves-per-pair form of the per-azimuth-polynomial kernels (option "split": the pair's tables shared by a
+    128-lane workgroup, each wave half of the azimuths, a queue per wave, workgroup barriers at every table hand-over)
+    forced for every order it is compiled for: n_q / 2 that does and does not divide 64, all rings resident and ring
+    groups (rows: the "ring_rows" option), forces-only and volume laws, against the oracle and against the one-wave
+    kernels of the same library."""
+    case = make_case(160, lmax, 2, seed=300 + lmax, rmax_fn=oracle.shape_rmax)
+    K, E = coeff_tables(1, 1000.0, expo)
+    b = case["bed"]
+    out = {}
+    for split in (1, 0):
+        sp = make_ctx(case, nq, K, E)
+        sp.set_option("jpoly", 1)
+        sp.set_option("split", split)
+        if rows:
+            sp.set_option("ring_rows", rows)
+        sp.set_option("count", 1)
+        f, tq, eng, vir = sp.compute(case["n"], b["x"], b["quat"], b["type"], b["shtype"], eflag=True, vflag=True)
+        ki = sp.kernel_info()
+        assert ki["family"] == 1 and ki["waves_per_pair"] == (2 if split else 1) and ki["scratch_bytes"] == 0
+        st = sp.stats()
+        out[split] = (f, tq, eng, (st["n_candidates"], st["n_contact"], st["n_touching"]))
+        sp.close()
+    o = oracle_compute(oracle, case, nq, K, E, eflag=True, vflag=True)
+    for split in (1, 0):
+        f, tq, eng, counts = out[split]
+        check(f, tq, o)
+        assert abs(eng - o["eng_virial"][0]) < TOL * abs(o["eng_virial"][0])
+        assert counts == tuple(o["counts"])
+    fs = np.abs(o["f"]).max()
+    assert np.abs(out[1][0] - out[0][0]).max() < 1e-12 * fs
+
+
+def test_split_option_is_ignored_where_it_does_not_apply(oracle):
+    """Odd n_q, orders below 7 and the body-frame family have no two-wave form: the option must fall back silently."""
+    for lmax, nq, jp in ((8, 9, 1), (6, 16, 1), (9, 16, 0)):
+        case = make_case(60, lmax, 1, seed=11, rmax_fn=oracle.shape_rmax)
+        K, E = coeff_tables(1, 1000.0, 1.25)
+        sp = make_ctx(case, nq, K, E)
+        sp.set_option("jpoly", jp)
+        sp.set_option("split", 1)
+        b = case["bed"]
+        f, tq, _, _ = sp.compute(case["n"], b["x"], b["quat"], b["type"], b["shtype"])
+        assert sp.kernel_info()["waves_per_pair"] == 1
+        check(f, tq, oracle_compute(oracle, case, nq, K, E))
+        sp.close()
+
+
 def test_mixed_types_and_exponents(oracle):
     case = make_case(300, 6, 3, seed=40, ntypes=3, rmax_fn=oracle.shape_rmax)
     K, E = coeff_tables(3, kn=lambda i, j: 300.0 * (i + j), expo=lambda i, j: 1.0 + 0.25 * abs(i - j))
