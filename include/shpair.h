@@ -143,7 +143,11 @@ int shpair_compute_device(shpair_ctx *ctx, int nlocal, int nghost, const double 
  * measured rule picks for (lmax, nq); same results to rounding, ~1e-14 relative), "split" (1: two waves per pair — the
  * pair's tables are shared by a 128-lane workgroup, each wave integrates half of the azimuths — for the "jpoly" family
  * at lmax >= 7 and even nq; 0: one wave per pair; -1 (default): two where one wave's private tables would leave a CU
- * fewer than 16 waves); diagnostics: "jpoly_rot" (1: the
+ * fewer than 16 waves), "deterministic" (1: bitwise reproducible forces and torques — each pair's force and torque
+ * are written once into a per-slot buffer and added per atom in list order by a gather pass through a reverse index
+ * that is rebuilt on the device whenever a list is installed, instead of hardware FP64 atomics whose order of
+ * arrival varies from run to run (last-bit differences, ~1e-16 relative per add); costs one more pass and 96 bytes per
+ * list slot; the energy / virial tallies, global and per atom, keep their atomics; 0 (default): atomics); diagnostics: "jpoly_rot" (1: the
  * rotations of the "jpoly" family by a wave per rotation instead of a lane per rotation), "lds_pad" (unused LDS bytes
  * added to every wave of the contact kernel: fewer resident waves, for occupancy experiments). */
 int shpair_set_option(shpair_ctx *ctx, const char *key, int value);

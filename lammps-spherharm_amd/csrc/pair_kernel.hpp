@@ -101,6 +101,8 @@ struct PairParams {
   // outputs / flags
   double* ev;           // 7 doubles or null
   double* pair_out;     // 7 doubles per slot or null
+  double* pair_ft;      // deterministic mode (det_kernels.hpp): 12 doubles per slot, F_i tau_i | F_j tau_j, written instead
+                        // of the atomics; null in the default mode
   unsigned char* flags;  // per slot: 1 = contact pair, 2 = touching pair; or null (stats only)
   int eflag;
   int vflag;
@@ -1748,14 +1750,17 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
   const double Fm = -pn * val;   // lanes 0-2: F_i; lanes 3-5: tau_i
   fcomp[lane] = Fm;
   wave_lds_sync();
-  atomicAdd((is_t ? E.torque : E.f) + 3 * (size_t)i + comp, Fm);
+  double* const det = E.pair_ft;   // deterministic mode: the pair's numbers are written once, a gather adds them in list order
+  if (det) det[12 * (size_t)w + lane] = Fm;
+  else atomicAdd((is_t ? E.torque : E.f) + 3 * (size_t)i + comp, Fm);
   const bool applyj = E.newton_pair || j < E.nlocal;
   if (applyj) {
     // F_j = -F_i ;  tau_j = -tau_i - d x F_j : component c needs d and F_j at c + 1, c + 2
     const int c1 = (comp == 2) ? 0 : comp + 1, c2 = (comp == 0) ? 2 : comp - 1;
     double vj = -Fm;
     if (is_t) vj -= fr[FR_D + c1] * (-fcomp[c2]) - fr[FR_D + c2] * (-fcomp[c1]);
-    atomicAdd((is_t ? E.torque : E.f) + 3 * (size_t)j + comp, vj);
+    if (det) det[12 * (size_t)w + 6 + lane] = vj;
+    else atomicAdd((is_t ? E.torque : E.f) + 3 * (size_t)j + comp, vj);
   }
   if (lane != 0) return;
   // the tallies (only when asked for) stay with lane 0

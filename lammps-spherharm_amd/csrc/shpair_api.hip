@@ -17,6 +17,7 @@
 #include "../../include/shpair.h"
 #include "fp64_peak.hpp"
 #include "pair_kernel.hpp"
+#include "det_kernels.hpp"
 #include "pair_setup.hpp"
 #include "shpair_ctx.hpp"
 #include "sh_const.hpp"
@@ -130,6 +131,7 @@ void shpair_destroy(shpair_ctx* c)
   c->d_x.release(); c->d_quat.release(); c->d_f.release(); c->d_torque.release(); c->d_ev.release();
   c->d_type.release(); c->d_shtype.release(); c->d_counters.release(); c->d_flags.release();
   c->d_eatom.release(); c->d_vatom.release(); c->d_list.release(); c->d_err.release(); c->d_rec.release(); c->d_rec_i.release(); c->d_rot.release();
+  c->d_pair_ft.release(); c->d_rev_start.release(); c->d_rev_cur.release(); c->d_rev_ent.release();
   if (c->h_list) (void)hipHostFree(c->h_list);
   if (c->h_err) (void)hipHostFree(c->h_err);
   if (c->h_ev) (void)hipHostFree(c->h_ev);
@@ -419,7 +421,12 @@ static bool use_split(const shpair_ctx* c, const bool jpoly)
 hipError_t shp_size_pair_buffers(shpair_ctx* c, size_t np)
 {
   if (np == 0) np = 1;
+  c->rev_dirty = true;   // a list is being installed: the reverse index of the deterministic mode is stale
   hipError_t e = c->d_rec.ensure(np * kRecStride);
+  if (e == hipSuccess && c->opt_deterministic) {
+    e = c->d_pair_ft.ensure(np * 12);
+    if (e == hipSuccess) e = c->d_rev_ent.ensure(np * 2);
+  }
   if (e == hipSuccess) e = c->d_rec_i.ensure(np * 4);
   int L = c->lmax;
   for (int s = 0; s < c->nshapes; ++s)
@@ -738,6 +745,36 @@ int shpair_compute_device(shpair_ctx* c, int nlocal, int nghost, const double* x
     c->last_lds_bytes = P.wave_lds_bytes;
     c->last_ring_rows = rows;
   }
+  P.pair_ft = nullptr;
+  if (c->opt_deterministic) {
+    // deterministic accumulation: reverse index (once per list), a clean per-slot buffer, stores instead of atomics
+    const int nall_idx = c->max_atom_index + 1;
+    HIPCHK(c, c->d_pair_ft.ensure((size_t)c->npairs * 12));
+    HIPCHK(c, c->d_rev_ent.ensure((size_t)c->npairs * 2));
+    HIPCHK(c, c->d_rev_start.ensure((size_t)nall_idx + 1));
+    HIPCHK(c, c->d_rev_cur.ensure((size_t)nall_idx + 1));
+    if (c->rev_dirty || c->rev_nall != nall_idx) {
+      HIPCHK(c, hipMemsetAsync(c->d_rev_cur.p, 0, ((size_t)nall_idx + 1) * sizeof(int), st));
+      hipLaunchKernelGGL(det_count_kernel, dim3((c->npairs + kDetBlock - 1) / kDetBlock), dim3(kDetBlock), 0, st, c->npairs,
+                         (const int*)c->d_pair_i.p, (const int*)c->d_pair_j.p, nall_idx, c->d_rev_cur.p);
+      HIPCHK(c, hipGetLastError());
+      {
+        const int rc = shstep_exclusive_scan(c, c->d_rev_cur.p, c->d_rev_start.p, nall_idx, st);
+        if (rc) return rc;
+      }
+      HIPCHK(c, hipMemsetAsync(c->d_rev_cur.p, 0, ((size_t)nall_idx + 1) * sizeof(int), st));
+      hipLaunchKernelGGL(det_fill_kernel, dim3((c->npairs + kDetBlock - 1) / kDetBlock), dim3(kDetBlock), 0, st, c->npairs,
+                         (const int*)c->d_pair_i.p, (const int*)c->d_pair_j.p, nall_idx, (const int*)c->d_rev_start.p,
+                         c->d_rev_cur.p, c->d_rev_ent.p);
+      hipLaunchKernelGGL(det_sort_kernel, dim3((nall_idx + kDetBlock - 1) / kDetBlock), dim3(kDetBlock), 0, st, nall_idx,
+                         (const int*)c->d_rev_start.p, c->d_rev_ent.p);
+      HIPCHK(c, hipGetLastError());
+      c->rev_dirty = false;
+      c->rev_nall = nall_idx;
+    }
+    HIPCHK(c, hipMemsetAsync(c->d_pair_ft.p, 0, (size_t)c->npairs * 12 * sizeof(double), st));
+    P.pair_ft = c->d_pair_ft.p;
+  }
   P.ev = ev; P.pair_out = c->pair_out;
   P.flags = nullptr;
   P.dbg = c->dbg;
@@ -771,6 +808,12 @@ int shpair_compute_device(shpair_ctx* c, int nlocal, int nghost, const double* x
     shp_launch_Lrt(P, needv, st);
   }
   HIPCHK(c, hipGetLastError());
+  if (c->opt_deterministic) {
+    const int nall_idx = c->max_atom_index + 1;
+    hipLaunchKernelGGL(det_gather_kernel, dim3((6 * nall_idx + kDetBlock - 1) / kDetBlock), dim3(kDetBlock), 0, st, nall_idx,
+                       (const int*)c->d_rev_start.p, (const int*)c->d_rev_ent.p, (const double*)c->d_pair_ft.p, f, torque);
+    HIPCHK(c, hipGetLastError());
+  }
   if (c->opt_timing) {
     HIPCHK(c, hipEventRecord(c->ev1, st));
     c->timed_last = true;
@@ -929,6 +972,10 @@ int shpair_set_option(shpair_ctx* c, const char* key, int value)
   else if (!strcmp(key, "ring_rows")) c->opt_ring_rows = value;
   else if (!strcmp(key, "jpoly")) c->opt_jpoly = value;
   else if (!strcmp(key, "split")) c->opt_split = value;
+  else if (!strcmp(key, "deterministic")) {
+    c->opt_deterministic = value ? 1 : 0;
+    c->rev_dirty = true;
+  }
   else if (!strcmp(key, "jpoly_rot")) c->opt_jpoly_rot = value;
   else if (!strcmp(key, "lds_pad")) c->opt_lds_pad = value;
   else if (!strcmp(key, "waves_per_block")) c->opt_wpb = value;

@@ -97,6 +97,12 @@ struct shpair_ctx {
   int opt_jpoly_rot = 0;   // 1: rotations by pair_rotate_kernel (diagnostic; default pair_rotate_lane_kernel)
   int opt_lds_pad = 0;     // diagnostic: unused LDS bytes added to every wave's allocation (fewer resident waves)
   bool last_jpoly = false;
+  // deterministic accumulation (det_kernels.hpp): per-slot results + reverse index (atom -> its list slots)
+  int opt_deterministic = 0;
+  shp::DevBuf<double> d_pair_ft;
+  shp::DevBuf<int> d_rev_start, d_rev_cur, d_rev_ent;
+  bool rev_dirty = true;
+  int rev_nall = 0;
   int opt_split = -1;      // 1 / 0: two waves per pair (pair_kernel.hpp WPP = 2) or one; -1: by the rule use_split
   bool last_split = false;
   int last_lds_bytes = 0, last_ring_rows = 0;  // of the last launch (shpair_get_kernel_info)

@@ -346,16 +346,28 @@ __global__ __launch_bounds__(kStepBlock) void forward_kernel(int nlocal, int ngh
   for (int k = 0; k < 4; ++k) quat[4 * row + k] = quat[4 * i + k];
 }
 
+// Comm::reverse_comm for the periodic images of one rank.  The images of an owner are consecutive ghost rows (they are
+// created owner by owner, fill_ghosts_kernel): the lane of an owner's FIRST image adds the whole run, in order, with
+// plain adds — one writer per owner row, no atomics, the same bits every run (the deterministic mode of the pair
+// kernel relies on it for reproducible trajectories; an owner has at most 7 images).
 __global__ __launch_bounds__(kStepBlock) void reverse_kernel(int nlocal, int nghost, const int* __restrict__ gowner,
                                                              double* __restrict__ f, double* __restrict__ tq)
 {
   const int g = blockIdx.x * kStepBlock + threadIdx.x;
   if (g >= nghost) return;
-  const int i = gowner[g], row = nlocal + g;
+  const int i = gowner[g];
+  if (g > 0 && gowner[g - 1] == i) return;   // not the first image of its owner
+  double a[3] = {0.0, 0.0, 0.0}, t[3] = {0.0, 0.0, 0.0};
+  for (int h = g; h < nghost && gowner[h] == i; ++h) {
+    const int row = nlocal + h;
+    for (int k = 0; k < 3; ++k) {
+      a[k] += f[3 * row + k];
+      t[k] += tq[3 * row + k];
+    }
+  }
   for (int k = 0; k < 3; ++k) {
-    const double a = f[3 * row + k], t = tq[3 * row + k];
-    if (a != 0.0) atomicAdd(&f[3 * i + k], a);
-    if (t != 0.0) atomicAdd(&tq[3 * i + k], t);
+    f[3 * i + k] += a[k];
+    tq[3 * i + k] += t[k];
   }
 }
 

@@ -1,0 +1,120 @@
+"""The deterministic accumulation mode (shpair_set_option "deterministic", csrc/det_kernels.hpp): each pair's force and
+torque written once, added per atom in list order through a device-built reverse index — bitwise reproducible where
+the default's hardware FP64 atomics reorder the sums from run to run."""
+import numpy as np
+import pytest
+
+from common import make_case, coeff_tables, oracle_compute
+
+pytestmark = pytest.mark.gpu
+
+
+def _ctx(case, nq, K, E, det):
+    from shpair import ShPair
+    sp = ShPair(0)
+    sp.settings(nq)
+    sp.set_ntypes(K.shape[0] - 1, len(case["shapes"]))
+    for s, a in enumerate(case["shapes"]):
+        sp.set_shape(s, case["lmax"], a)
+    for i in range(1, K.shape[0]):
+        for j in range(1, K.shape[0]):
+            sp.coeff(i, j, K[i, j], E[i, j])
+    sp.set_neighbors_csr(case["ilist"], case["offsets"], case["jlist"])
+    sp.set_option("deterministic", det)
+    return sp
+
+
+def test_full_size_bitwise_reproducible_and_equal_to_the_atomic_path(oracle):
+    """BASELINE configs[1] at full size: three deterministic computes (two contexts) are bitwise equal, the atomic path
+    agrees to 1e-12 (it only reorders the sums), and the atomic path itself is NOT bitwise reproducible here (if it
+    were, the mode would be untested)."""
+    case = make_case(100000, 6, 1, seed=2, rmax_fn=oracle.shape_rmax)
+    K, E = coeff_tables(1, 1000.0, 1.25)
+    b = case["bed"]
+    n = case["n"]
+    runs = []
+    for rep in range(2):
+        sp = _ctx(case, 16, K, E, 1)
+        for _ in range(2 if rep == 0 else 1):
+            f, tq, eng, _ = sp.compute(n, b["x"], b["quat"], b["type"], b["shtype"], eflag=True)
+            runs.append((f.copy(), tq.copy(), eng))
+        sp.close()
+    for f, tq, _ in runs[1:]:
+        assert np.array_equal(f, runs[0][0]) and np.array_equal(tq, runs[0][1])
+    sp = _ctx(case, 16, K, E, 0)
+    fa, ta, ea, _ = sp.compute(n, b["x"], b["quat"], b["type"], b["shtype"], eflag=True)
+    fb, tb, _, _ = sp.compute(n, b["x"], b["quat"], b["type"], b["shtype"], eflag=True)
+    sp.close()
+    fs = np.abs(fa).max()
+    assert fs > 0
+    assert np.abs(fa - runs[0][0]).max() < 1e-12 * fs and np.abs(ta - runs[0][1]).max() < 1e-12 * fs
+    assert abs(ea - runs[0][2]) < 1e-11 * ea
+    if np.array_equal(fa, fb) and np.array_equal(ta, tb):
+        pytest.skip("the atomic path happened to be bitwise reproducible on this run (the deterministic checks passed)")
+
+
+@pytest.mark.parametrize("newton", [True, False])
+def test_against_the_oracle_with_ghosts_and_mixed_shapes(oracle, newton):
+    """Half list over owned rows with ghosts behind them, newton on / off, two shapes, two orders of the list: the
+    gather must add ghost rows only with newton on, and a changed list must rebuild the reverse index."""
+    case = make_case(400, 5, 2, seed=12, rmax_fn=oracle.shape_rmax)
+    nlocal = 400 if newton else 250
+    if not newton:
+        case = dict(case)
+        case["ilist"] = case["ilist"][:nlocal]
+        case["jlist"] = case["jlist"][:case["offsets"][nlocal]]
+        case["offsets"] = case["offsets"][:nlocal + 1]
+    K, E = coeff_tables(1, 800.0, 1.25)
+    sp = _ctx(case, 12, K, E, 1)
+    b = case["bed"]
+    f, tq, eng, vir = sp.compute(nlocal, b["x"], b["quat"], b["type"], b["shtype"], newton_pair=newton, eflag=True, vflag=True)
+    o = oracle_compute(oracle, case, 12, K, E, nlocal=nlocal, newton_pair=newton, eflag=True, vflag=True)
+    fs = np.abs(o["f"]).max()
+    assert np.abs(f - o["f"]).max() < 1e-9 * fs and np.abs(tq - o["torque"]).max() < 1e-9 * max(fs, np.abs(o["torque"]).max())
+    assert abs(eng - o["eng_virial"][0]) < 1e-9 * o["eng_virial"][0]
+    # a shorter list on the same context: the reverse index follows
+    h = len(case["ilist"]) // 2
+    sub = dict(case)
+    sub["ilist"], sub["offsets"], sub["jlist"] = case["ilist"][:h], case["offsets"][:h + 1], case["jlist"][:case["offsets"][h]]
+    sp.set_neighbors_csr(sub["ilist"], sub["offsets"], sub["jlist"])
+    f2, tq2, _, _ = sp.compute(nlocal, b["x"], b["quat"], b["type"], b["shtype"], newton_pair=newton)
+    o2 = oracle_compute(oracle, sub, 12, K, E, nlocal=nlocal, newton_pair=newton)
+    assert np.abs(f2 - o2["f"]).max() < 1e-9 * fs
+    # accumulation into non-zero arrays, like the atomics
+    f0 = np.full_like(f2, 0.25)
+    t0 = np.full_like(f2, -0.5)
+    sp.compute(nlocal, b["x"], b["quat"], b["type"], b["shtype"], newton_pair=newton, f=f0, torque=t0)
+    assert np.abs(f0 - 0.25 - f2).max() < 1e-12 * fs and np.abs(t0 + 0.5 - tq2).max() < 1e-12 * fs
+    sp.close()
+
+
+def test_device_resident_trajectories_are_bitwise_reproducible():
+    """Two device-resident runs of the same periodic bed (device neighbour build, rebuilds, ghosts): identical bits with
+    the mode on."""
+    import torch
+    from shpair import ShPair, shapes, bed
+    from shpair.run import DeviceRun
+    lmax, nq = 4, 8
+    shp = [shapes.random_shape(lmax, 400 + s, amp=0.2) for s in range(2)]
+    pts, lo, hi = bed.periodic_hcp(3000, 1.9, (1, 1, 1))
+    rng = np.random.default_rng(5)
+    n = pts.shape[0]
+    x = pts + rng.uniform(-0.15, 0.15, pts.shape)
+    quat = bed.random_quaternions(n, rng)
+    sht = rng.integers(0, 2, n).astype(np.int32)
+    out = []
+    for _ in range(2):
+        sp = ShPair(0)
+        sp.settings(nq)
+        sp.set_ntypes(1, 2)
+        for s, a in enumerate(shp):
+            sp.set_shape(s, lmax, a)
+        sp.coeff(1, 1, 400.0, 1.25)
+        sp.set_option("deterministic", 1)
+        run = DeviceRun(sp, x, quat, sht, lo, hi, (1, 1, 1), 0.2, dt=2e-3)
+        run.run(150)
+        torch.cuda.synchronize()
+        out.append((run.x[:n].cpu().numpy().copy(), run.q[:n].cpu().numpy().copy(), run.builds))
+        sp.close()
+    assert out[0][2] == out[1][2] and out[0][2] > 1           # rebuilds happened
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])

@@ -23,6 +23,7 @@ ap.add_argument("--wpb", type=int, nargs="*", default=[0], help="waves per workg
 ap.add_argument("--ring-rows", type=int, nargs="*", default=[0], help="one value per lib (0 = library default)")
 ap.add_argument("--jpoly", type=int, nargs="*", default=[-1], help="one value per lib: the 'jpoly' option (-1 = leave the default)")
 ap.add_argument("--lds-pad", type=int, nargs="*", default=[0], help="one value per lib: unused LDS bytes per wave (occupancy experiments)")
+ap.add_argument("--det", type=int, nargs="*", default=[0], help="one value per lib: the 'deterministic' option")
 ap.add_argument("--split", type=int, nargs="*", default=[-1], help="one value per lib: the 'split' option (two waves per pair; -1 = leave the default)")
 a = ap.parse_args()
 
@@ -39,6 +40,9 @@ wp = (a.wpb * len(ctxs))[:len(ctxs)] if len(a.wpb) == 1 else a.wpb
 jp = (a.jpoly * len(ctxs))[:len(ctxs)] if len(a.jpoly) == 1 else a.jpoly
 lp = (a.lds_pad * len(ctxs))[:len(ctxs)] if len(a.lds_pad) == 1 else a.lds_pad
 spl = (a.split * len(ctxs))[:len(ctxs)] if len(a.split) == 1 else a.split
+det = (a.det * len(ctxs))[:len(ctxs)] if len(a.det) == 1 else a.det
+for sp, dv in zip(ctxs, det):
+    sp.set_option("deterministic", dv)
 for sp, rows, w, j, pad, sv in zip(ctxs, rr, wp, jp, lp, spl):
     if j >= 0:
         sp.set_option("jpoly", j)
@@ -67,7 +71,7 @@ ty = torch.from_numpy(b["type"]).to(dev)
 sh = torch.from_numpy(b["shtype"]).to(dev)
 f = torch.zeros(a.n, 3, dtype=torch.float64, device=dev)
 tq = torch.zeros_like(f)
-a.libs = [f"{lib}#{rows}w{w}j{j}p{pad}s{sv}" for lib, rows, w, j, pad, sv in zip(a.libs, rr, wp, jp, lp, spl)]
+a.libs = [f"{lib}#{rows}w{w}j{j}p{pad}s{sv}d{dv}" for lib, rows, w, j, pad, sv, dv in zip(a.libs, rr, wp, jp, lp, spl, det)]
 res = {lib: [] for lib in a.libs}
 fref = None
 for r in range(a.rounds + 1):
