@@ -22,6 +22,8 @@
 #ifndef SHPAIR_H
 #define SHPAIR_H
 
+#include <stddef.h>
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -119,6 +121,16 @@ int shpair_set_neighbors_device(shpair_ctx *ctx, int inum, const int *ilist_dev,
 int shpair_compute(shpair_ctx *ctx, int nlocal, int nghost, const double *x, const double *quat,
                    const int *type, const int *shtype, int newton_pair, int eflag, int vflag,
                    double *f, double *torque, double *eng_vdwl, double *virial);
+
+/* Optional, for hosts that call shpair_compute() every step with the SAME arrays (LAMMPS: atom->x, f, torque and the
+ * per-atom vectors stay where they are until atom->nmax grows): page-lock a caller-owned array (hipHostRegister), so
+ * that the per-call copies are direct DMA at PCIe rate (16 MB per call at 100k atoms: ~0.25 ms) instead of the
+ * runtime's staged copy of pageable memory, and the upload of f / torque overlaps the set-up kernels.  CONTRACT: the
+ * range [ptr, ptr + bytes) stays allocated until shpair_unpin_host(ptr), a shpair_pin_host() of the same ptr with another
+ * length, or shpair_destroy(); when the host reallocates an array (nmax changed) it unpins the old pointer — also if the
+ * memory is already gone — and pins the new one.  Pinning is never required: unpinned arrays take the staged path. */
+int shpair_pin_host(shpair_ctx *ctx, void *ptr, size_t bytes);
+int shpair_unpin_host(shpair_ctx *ctx, void *ptr);
 
 /* Device-pointer form: all arrays already resident in HBM (the measured
  * path). Same layout and ADD semantics; ev_dev (nullable) is 7 doubles on the

@@ -1799,7 +1799,7 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
 }
 
 // Host-callable launcher, one per compiled order (pair_kernels_L*.hip).
-typedef void (*pair_launch_fn)(const PairParams&, bool needv, hipStream_t);
+typedef void (*pair_launch_fn)(const PairParams&, bool needv, hipStream_t, hipEvent_t wait_before_contact);
 // Register / LDS footprint of the kernel that launch would pick (occupancy evidence for bench.py).
 typedef hipError_t (*pair_attr_fn)(bool needv, bool weighted, hipFuncAttributes*, bool jpoly, bool split);
 
@@ -1836,8 +1836,10 @@ static inline void launch_contact_one(K kern, const dim3 grid, const dim3 block,
   hipLaunchKernelGGL(kern, grid, block, lds, st, P);
 }
 
+// wait_before_contact (nullable): an event the CONTACT kernel waits for, not the rotation kernel in front of it — the
+// host-pointer entry point uploads f and torque on a second stream beside the set-up and rotation kernels.
 template <int L>
-void launch_pair_contact(const PairParams& P, bool needv, hipStream_t st)
+void launch_pair_contact(const PairParams& P, bool needv, hipStream_t st, hipEvent_t wait_before_contact = nullptr)
 {
   if (P.npairs <= 0) return;
   const int wpb = P.waves_per_block;
@@ -1845,6 +1847,7 @@ void launch_pair_contact(const PairParams& P, bool needv, hipStream_t st)
   const size_t lds = (size_t)wpb * P.wave_lds_bytes;
   if (P.rule) {
     // SPEC §2.8; one instantiation (with the volume path) serves both force laws
+    if (wait_before_contact) (void)hipStreamWaitEvent(st, wait_before_contact, 0);
     if constexpr (L >= 0) launch_contact_one(pair_contact_kernel<L, true, true>, grid, block, lds, st, P);
     return;
   }
@@ -1857,6 +1860,7 @@ void launch_pair_contact(const PairParams& P, bool needv, hipStream_t st)
       else
         hipLaunchKernelGGL((pair_rotate_lane_kernel<L>), dim3((2 * (unsigned)P.npairs + 63) / 64), dim3(64),
                            RotLaneLds<L>::bytes(), st, P, const_cast<double*>(P.rot));
+      if (wait_before_contact) (void)hipStreamWaitEvent(st, wait_before_contact, 0);
       if constexpr (split_compiled(L)) {
         if (P.split) {   // two waves per pair: the workgroup is the pair
           const dim3 grid2(P.npairs), block2(128);
@@ -1870,6 +1874,7 @@ void launch_pair_contact(const PairParams& P, bool needv, hipStream_t st)
       return;
     }
   }
+  if (wait_before_contact) (void)hipStreamWaitEvent(st, wait_before_contact, 0);
   if (needv) launch_contact_one(pair_contact_kernel<L, true>, grid, block, lds, st, P);
   else launch_contact_one(pair_contact_kernel<L, false>, grid, block, lds, st, P);
 }

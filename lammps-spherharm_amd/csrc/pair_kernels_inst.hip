@@ -18,6 +18,6 @@
 #endif
 
 namespace shp {
-void SHP_FN(const PairParams& P, bool needv, hipStream_t st) { launch_pair_contact<SHP_L>(P, needv, st); }
+void SHP_FN(const PairParams& P, bool needv, hipStream_t st, hipEvent_t w) { launch_pair_contact<SHP_L>(P, needv, st, w); }
 hipError_t SHP_AFN(bool needv, bool weighted, hipFuncAttributes* a, bool jpoly, bool split) { return pair_contact_attributes<SHP_L>(needv, weighted, a, jpoly, split); }
 }  // namespace shp

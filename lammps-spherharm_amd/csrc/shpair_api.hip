@@ -24,12 +24,12 @@
 #include "sh_tables.hpp"
 
 namespace shp {
-#define SHP_DECL(L) void shp_launch_L##L(const PairParams&, bool, hipStream_t); \
+#define SHP_DECL(L) void shp_launch_L##L(const PairParams&, bool, hipStream_t, hipEvent_t); \
   hipError_t shp_attr_L##L(bool, bool, hipFuncAttributes*, bool, bool);
 SHP_DECL(0) SHP_DECL(1) SHP_DECL(2) SHP_DECL(3) SHP_DECL(4) SHP_DECL(5) SHP_DECL(6)
 SHP_DECL(7) SHP_DECL(8) SHP_DECL(9) SHP_DECL(10) SHP_DECL(11) SHP_DECL(12)
 #undef SHP_DECL
-void shp_launch_Lrt(const PairParams&, bool, hipStream_t);
+void shp_launch_Lrt(const PairParams&, bool, hipStream_t, hipEvent_t);
 hipError_t shp_attr_Lrt(bool, bool, hipFuncAttributes*, bool, bool);
 
 constexpr int kMaxUnrolledL = 12;
@@ -105,6 +105,8 @@ int shpair_create(shpair_ctx** out, int device_id)
   if (!c) return SHPAIR_ENOMEM;
   c->device = device_id;
   if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
+      hipStreamCreateWithFlags(&c->stream_up, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_up, hipEventDisableTiming) != hipSuccess ||
       hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess ||
       hipEventCreate(&c->evA) != hipSuccess || hipEventCreate(&c->evB) != hipSuccess ||
       hipHostMalloc((void**)&c->h_ev, 7 * sizeof(double)) != hipSuccess ||
@@ -140,6 +142,10 @@ void shpair_destroy(shpair_ctx* c)
   if (c->ev1) (void)hipEventDestroy(c->ev1);
   if (c->evA) (void)hipEventDestroy(c->evA);
   if (c->evB) (void)hipEventDestroy(c->evB);
+  for (auto& pr : c->pinned) (void)hipHostUnregister(pr.first);
+  (void)hipGetLastError();
+  if (c->ev_up) (void)hipEventDestroy(c->ev_up);
+  if (c->stream_up) (void)hipStreamDestroy(c->stream_up);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -803,9 +809,9 @@ int shpair_compute_device(shpair_ctx* c, int nlocal, int nghost, const double* x
   launch_pair_setup(P, c->d_rec.p, c->d_rec_i.p, st);
   if (c->lmax <= kMaxUnrolledL && c->opt_variant != 1) {
     P.coef = c->d_coefm.p;  // compiled orders read the monomial (Horner) table
-    kLaunch[c->lmax](P, needv, st);
+    kLaunch[c->lmax](P, needv, st, c->pre_contact_wait);
   } else {
-    shp_launch_Lrt(P, needv, st);
+    shp_launch_Lrt(P, needv, st, c->pre_contact_wait);
   }
   HIPCHK(c, hipGetLastError());
   if (c->opt_deterministic) {
@@ -882,11 +888,21 @@ int shpair_compute(shpair_ctx* c, int nlocal, int nghost, const double* x, const
   // travel up, the kernel accumulates into them on the device, and the sums overwrite the host arrays.  Measured at
   // 100k atoms against staging zeros and adding on the host (interleaved runs, tools/gpu_check.py): call wall time
   // minus kernel time 0.45 ms instead of 0.52 ms; 16 MB cross PCIe per call either way.
-  HIPCHK(c, hipMemcpyAsync(c->d_f.p, f, 3 * nall * sizeof(double), hipMemcpyHostToDevice, st));
-  HIPCHK(c, hipMemcpyAsync(c->d_torque.p, torque, 3 * nall * sizeof(double), hipMemcpyHostToDevice, st));
+  // They go up on a second stream, beside the set-up and rotation kernels, which do not touch them: the contact kernel
+  // (its epilogue's atomics; the gather of the deterministic mode) waits for the event.  With the caller's arrays
+  // registered (shpair_pin_host) the copies are true asynchronous DMA and the overlap is real; pageable memory is
+  // staged by the runtime and mostly serialises.
+  HIPCHK(c, hipEventRecord(c->ev_up, st));                 // the previous call's read-back of d_f / d_torque is long done;
+  HIPCHK(c, hipStreamWaitEvent(c->stream_up, c->ev_up, 0));   // orders the second stream behind this one all the same
+  HIPCHK(c, hipMemcpyAsync(c->d_f.p, f, 3 * nall * sizeof(double), hipMemcpyHostToDevice, c->stream_up));
+  HIPCHK(c, hipMemcpyAsync(c->d_torque.p, torque, 3 * nall * sizeof(double), hipMemcpyHostToDevice, c->stream_up));
+  HIPCHK(c, hipEventRecord(c->ev_up, c->stream_up));
   HIPCHK(c, hipMemsetAsync(c->d_ev.p, 0, 7 * sizeof(double), st));
+  c->pre_contact_wait = c->ev_up;
   const int rc = shpair_compute_device(c, nlocal, nghost, c->d_x.p, c->d_quat.p, c->d_type.p, c->d_shtype.p,
                                        newton_pair, eflag, vflag, c->d_f.p, c->d_torque.p, c->d_ev.p, st);
+  c->pre_contact_wait = nullptr;
+  HIPCHK(c, hipStreamWaitEvent(st, c->ev_up, 0));   // whatever path the launch took (no pairs, an early error): st is behind the uploads
   if (rc) return rc;
   if (pe) HIPCHK(c, hipMemcpyAsync(c->eatom_host, c->d_eatom.p, nall * sizeof(double), hipMemcpyDeviceToHost, st));
   if (pv) HIPCHK(c, hipMemcpyAsync(c->vatom_host, c->d_vatom.p, 6 * nall * sizeof(double), hipMemcpyDeviceToHost, st));
@@ -940,6 +956,48 @@ int shpair_get_kernel_info(shpair_ctx* c, shpair_kernel_info* out)
   out->waves_per_cu = cu;
   out->family = (compiled && c->last_jpoly) ? 1 : 0;
   return SHPAIR_OK;
+}
+
+// Page-locks a caller-owned host array for the host-pointer entry point (hipHostRegister): hipMemcpyAsync of a
+// registered range is a direct DMA at PCIe rate instead of the runtime's staged copy of pageable memory.
+int shpair_pin_host(shpair_ctx* c, void* ptr, size_t bytes)
+{
+  if (!c) return SHPAIR_EINVAL;
+  if (!ptr || bytes == 0) CTX_FAIL(c, SHPAIR_EINVAL, "pin_host: null pointer or zero size");
+  HIPCHK(c, hipSetDevice(c->device));
+  for (auto& pr : c->pinned)
+    if (pr.first == ptr) {
+      if (pr.second == bytes) return SHPAIR_OK;
+      (void)hipHostUnregister(ptr);   // same start, another length: the array was reallocated in place
+      (void)hipGetLastError();
+      pr = c->pinned.back();
+      c->pinned.pop_back();
+      break;
+    }
+  const hipError_t e = hipHostRegister(ptr, bytes, hipHostRegisterDefault);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    CTX_FAIL(c, SHPAIR_EHIP, "hipHostRegister(%p, %zu) failed: %s (the copies fall back to the runtime's staging)", ptr, bytes,
+             hipGetErrorString(e));
+  }
+  c->pinned.emplace_back(ptr, bytes);
+  return SHPAIR_OK;
+}
+
+int shpair_unpin_host(shpair_ctx* c, void* ptr)
+{
+  if (!c) return SHPAIR_EINVAL;
+  HIPCHK(c, hipSetDevice(c->device));
+  if (c->stream) HIPCHK(c, hipStreamSynchronize(c->stream));
+  for (size_t k = 0; k < c->pinned.size(); ++k)
+    if (c->pinned[k].first == ptr) {
+      (void)hipHostUnregister(ptr);
+      (void)hipGetLastError();
+      c->pinned[k] = c->pinned.back();
+      c->pinned.pop_back();
+      return SHPAIR_OK;
+    }
+  CTX_FAIL(c, SHPAIR_EINVAL, "unpin_host: %p was not pinned through this context", ptr);
 }
 
 int shpair_set_peratom_output(shpair_ctx* c, double* eatom_dev, double* vatom_dev)

@@ -47,6 +47,10 @@ struct shstep_state;  // shstep_api.hip
 struct shpair_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
+  hipStream_t stream_up = nullptr;   // host-pointer form: f / torque go up here beside the set-up and rotation kernels
+  hipEvent_t ev_up = nullptr;        // ... and the contact kernel waits for this
+  hipEvent_t pre_contact_wait = nullptr;   // set by shpair_compute for the duration of its call (launch_pair_contact)
+  std::vector<std::pair<void*, size_t>> pinned;   // shpair_pin_host registrations
   std::string err;
 
   int nq = 16;

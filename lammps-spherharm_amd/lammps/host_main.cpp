@@ -67,6 +67,7 @@ int main(int argc, char **argv)
   Atom *atom = lmp.atom;
   atom->ntypes = ntypes;
   atom->nlocal = nlocal;
+  atom->nmax = nall;
   atom->nghost = nghost;
   atom->x = x;
   atom->f = f;

@@ -50,6 +50,10 @@ PairSH::PairSH(LAMMPS *lmp) :
   // forwards them itself (Comm::forward_comm(this), 4 doubles per ghost) at the top of compute().  An atom style
   // that carries the quaternion (atom->extract("quat")) is expected to pack it in its own pack_comm, as LAMMPS'
   // aspherical atom styles do.
+  for (int k = 0; k < 6; k++) {
+    pinned_ptr[k] = nullptr;
+    pinned_bytes[k] = 0;
+  }
   comm_forward = 4;
   single_enable = 0;
   restartinfo = 0;
@@ -59,12 +63,27 @@ PairSH::PairSH(LAMMPS *lmp) :
 
 PairSH::~PairSH()
 {
-  if (ctx) shpair_destroy(ctx);
+  if (ctx) shpair_destroy(ctx);    // also releases the page locks
   if (allocated) {
     memory->destroy(setflag);
     memory->destroy(cutsq);
     memory->destroy(kn);
     memory->destroy(exponent);
+  }
+}
+
+/* page-lock one of LAMMPS' per-atom arrays for the per-step copies; a failure is not an error (the copies are then
+   staged by the HIP runtime, as for any pageable memory) */
+
+void PairSH::pin(int slot, void *ptr, size_t bytes)
+{
+  if (pinned_ptr[slot] == ptr && pinned_bytes[slot] == bytes) return;
+  if (pinned_ptr[slot]) shpair_unpin_host(ctx, pinned_ptr[slot]);    // the old array: LAMMPS has reallocated it
+  pinned_ptr[slot] = nullptr;
+  pinned_bytes[slot] = 0;
+  if (ptr && bytes && shpair_pin_host(ctx, ptr, bytes) == SHPAIR_OK) {
+    pinned_ptr[slot] = ptr;
+    pinned_bytes[slot] = bytes;
   }
 }
 
@@ -322,6 +341,16 @@ void PairSH::compute(int eflag, int vflag)
   double *q0 = nall ? quat[0] : nullptr;
   double *f0 = nall ? atom->f[0] : nullptr;
   double *t0 = nall ? atom->torque[0] : nullptr;
+  if (nall) {
+    // the arrays keep their place until atom->nmax grows: page-locked once, copied by DMA every step
+    const size_t rows = (size_t) (atom->nmax > nall ? atom->nmax : nall);
+    pin(0, x0, rows * 3 * sizeof(double));
+    pin(1, q0, rows * 4 * sizeof(double));
+    pin(2, f0, rows * 3 * sizeof(double));
+    pin(3, t0, rows * 3 * sizeof(double));
+    pin(4, atom->type, rows * sizeof(int));
+    pin(5, shtype, rows * sizeof(int));
+  }
   // per-atom tallies (compute pe/atom, stress/atom): Pair's own eatom / vatom arrays, sized by ev_init
   check(shpair_set_peratom_host(ctx, (eflag_atom && nall) ? eatom : nullptr, (vflag_atom && nall) ? vatom[0] : nullptr),
         "shpair_set_peratom_host");

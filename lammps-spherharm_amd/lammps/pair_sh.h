@@ -24,6 +24,7 @@ PairStyle(sh/hip,PairSH);
 
 #include "pair.h"
 
+#include <cstddef>
 #include <string>
 #include <vector>
 
@@ -56,6 +57,12 @@ class PairSH : public Pair {
   bigint last_neigh_build;              // neighbor->lastcall of the list already uploaded
   double **quat_comm;                   // the array forward communication packs from / unpacks into
   int quat_is_custom;                   // orientation comes from fix property/atom: ghosts must be refreshed here
+
+  // host arrays page-locked for the per-step copies (shpair_pin_host): x, quat, f, torque, type, shtype — re-pinned
+  // when LAMMPS reallocates them (the pointer or atom->nmax changed)
+  void *pinned_ptr[6];
+  size_t pinned_bytes[6];
+  void pin(int slot, void *ptr, size_t bytes);
 
   void allocate();
   void load_shapes();

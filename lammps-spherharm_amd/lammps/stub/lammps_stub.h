@@ -53,6 +53,7 @@ class Memory {
 class Atom {
  public:
   int ntypes = 1, nlocal = 0, nghost = 0;
+  int nmax = 0;    // rows the per-atom arrays are allocated for (Atom::nmax)
   double **x = nullptr, **f = nullptr, **torque = nullptr, **v = nullptr, **angmom = nullptr;
   int *type = nullptr, *mask = nullptr;
   int firstgroup = -1, nfirst = 0;

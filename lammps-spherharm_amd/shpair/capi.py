@@ -108,6 +108,8 @@ SYMBOLS = {
     "shpair_set_pair_output": (C.c_int, [C.c_void_p, C.c_void_p]),
     "shpair_set_peratom_output": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "shpair_set_peratom_host": (C.c_int, [C.c_void_p, _dp, _dp]),
+    "shpair_pin_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "shpair_unpin_host": (C.c_int, [C.c_void_p, C.c_void_p]),
     "shpair_fp64_peak": (C.c_int, [C.c_void_p, C.c_int, C.c_double, _dp, _dp]),
     "shpair_get_stream": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
     "shpair_synchronize": (C.c_int, [C.c_void_p]),
@@ -331,6 +333,14 @@ class ShPair:
                                            f.ctypes.data_as(_dp), torque.ctypes.data_as(_dp),
                                            C.byref(eng), vir.ctypes.data_as(_dp)))
         return f, torque, eng.value, vir
+
+    def pin_host(self, array):
+        """shpair_pin_host: page-locks a numpy array that will be handed to compute() repeatedly (it must outlive the
+        pin; unpin_host(array) or close() releases it)."""
+        self._chk(self._lib.shpair_pin_host(self._h, C.c_void_p(array.ctypes.data), C.c_size_t(array.nbytes)))
+
+    def unpin_host(self, array):
+        self._chk(self._lib.shpair_unpin_host(self._h, C.c_void_p(array.ctypes.data)))
 
     def compute_device(self, nlocal, nghost, x, quat, type_, shtype, f, torque, newton_pair=True,
                        eflag=False, vflag=False, ev=None, stream=None):

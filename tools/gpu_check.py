@@ -42,6 +42,26 @@ def run(n, lmax, nq, nshapes, expo, check, force_volume=0, eflag=False):
         f, tq, eng, vir = sp.compute(n, b["x"], b["quat"], b["type"], b["shtype"], eflag=eflag, vflag=eflag, f=fbuf, torque=tbuf)
         walls.append(1e3 * (time.perf_counter() - tw))
         st = sp.stats()
+    if n >= 50000:
+        # the same calls with the caller's arrays page-locked (shpair_pin_host): what PairSH does with LAMMPS' arrays
+        arrs = [b["x"], b["quat"], b["type"], b["shtype"], fbuf, tbuf]
+        for a_ in arrs:
+            sp.pin_host(a_)
+        pw = []
+        for _ in range(7):
+            fbuf[:] = 0.0
+            tbuf[:] = 0.0
+            tw = time.perf_counter()
+            sp.compute(n, b["x"], b["quat"], b["type"], b["shtype"], eflag=eflag, vflag=eflag, f=fbuf, torque=tbuf)
+            pw.append(1e3 * (time.perf_counter() - tw))
+            stp = sp.stats()
+        for a_ in arrs:
+            sp.unpin_host(a_)
+        assert np.array_equal(fbuf, f) or np.abs(fbuf - f).max() < 1e-12 * np.abs(f).max()
+        print(f"   host-pointer call at n={n}: pageable wall {min(walls):.3f} ms, pinned wall {min(pw):.3f} ms, kernels "
+              f"{stp['kernel_ms']:.3f} ms -> wall - kernel: pageable {min(walls) - st['kernel_ms']:.3f}, pinned "
+              f"{min(pw) - stp['kernel_ms']:.3f} ms ({(b['x'].nbytes + b['quat'].nbytes + 2 * fbuf.nbytes + b['type'].nbytes * 2) / 1e6:.1f} MB up, "
+              f"{2 * fbuf.nbytes / 1e6:.1f} MB down)", flush=True)
     print(f"n={n} L={lmax} nq={nq} nshapes={nshapes} expo={expo} fv={force_volume} e={eflag}: pairs={jl.size} "
           f"contact={ncontact} touching={st['n_touching']} kernel_ms={st['kernel_ms']:.3f} "
           f"total_ms={st['total_ms']:.3f} wall_ms={min(walls):.3f} first_call_s={t1 - t0:.2f} "
