@@ -21,8 +21,10 @@
 // Per-pair data is wave-uniform: particle j's coefficients (monomial form, Horner,
 // sh_device.hpp) arrive as scalar loads, the pair frame, the rotation's work vectors,
 // the ring tables and the queue sit in per-wave LDS.  The seven integrals (V, S_n,
-// T_n) are reduced with cross-lane shuffles and lane 0 applies the force law and
-// issues the FP64 atomics.  One wave per workgroup.
+// T_n) are transposed through LDS and added in two levels; lanes 0-5 then own one
+// component of the force / torque each, apply the force law and issue ONE 6-lane FP64
+// atomic per atom (or, in the deterministic mode, one store per pair: det_kernels.hpp).
+// One wave per workgroup — or, for large tables, two waves per pair (pair_lds_layout2).
 // No MFMA: the work is polynomial evaluation per node, FP64 VALU bound.
 // Two kernel families differ in how particle j's radius is evaluated (template parameter JPT, chosen per (L, n_q) by
 // shpair_api.hip use_jpoly): 0 in j's body frame from scalar-fed monomial coefficients (sh_device.hpp); 1 — the
@@ -73,9 +75,8 @@ struct PairParams {
   const double* jval;    // first stage, ELL: (2 lmax + 4)(lmax + 1) rows x (lmax/2+1) values (sh_tables.cpp build_jpoly_ell)
   const int* jcol;       // ... and indices into the rotated coefficient vector
   const double* trigj;   // (cos, sin)(m psi_l), m = 0..lmax + 1, of the first nq azimuths, l-major
-  const double* rot;     // compiled orders: [2 w + which][(lmax+1)^2] rotated, scaled coefficient vectors of slot w's
-                         // particles (which 0: i, 1: j), written by pair_rotate_kernel
-  int rot_by_wave;       // 1: pair_rotate_kernel (a wave per rotation) instead of pair_rotate_lane_kernel (diagnostic)
+  const double* rot;     // compiled orders: [2 w + which][rot_stride(lmax)] rotated, scaled coefficient vectors of slot
+                         // w's particles (which 0: i, 1: j), written by pair_rotate_lane_kernel
   int jpoly;             // 1: the pair records carry the Euler angles of j's frame in the slots of FR_BJ1 / FR_BJ2
   int split;             // 1: two waves per pair (pair_contact_kernel<..., WPP = 2>); wave_lds_bytes is then the PAIR's LDS
   // per-pair records written by pair_setup_kernel (pair_setup.hpp), read here instead of redoing the scalar set-up on
@@ -127,7 +128,7 @@ constexpr int kPairErrCoincident = 4;   // two centres coincide (rho = 0) or the
 #define SHP_MIN_WAVES(L, NEEDV) \
   ((NEEDV) ? (((L) == 0 || (L) == 1 || (L) == 6) ? 6 : 5) : (((L) >= 0 && (L) <= 6) ? 6 : 5))
 #endif
-// kernels that evaluate particle j from per-azimuth polynomials (JPT): a lane's row sits in 4L + 2 registers
+// kernels that evaluate particle j from per-azimuth polynomials (JPT): the rows of j's table are read from LDS
 #ifndef SHP_JMIN_WAVES
 #define SHP_JMIN_WAVES(L, NEEDV) (((L) <= 6) ? 5 : 4)
 #endif
@@ -170,7 +171,7 @@ enum { FR_BJ1 = 0, FR_BJ2 = 3, FR_BJC = 6, FR_DJ = 9, FR_E1 = 12, FR_E2 = 15, FR
 struct WaveLdsLayout {
   int trig, v0, v1, ring, qri, qrj, qp, bytes;  // offsets in doubles (qp: in doubles too), total bytes
   int qw;                                        // weighted rule only: the queued nodes' weights
-  int coef;                                      // SHP_COEF_LDS ablation build only
+  int coef;                                      // end of the queue region (the table of particle j starts here)
   int pj, gh;                                    // particle j's polynomials: first-stage scratch, per-azimuth table
   int glw;                                       // JPT kernels: the Gauss-Legendre weights (nqj doubles)
   int park;                                      // JPT kernels: 2 x 64 parked sums + 64 prefetched Gauss nodes (over the queue)
@@ -235,12 +236,8 @@ __host__ __device__ inline WaveLdsLayout wave_lds_layout(const int L, const int 
   }
   w.coef += w.coef & 1;
   w.gh = w.coef;   // per-azimuth polynomials of particle j: nqj rows, resident for the whole pair
-#ifdef SHP_COEF_LDS
-  w.bytes = 8 * (w.coef + sh_chunk_stride(L));
-#else
   w.glw = w.gh + jpoly_glw(L);   // weight of ring k at glw + k * jpoly_row(L)
   w.bytes = 8 * (w.gh + nqj * jpoly_row(L));
-#endif
   // the epilogue's reduction scratch lies behind the frame, over everything that is dead by then
   if (w.bytes < 8 * (kFrame + kRedDoubles)) w.bytes = 8 * (kFrame + kRedDoubles);
   w.bytes = (w.bytes + 15) & ~15;
@@ -285,17 +282,6 @@ __host__ __device__ inline WaveLdsLayout pair_lds_layout2(const int L, const int
 // instruction in the node loops, 27 % of them bank conflicts, the LDS pipe 83 % busy beside an 80 % busy VALU.
 typedef double v2d __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ v2d lds2(const double* p) { return *(const v2d*)__builtin_assume_aligned(p, 16); }
-// experiment switches (bit mask SHP_X): 1 eval2, 2 eval, 4 phase-1 ring, 8 grad — read as two doubles instead
-#ifndef SHP_X
-#define SHP_X 0
-#endif
-template <int BIT>
-__device__ __forceinline__ v2d lds2x(const double* p)
-{
-  if constexpr ((SHP_X & BIT) != 0) { v2d r; r[0] = p[0]; r[1] = p[1]; return r; }
-  else return lds2(p);
-}
-
 // TWO WAVES PER PAIR (template parameter WPP = 2 of pair_contact_kernel; JPT kernels): the workgroup is one pair, the
 // tables — frame, particle i's rotated vector, the ring rows, particle j's per-azimuth polynomials — are shared and
 // built by all 128 lanes, each wave classifies and integrates HALF of the azimuths (wave h the node pairs l, l + n_q
@@ -478,53 +464,17 @@ __device__ __forceinline__ void cap_frame_rotate(const PairParams& P, double* __
   // the rotated, scaled coefficients are now in v0
 }
 
-// The rotations as a kernel of their own (compiled orders): ONE WAVE PER (list slot, particle).  Inside the contact
-// kernel a rotation is a chain of five dependent table-load / LDS steps, ~4 500 cycles during which the wave holds its
-// ~120 registers and 8 KB of LDS and issues 85 instructions; with particle j rotated as well that was a third of the
-// contact kernel's time (ablation builds, round 2).  Here a wave needs 24 registers and 1.2 KB, forty of them fit a
-// CU, and the chains of different waves overlap.  Output: (L+1)^2 doubles per particle, 784 B per pair at L = 6, read
-// back by the contact kernel with two coalesced loads at its start.
-struct RotLds {
-  static __host__ __device__ constexpr int euler() { return 0; }
-  static __host__ __device__ constexpr int trig() { return 8; }
-  static __host__ __device__ int v0(const int L) { return 8 + 6 * (L + 1); }
-  static __host__ __device__ int v1(const int L) { return v0(L) + (L + 1) * (L + 1); }
-  static __host__ __device__ int bytes(const int L) { return (8 * (v1(L) + (L + 1) * (L + 1)) + 15) & ~15; }
-};
-constexpr int kRotWaves = 4;   // rotations per workgroup (one per wave): a quarter of the workgroup launches
-template <int L>
-__global__ void __launch_bounds__(64 * kRotWaves) pair_rotate_kernel(const PairParams P, double* __restrict__ rot)
-{
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_rot[];
-  const int lane = threadIdx.x & 63;
-  const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int LL = (L >= 0) ? L : P.lmax;
-  double* lw = (double*)(smem_rot + (size_t)wib * RotLds::bytes(LL));
-  const int task = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * kRotWaves)) + wib;   // 2 * slot + particle
-  if (task >= 2 * P.npairs) return;
-  const int w = task >> 1, which = task & 1;
-  const int* rid = P.rec_i + 4 * (size_t)w;
-  if (rid[0] == 0) return;   // no contact pair in this slot (or a shape index outside the table): nothing will read it
-  const int shape = rid[1 + which];
-  if (lane < 6) lw[lane] = P.rec[(size_t)kRecStride * w + (which ? FR_EULERJ : FR_EULER) + lane];
-  WaveLdsLayout W;
-  W.trig = RotLds::trig();
-  W.v0 = RotLds::v0(LL);
-  W.v1 = RotLds::v1(LL);
-  wave_lds_sync();
-  cap_frame_rotate<L>(P, lw, W, LL, shape, lane, RotLds::euler());
-  const int ns = (LL + 1) * (LL + 1);
-  double* out = rot + (size_t)task * ns;
-  for (int e = lane; e < ns; e += 64) out[e] = lw[W.v0 + e];
-}
-
-// The same rotations with ONE LANE PER ROTATION (compiled orders).  The wave-per-rotation form above is a chain of
-// five table-load / LDS steps per rotation, ~10 000 cycles of latency for 85 instructions: 0.6 ms per launch at the
-// headline however many waves are resident.  Here a wave carries 64 rotations through the same five steps; the
+// The rotations as a kernel of their own (compiled orders), ONE LANE PER ROTATION.  Inside the contact kernel a
+// rotation is a chain of five dependent table-load / LDS steps, ~10 000 cycles of latency for 85 instructions during
+// which the wave holds its registers and LDS (a wave-per-rotation kernel measured 0.6 ms per launch at the headline
+// however many waves were resident: round 2, profiles/r02_w_*).  Here a wave carries 64 rotations through the same five steps; the
 // rotation is block diagonal in l, so a lane's block of 2l + 1 values lives in LDS as [element][lane] (conflict
 // free) between the steps that gather (X^T, X) and in registers for those that do not (the Z turns; cos/sin(m angle) of
 // the three angles sit in registers too), the X matrices are wave-uniform (scalar loads, SGPR operands) and every
 // loop is wave-uniform: ~20 instructions per rotation.  The arithmetic and its order are those of cap_frame_rotate.
+// Doubles between the rotated vectors of consecutive rotations: (L+1)^2 rounded up to whole 64-byte lines, so that no
+// line is shared by two rotations' rows (392-byte rows at L = 6 straddled lines: WRITE_SIZE 1.46x the payload, round 2).
+__host__ __device__ constexpr int rot_stride(const int L) { return ((L + 1) * (L + 1) + 7) & ~7; }
 template <int L>
 struct RotLaneLds {
   static constexpr int NB = 2 * L + 1;
@@ -598,7 +548,7 @@ __device__ __forceinline__ void rotate_lane_block(const PairParams& P, double* _
   for (int it = 0; it < n; ++it) {
     const int idx = lane + 64 * it;   // < 64 n
     const int tk = idx / n, r = idx - tk * n;
-    if (task0 + tk < ntasks) rot[(size_t)(task0 + tk) * ns + base + r] = At[64 * r + tk];
+    if (task0 + tk < ntasks) rot[(size_t)(task0 + tk) * rot_stride(L) + base + r] = At[64 * r + tk];
   }
   wave_lds_sync();
   if constexpr (LB < L) rotate_lane_block<L, LB + 1>(P, sm, lane, cre, rot, task0, ntasks, T);
@@ -924,7 +874,7 @@ __device__ __forceinline__ double jpoly_eval(const double* __restrict__ row, con
   // 2L + 1 coefficients in L + 1 aligned 16-byte pairs (the second half of the last pair is the ring weight)
   v2d c[L + 1];
 #pragma unroll
-  for (int t = 0; t <= L; ++t) c[t] = lds2x<2>(row + 2 * t);
+  for (int t = 0; t <= L; ++t) c[t] = lds2(row + 2 * t);
   double g = c[0][0];
 #pragma unroll
   for (int t = 1; t <= L; ++t) g = fma(g, mu, c[t >> 1][t & 1]);
@@ -948,7 +898,7 @@ __device__ __forceinline__ void ring_grad_rec(const double* __restrict__ row, co
   double cm = c1, sm = s1;
 #pragma unroll
   for (int m = 1; m <= L; ++m) {
-    const v2d ab = lds2x<8>(row + 4 * m), dab = lds2x<8>(row + 4 * m + 2);   // two ds_read_b128 per order
+    const v2d ab = lds2(row + 4 * m), dab = lds2(row + 4 * m + 2);   // two ds_read_b128 per order
     const double A = ab[0], B = ab[1], dm = (double)m;
     rmu = fma(dab[0], cm, rmu);
     rmu = fma(dab[1], sm, rmu);
@@ -969,7 +919,7 @@ __device__ __forceinline__ void jpoly_eval2(const double* __restrict__ row, cons
 {
   v2d cc[L + 1];
 #pragma unroll
-  for (int t = 0; t <= L; ++t) cc[t] = lds2x<1>(row + 2 * t);
+  for (int t = 0; t <= L; ++t) cc[t] = lds2(row + 2 * t);
   const double c0 = cc[0][0];
   double ga = c0, gb = c0;
 #pragma unroll
@@ -1051,12 +1001,12 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
   const double recv = P.rec[(size_t)kRecStride * w + (lane < kRecUsed ? lane : 0)];
   if constexpr (JPT && L >= 0 && !WEIGHTED) {
     constexpr int ns = (L + 1) * (L + 1);
-    const double* rv = P.rot + (size_t)(2 * w) * ns;
+    const double* rv = P.rot + (size_t)(2 * w) * rot_stride(L);
 #pragma unroll
     for (int t = 0; t < NSL; ++t) {
       const int e = tid + NT * t;
       vi[t] = rv[e < ns ? e : 0];
-      vj[t] = rv[ns + (e < ns ? e : 0)];
+      vj[t] = rv[rot_stride(L) + (e < ns ? e : 0)];
     }
     pre.fetch(P, lane, P.nq);
   }
@@ -1116,18 +1066,9 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
 #endif
 
   const double* rc = P.rc;
-#ifndef SHP_COEF_LDS
+  // particle j's coefficients (body-frame family): wave-uniform, fetched with scalar loads.  (Staged in LDS instead —
+  // what north_star suggests — every term costs a broadcast ds_read: +40 % at L = 6, +87 % at L = 12, round 1 A/B.)
   const double* cwj = P.coef + (size_t)sj * P.cstride;
-#else
-  // ablation: coalesced copy of shape j's table into this wave's LDS, read back per term
-  {
-    const double* src = P.coef + (size_t)sj * P.cstride;
-    double* dst = SHP_LDS() + W.coef;
-    for (int t = lane; t < P.cstride; t += 64) dst[t] = src[t];
-    wave_lds_sync();
-  }
-#define cwj (SHP_LDS() + W.coef)
-#endif
   const int lrt = P.lmax;
   (void)rc; (void)lrt;
   const double* fr = SHP_LDS();
@@ -1336,19 +1277,19 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
       const int k = valid ? (int)(((unsigned)pp * magicr) >> 24) : k0;   // idle lanes read a resident row
       const int l = (valid ? pp - k * per_ring : 0) + half * per_ring;
       const double* row = fr + W.ring + (k - k0) * rowlen;
-      const v2d r01 = lds2x<16>(row);   // (A_k0, mu_k)
+      const v2d r01 = lds2(row);   // (A_k0, mu_k)
       const double mu = r01[1], sig = row[3];
       // r_i at the two azimuths: psi + pi changes the sign of the odd orders
       // cos/sin(m psi_l): the first order from the lane's row of particle j's table, the rest by angle addition
       const double* gr = fr + W.gh + l * jpoly_row(LJ);
       double re = r01[0], ro = 0.0;
       if constexpr (LJ >= 1) {
-        const v2d cs1 = lds2x<32>(gr + jpoly_trig(LJ));
+        const v2d cs1 = lds2(gr + jpoly_trig(LJ));
         const double c1 = cs1[0], s1 = cs1[1];
         double cm = c1, sm = s1;
 #pragma unroll
         for (int m = 1; m <= LJ; ++m) {
-          const v2d ab = lds2x<4>(row + 4 * m);
+          const v2d ab = lds2(row + 4 * m);
           const double A = ab[0], B = ab[1];
           if (m & 1) ro = fma(A, cm, fma(B, sm, ro));
           else re = fma(A, cm, fma(B, sm, re));
@@ -1647,7 +1588,7 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
       const double sg = (l >= nq) ? -1.0 : 1.0;
       const double* tg = fr + W.gh + (l >= nq ? l - nq : l) * jpoly_row(LJ) + jpoly_trig(LJ);
       if constexpr (LJ >= 1) {
-        const v2d cs1 = lds2x<64>(tg);
+        const v2d cs1 = lds2(tg);
         c1 = sg * cs1[0];
         s1 = sg * cs1[1];
       }
@@ -1715,9 +1656,6 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
   if (lane >= 6) return;
   fr = SHP_LDS();
 #undef SHP_LDS
-#ifdef SHP_COEF_LDS
-#undef cwj
-#endif
   const double* tot = fr + kFrame + 7 * kRedStride + 56;
   double* fcomp = (double*)tot + 7;
   const int comp = (lane >= 3) ? lane - 3 : lane;   // 0..2
@@ -1853,13 +1791,9 @@ void launch_pair_contact(const PairParams& P, bool needv, hipStream_t st, hipEve
   }
   if constexpr (L >= 0) {
     if (P.jpoly) {
-      // both particles' coefficient rotations, one wave each, then the contact kernel that reads them
-      if (P.rot_by_wave)
-        hipLaunchKernelGGL((pair_rotate_kernel<L>), dim3((2 * (unsigned)P.npairs + kRotWaves - 1) / kRotWaves),
-                           dim3(64 * kRotWaves), (size_t)kRotWaves * RotLds::bytes(L), st, P, const_cast<double*>(P.rot));
-      else
-        hipLaunchKernelGGL((pair_rotate_lane_kernel<L>), dim3((2 * (unsigned)P.npairs + 63) / 64), dim3(64),
-                           RotLaneLds<L>::bytes(), st, P, const_cast<double*>(P.rot));
+      // both particles' coefficient rotations, one lane each, then the contact kernel that reads them
+      hipLaunchKernelGGL((pair_rotate_lane_kernel<L>), dim3((2 * (unsigned)P.npairs + 63) / 64), dim3(64),
+                         RotLaneLds<L>::bytes(), st, P, const_cast<double*>(P.rot));
       if (wait_before_contact) (void)hipStreamWaitEvent(st, wait_before_contact, 0);
       if constexpr (split_compiled(L)) {
         if (P.split) {   // two waves per pair: the workgroup is the pair

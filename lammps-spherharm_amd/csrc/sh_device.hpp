@@ -39,20 +39,12 @@ namespace shp {
 // The result is typed as a constant-address-space (AS4) pointer: after the asm
 // the compiler no longer knows the pointer is global, and a generic pointer
 // would be read with per-lane flat_load into VGPRs instead of s_load.
-#ifndef SHP_COEF_LDS
 typedef const double __attribute__((address_space(4))) * cdptr;
 __device__ __forceinline__ cdptr launder_uniform(const double* p)
 {
   asm volatile("" : "+s"(p));
   return (cdptr)p;
 }
-#else
-// ABLATION BUILD ONLY (make ldscoef): particle j's coefficients are staged into
-// per-wave LDS at pair set-up, as BASELINE.json's north_star words it, and read back with
-// broadcast ds_read_b128.  The caller passes an LDS pointer that is already laundered per call.
-typedef const double* cdptr;
-__device__ __forceinline__ cdptr launder_uniform(const double* p) { return p; }
-#endif
 
 // Shape coefficients travel in chunks of 4 complex terms = one s_load_dwordx16
 // through the scalar data cache.  The load is an ordinary AS4 load (so the
@@ -68,11 +60,7 @@ __device__ __forceinline__ cdptr launder_uniform(const double* p) { return p; }
 constexpr int kChunk = 4;  // complex terms per scalar load
 typedef double sh_d8 __attribute__((ext_vector_type(2 * kChunk)));
 typedef sh_d8 sh_d8_u __attribute__((aligned(8)));
-#ifndef SHP_COEF_LDS
 typedef const sh_d8_u __attribute__((address_space(4))) * cd8ptr;
-#else
-typedef const sh_d8_u* cd8ptr;
-#endif
 __device__ __forceinline__ sh_d8 sload_chunk(const cdptr base, const int off)
 {
   return *(cd8ptr)(base + off);
@@ -88,13 +76,9 @@ struct ShAcc {
 // instructions per Horner step instead of one.
 __device__ __forceinline__ double horner_step(const double w, const double z, const double c)
 {
-#ifndef SHP_COEF_LDS
   double o;
   asm("v_fma_f64 %0, %1, %2, %3" : "=v"(o) : "v"(w), "v"(z), "s"(c));
   return o;
-#else
-  return fma(w, z, c);  // the coefficient is in a VGPR pair
-#endif
 }
 
 // w + c with the wave-uniform c as the SGPR operand of one v_add_f64.  Without it the compiler contracts the first
@@ -102,13 +86,9 @@ __device__ __forceinline__ double horner_step(const double w, const double z, co
 // v_fmac_f64 instead of a v_mul_f64 and a v_add_f64 (26 v_mov_b32 per radius evaluation at L = 6).
 __device__ __forceinline__ double sgpr_add(const double w, const double c)
 {
-#ifndef SHP_COEF_LDS
   double o;
   asm("v_add_f64 %0, %1, %2" : "=v"(o) : "v"(w), "s"(c));
   return o;
-#else
-  return w + c;
-#endif
 }
 
 // Compiled orders evaluate W_m(z) in MONOMIAL form by Horner (coefficients in descending powers,

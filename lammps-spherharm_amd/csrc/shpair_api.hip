@@ -438,7 +438,7 @@ hipError_t shp_size_pair_buffers(shpair_ctx* c, size_t np)
   for (int s = 0; s < c->nshapes; ++s)
     if (c->shapes[s].lmax > L) L = c->shapes[s].lmax;
   if (e == hipSuccess && L >= 0 && c->nq > 0) {
-    if (use_jpoly_at(c, L)) e = c->d_rot.ensure(np * 2 * (size_t)(L + 1) * (L + 1));
+    if (use_jpoly_at(c, L)) e = c->d_rot.ensure(np * 2 * (size_t)rot_stride(L));
   }
   return e;
 }
@@ -669,7 +669,6 @@ int shpair_compute_device(shpair_ctx* c, int nlocal, int nghost, const double* x
   const bool jpoly = use_jpoly(c);
   c->last_jpoly = jpoly;
   P.jpoly = jpoly ? 1 : 0;
-  P.rot_by_wave = (c->opt_jpoly_rot == 1) ? 1 : 0;
   const bool split = use_split(c, jpoly);
   c->last_split = split;
   P.split = split ? 1 : 0;
@@ -745,7 +744,7 @@ int shpair_compute_device(shpair_ctx* c, int nlocal, int nghost, const double* x
       if (wpb * wl.bytes > 160 * 1024) wpb = (160 * 1024) / wl.bytes;
     }
     if (split) wpb = 1;   // the workgroup is the pair; wave_lds_bytes its whole LDS
-    P.wave_lds_bytes = wl.bytes + ((c->opt_lds_pad > 0) ? (c->opt_lds_pad & ~15) : 0);   // lds_pad: occupancy experiments
+    P.wave_lds_bytes = wl.bytes;
     P.waves_per_block = wpb;
     P.ring_rows = rows;
     c->last_lds_bytes = P.wave_lds_bytes;
@@ -800,7 +799,7 @@ int shpair_compute_device(shpair_ctx* c, int nlocal, int nghost, const double* x
   P.rec = c->d_rec.p;
   P.rec_i = c->d_rec_i.p;
   if (jpoly) {   // grows only when the list or the order grew: sized by shpair_prepare_tables() ahead of a stream capture
-    HIPCHK(c, c->d_rot.ensure((size_t)c->npairs * 2 * (c->lmax + 1) * (c->lmax + 1)));
+    HIPCHK(c, c->d_rot.ensure((size_t)c->npairs * 2 * rot_stride(c->lmax)));
     P.rot = c->d_rot.p;
   } else {
     P.rot = nullptr;
@@ -1034,8 +1033,6 @@ int shpair_set_option(shpair_ctx* c, const char* key, int value)
     c->opt_deterministic = value ? 1 : 0;
     c->rev_dirty = true;
   }
-  else if (!strcmp(key, "jpoly_rot")) c->opt_jpoly_rot = value;
-  else if (!strcmp(key, "lds_pad")) c->opt_lds_pad = value;
   else if (!strcmp(key, "waves_per_block")) c->opt_wpb = value;
   else CTX_FAIL(c, SHPAIR_EINVAL, "unknown option '%s'", key);
   return SHPAIR_OK;

@@ -98,8 +98,6 @@ struct shpair_ctx {
   int opt_force_volume = 0, opt_timing = 0, opt_count = 0, opt_variant = 0, opt_ring_rows = 0, opt_wpb = 0, opt_rule = 0;
   int opt_jpoly = -1;      // 1 / 0: compiled orders evaluate particle j from per-azimuth polynomials or not; -1: by the
                            // measured rule (shpair_api.hip use_jpoly)
-  int opt_jpoly_rot = 0;   // 1: rotations by pair_rotate_kernel (diagnostic; default pair_rotate_lane_kernel)
-  int opt_lds_pad = 0;     // diagnostic: unused LDS bytes added to every wave's allocation (fewer resident waves)
   bool last_jpoly = false;
   // deterministic accumulation (det_kernels.hpp): per-slot results + reverse index (atom -> its list slots)
   int opt_deterministic = 0;

@@ -25,7 +25,7 @@ def test_no_kernel_spills_vector_registers_or_touches_scratch():
     # + the per-azimuth-polynomial variants of the compiled orders x {forces only, volume path}
     # + their two-waves-per-pair forms for L = 7..12 x {forces only, volume path}
     assert len(pair) == 13 * 3 + 2 + 13 * 2 + 6 * 2, len(pair)
-    assert len([k for k in ks if "pair_rotate_kernel" in k["symbol"]]) == 13
+    assert len([k for k in ks if "pair_rotate_lane_kernel" in k["symbol"]]) == 13
     assert len(ks) >= len(pair) + 20           # the integrator / list / halo kernels
     nominal = []
     for k in ks:

@@ -22,7 +22,6 @@ ap.add_argument("--rule", type=int, default=0, help="0 sharp, 1 weighted (docs/S
 ap.add_argument("--wpb", type=int, nargs="*", default=[0], help="waves per workgroup per lib (0 = default)")
 ap.add_argument("--ring-rows", type=int, nargs="*", default=[0], help="one value per lib (0 = library default)")
 ap.add_argument("--jpoly", type=int, nargs="*", default=[-1], help="one value per lib: the 'jpoly' option (-1 = leave the default)")
-ap.add_argument("--lds-pad", type=int, nargs="*", default=[0], help="one value per lib: unused LDS bytes per wave (occupancy experiments)")
 ap.add_argument("--det", type=int, nargs="*", default=[0], help="one value per lib: the 'deterministic' option")
 ap.add_argument("--split", type=int, nargs="*", default=[-1], help="one value per lib: the 'split' option (two waves per pair; -1 = leave the default)")
 a = ap.parse_args()
@@ -38,7 +37,7 @@ b = None
 rr = (a.ring_rows * len(ctxs))[:len(ctxs)] if len(a.ring_rows) == 1 else a.ring_rows
 wp = (a.wpb * len(ctxs))[:len(ctxs)] if len(a.wpb) == 1 else a.wpb
 jp = (a.jpoly * len(ctxs))[:len(ctxs)] if len(a.jpoly) == 1 else a.jpoly
-lp = (a.lds_pad * len(ctxs))[:len(ctxs)] if len(a.lds_pad) == 1 else a.lds_pad
+lp = [0] * len(ctxs)
 spl = (a.split * len(ctxs))[:len(ctxs)] if len(a.split) == 1 else a.split
 det = (a.det * len(ctxs))[:len(ctxs)] if len(a.det) == 1 else a.det
 for sp, dv in zip(ctxs, det):
@@ -48,8 +47,6 @@ for sp, rows, w, j, pad, sv in zip(ctxs, rr, wp, jp, lp, spl):
         sp.set_option("jpoly", j)
     if sv >= 0:
         sp.set_option("split", sv)
-    if pad:
-        sp.set_option("lds_pad", pad)
     sp.set_option("ring_rows", rows)
     sp.set_option("waves_per_block", w)
     sp.settings(a.nq)
