@@ -895,7 +895,10 @@ __device__ __forceinline__ void ring_grad_rec(const double* __restrict__ row, co
 {
   rmu = row[2];
   rpsi = 0.0;
-  double cm = c1, sm = s1;
+  // cos / sin((m + 1) psi) = 2 cos(psi) cos / sin(m psi) - cos / sin((m - 1) psi): ONE v_fma_f64 each (the angle
+  // addition form costs two; the three-term form loses ~m^2 ulp, 1e-14 at L = 12, far inside the 1e-9 bar)
+  double cm = c1, sm = s1, cp = 1.0, sp = 0.0;
+  const double tc = c1 + c1;
 #pragma unroll
   for (int m = 1; m <= L; ++m) {
     const v2d ab = lds2(row + 4 * m), dab = lds2(row + 4 * m + 2);   // two ds_read_b128 per order
@@ -905,7 +908,9 @@ __device__ __forceinline__ void ring_grad_rec(const double* __restrict__ row, co
     rpsi = fma(dm * B, cm, rpsi);
     rpsi = fma(-dm * A, sm, rpsi);
     if (m < L) {
-      const double c = fma(cm, c1, -(sm * s1)), s = fma(cm, s1, sm * c1);
+      const double c = fma(tc, cm, -cp), s = fma(tc, sm, -sp);
+      cp = cm;
+      sp = sm;
       cm = c;
       sm = s;
     }
@@ -1286,7 +1291,8 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
       if constexpr (LJ >= 1) {
         const v2d cs1 = lds2(gr + jpoly_trig(LJ));
         const double c1 = cs1[0], s1 = cs1[1];
-        double cm = c1, sm = s1;
+        double cm = c1, sm = s1, cp = 1.0, sp = 0.0;   // three-term recurrence: one v_fma_f64 per cos / sin (ring_grad_rec)
+        const double tc = c1 + c1;
 #pragma unroll
         for (int m = 1; m <= LJ; ++m) {
           const v2d ab = lds2(row + 4 * m);
@@ -1294,7 +1300,9 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
           if (m & 1) ro = fma(A, cm, fma(B, sm, ro));
           else re = fma(A, cm, fma(B, sm, re));
           if (m < LJ) {
-            const double c = fma(cm, c1, -(sm * s1)), s = fma(cm, s1, sm * c1);
+            const double c = fma(tc, cm, -cp), s = fma(tc, sm, -sp);
+            cp = cm;
+            sp = sm;
             cm = c;
             sm = s;
           }
