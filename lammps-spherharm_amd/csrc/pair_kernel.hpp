@@ -292,6 +292,13 @@ __device__ __forceinline__ v2d lds2(const double* p) { return *(const v2d*)__bui
 //   [epilogue scratch of both waves over everything behind the frame] | queue of wave 0 | queue of wave 1
 __host__ __device__ inline WaveLdsLayout pair_lds_layout2(const int L, const int rows, const int nq);
 
+// Wave votes as SCALAR mask arithmetic.  HIP's __any() goes through a 0 / 1 value per lane (v_cndmask + v_cmp, two
+// vector instructions per vote) and boolean algebra on lane predicates is materialised the same way; a ballot is the
+// compare's own SGPR pair, masks combine on the scalar unit, and lane_of() hands a mask back as a lane predicate
+// (s_and_saveexec on the mask itself).
+__device__ __forceinline__ bool wave_any(const bool p) { return __ballot(p) != 0ULL; }
+__device__ __forceinline__ bool lane_of(const unsigned long long mask) { return __builtin_amdgcn_inverse_ballot_w64(mask); }
+
 __device__ __forceinline__ unsigned launder_u32(unsigned v)
 {
   asm volatile("" : "+v"(v));
@@ -1187,7 +1194,7 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
         const double sN = s2 * inv;
         g0 = sN - fr[FR_RJ];  // outside B_j: the stand-in of SPEC §2.8 (>= 0)
         double rj0 = fr[FR_RJ];
-        if (__any(cand)) {  // wave-uniform
+        if (wave_any(cand)) {  // wave-uniform
           const double rj0e = sh_eval<L>(rc, cwj, lrt, q0 * inv, q1 * inv, q2 * inv);
           if (!szero) rj0 = rj0e;
           if (cand) g0 = szero ? -rj0 : sN - rj0;
@@ -1261,10 +1268,10 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
     // inside nodes in one slab, i.e. a deeply overlapping pair; rare), the slab is NOT consumed: what is queued is
     // drained as a (short) batch first and the slab is classified again with the queue empty.  (Until round 3 the
     // second half waited in five registers that were live through phase 2, which the kernel does not have.)
-#define SHP_PUSH(in, m_, pn, rin_, rjn_)                                                                              \
+#define SHP_PUSH(m_, pn, rin_, rjn_)                                                                                  \
     {                                                                                                                  \
       if (m_ != 0ULL) {                                                                                                \
-        if (in) {                                                                                                      \
+        if (lane_of(m_)) {                                                                                             \
           const int pos_ = (qhead + qcount + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m_ >> 32),                      \
                                                     __builtin_amdgcn_mbcnt_lo((unsigned)m_, 0u))) & (kQueue - 1);     \
           double* lq_ = SHP_LDS();                                                                                     \
@@ -1313,8 +1320,10 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
       const double qa0 = fma(ria, mu, -rho), qa1 = ria * sig;
       const double qb0 = fma(rib, mu, -rho), qb1 = -rib * sig;
       const double sa2 = fma(qa0, qa0, qa1 * qa1), sb2 = fma(qb0, qb0, qb1 * qb1);
-      const bool canda = valid && (sa2 < rj2), candb = valid && (sb2 < rj2);
-      if (!__any(canda || candb)) {   // wave-uniform: all 128 nodes miss B_j
+      // candidates, inside nodes: masks (scalar unit), not lane predicates
+      const unsigned long long mvalid = __ballot(valid);
+      const unsigned long long mca = __ballot(sa2 < rj2) & mvalid, mcb = __ballot(sb2 < rj2) & mvalid;
+      if ((mca | mcb) == 0ULL) {   // wave-uniform: all 128 nodes miss B_j
 #ifdef SHP_STATS   // a slab of this family is 128 nodes: counted as two, so that the counters compare across families
         if (lane == 0) atomicAdd(&P.dbg[0], 2ULL);
 #endif
@@ -1327,21 +1336,21 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
       jpoly_eval2<LJ>(fr + W.gh + l * jpoly_row(LJ), qa0 * inva, qa1 * inva, qb0 * invb, qb1 * invb, rjae, rjbe);
       const double Rjl = s_rj;
       const double rja = za ? Rjl : rjae, rjb = zb ? Rjl : rjbe;
-      const bool ina = canda && (za || sa2 * inva < rja), inb = candb && (zb || sb2 * invb < rjb);
+      const unsigned long long ma = mca & (__ballot(za) | __ballot(sa2 * inva < rja));
+      const unsigned long long mb = mcb & (__ballot(zb) | __ballot(sb2 * invb < rjb));
       const int pa = k * npsi + l;
-      const unsigned long long ma = __ballot(ina), mb = __ballot(inb);
       if (qcount + __builtin_popcountll(ma) + __builtin_popcountll(mb) > kQueue) break;   // wave-uniform; qcount > 0 here
 #ifdef SHP_STATS
       if (lane == 0) atomicAdd(&P.dbg[0], 2ULL);
-      if (canda) atomicAdd(&P.dbg[1], 1ULL);
-      if (candb) atomicAdd(&P.dbg[1], 1ULL);
+      if (lane_of(mca)) atomicAdd(&P.dbg[1], 1ULL);
+      if (lane_of(mcb)) atomicAdd(&P.dbg[1], 1ULL);
       if (lane == 0) atomicAdd(&P.dbg[2], 2ULL);
-      if (ina) atomicAdd(&P.dbg[3], 1ULL);
-      if (inb) atomicAdd(&P.dbg[3], 1ULL);
+      if (lane_of(ma)) atomicAdd(&P.dbg[3], 1ULL);
+      if (lane_of(mb)) atomicAdd(&P.dbg[3], 1ULL);
 #endif
       ++slab;
-      SHP_PUSH(ina, ma, pa, ria, rja);
-      SHP_PUSH(inb, mb, pa + nq, rib, rjb);
+      SHP_PUSH(ma, pa, ria, rja);
+      SHP_PUSH(mb, pa + nq, rib, rjb);
     }
 #undef SHP_PUSH
     } else {
@@ -1371,7 +1380,7 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
       if (cand) atomicAdd(&P.dbg[1], 1ULL);
       { const bool a_ = __any(cand); if (lane == 0 && a_) atomicAdd(&P.dbg[2], 1ULL); }
 #endif
-      if (!__any(cand)) continue;  // wave-uniform: the whole 64-node slab misses B_j
+      if (!wave_any(cand)) continue;  // wave-uniform: the whole 64-node slab misses B_j
 
       // s == 0 (the node sits on x_j) is inside by definition; clamping s2 keeps that lane
       // finite without a select per component (its direction is then the zero vector)
@@ -1473,7 +1482,7 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
       }
       if (!act) lam = ri;
       for (int it = 0; it < 60; ++it) {
-        if (!__any(act)) break;
+        if (!wave_any(act)) break;
         fr = SHP_LDS();
 #ifdef SHP_STATS
         if (lane == 0) atomicAdd(&P.dbg[5], 1ULL);
@@ -1525,7 +1534,7 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
           const bool tiny = JP ? (hi - lo <= s_tiny) : (hi - lo <= 1e-14 * Rjl);
           double res = ext, nxt = ext;
           bool stop = accept;
-          if (__any(act && (!inb || tiny))) {
+          if (wave_any(act && (!inb || tiny))) {
             // the general case, lane by lane with selects: the secant is the fallback of the interpolation, the
             // midpoint the fallback of both; an accepted point is clamped to the bracket
             double sec = ext, e2 = ext;
