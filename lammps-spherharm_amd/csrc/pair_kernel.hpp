@@ -1335,7 +1335,12 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
       double rjae, rjbe;   // one pass over the lane's row of particle j's table serves both nodes
       jpoly_eval2<LJ>(fr + W.gh + l * jpoly_row(LJ), qa0 * inva, qa1 * inva, qb0 * invb, qb1 * invb, rjae, rjbe);
       const double Rjl = s_rj;
-      const double rja = za ? Rjl : rjae, rjb = zb ? Rjl : rjbe;
+      double rja = rjae, rjb = rjbe;
+      if (wave_any(za || zb)) {   // a node on x_j: measure zero; the volatile statement keeps this a branch
+        asm volatile("; rare: a node on x_j");
+        rja = za ? Rjl : rjae;
+        rjb = zb ? Rjl : rjbe;
+      }
       const unsigned long long ma = mca & (__ballot(za) | __ballot(sa2 * inva < rja));
       const unsigned long long mb = mcb & (__ballot(zb) | __ballot(sb2 * invb < rjb));
       const int pa = k * npsi + l;
@@ -1481,9 +1486,12 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
         ga = gb = sqrt_nr1(s2i) - rj0;
       }
       if (!act) lam = ri;
+      // JPT: the byte address of the node's row of particle j's table, laundered (no instruction) at every iteration so
+      // that the reads stay in the loop; re-deriving it from the wave's scalar LDS offset cost three vector instructions
+      unsigned jrow_addr = wave_off + 8u * (unsigned)ghrow_;
       for (int it = 0; it < 60; ++it) {
         if (!wave_any(act)) break;
-        fr = SHP_LDS();
+        if constexpr (!JP) fr = SHP_LDS();
 #ifdef SHP_STATS
         if (lane == 0) atomicAdd(&P.dbg[5], 1ULL);
         if (act) atomicAdd(&P.dbg[6], 1ULL);
@@ -1502,10 +1510,18 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
         const bool z0 = !(ss2 > 0.0);
         const double iv = rsqrt_nr1(fmax(ss2, 1e-300));
         double rj;
-        if constexpr (JP) rj = jpoly_eval<LJ>(fr + ghrow_, y0 * iv, y1 * iv);   // the node's row, read at every iteration
-        else rj = sh_eval<L>(rc, cwj, lrt, y0 * iv, y1 * iv, y2 * iv);
+        if constexpr (JP) {   // the node's row, read at every iteration
+          jrow_addr = launder_u32(jrow_addr);
+          rj = jpoly_eval<LJ>((const double*)(smem_raw + jrow_addr), y0 * iv, y1 * iv);
+        } else {
+          rj = sh_eval<L>(rc, cwj, lrt, y0 * iv, y1 * iv, y2 * iv);
+        }
         const double Rjl = JP ? s_rj : fr[FR_RJ];
-        const double gl = z0 ? -Rjl : ss2 * iv - rj;
+        double gl = ss2 * iv - rj;
+        if (wave_any(z0)) {   // the point sits on x_j (measure zero): a wave-uniform branch, not two selects per iteration
+          asm volatile("; rare: a point on x_j");   // ... which the volatile statement keeps a branch (no if-conversion)
+          gl = z0 ? -Rjl : gl;
+        }
         // The update has no divergent control flow: every lane goes through it, and a lane that is done (or never was
         // active) carries on with values nobody reads — its r_in is frozen by `act`.  (Nested conditionals cost a
         // copy of each loop-carried value per merge: 19 v_mov_b64 and 84 vector instructions per iteration beside
