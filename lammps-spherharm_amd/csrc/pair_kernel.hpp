@@ -296,7 +296,9 @@ __host__ __device__ inline WaveLdsLayout pair_lds_layout2(const int L, const int
 // vector instructions per vote) and boolean algebra on lane predicates is materialised the same way; a ballot is the
 // compare's own SGPR pair, masks combine on the scalar unit, and lane_of() hands a mask back as a lane predicate
 // (s_and_saveexec on the mask itself).
-__device__ __forceinline__ bool wave_any(const bool p) { return __ballot(p) != 0ULL; }
+// (the HIP wrappers __ballot / __any take an int: the predicate is first turned into 0 / 1 per lane and compared again)
+__device__ __forceinline__ unsigned long long wave_ballot(const bool p) { return __builtin_amdgcn_ballot_w64(p); }
+__device__ __forceinline__ bool wave_any(const bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ULL; }
 __device__ __forceinline__ bool lane_of(const unsigned long long mask) { return __builtin_amdgcn_inverse_ballot_w64(mask); }
 
 __device__ __forceinline__ unsigned launder_u32(unsigned v)
@@ -1242,7 +1244,7 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
         double wt = (wg1 < 0.0) ? 1.0 : 0.0;
         if (den > 0.0) wt = fmin(1.0, fmax(0.0, fma(-wg1, rcp_nr(den), 0.5)));
         const bool take = valid1 && win1 && (wt > 0.0);
-        const unsigned long long m = __ballot(take);
+        const unsigned long long m = wave_ballot(take);
         if (m != 0ULL) {
           if (take) {
             const int pos = (qhead + qcount + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32),
@@ -1321,8 +1323,8 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
       const double qb0 = fma(rib, mu, -rho), qb1 = -rib * sig;
       const double sa2 = fma(qa0, qa0, qa1 * qa1), sb2 = fma(qb0, qb0, qb1 * qb1);
       // candidates, inside nodes: masks (scalar unit), not lane predicates
-      const unsigned long long mvalid = __ballot(valid);
-      const unsigned long long mca = __ballot(sa2 < rj2) & mvalid, mcb = __ballot(sb2 < rj2) & mvalid;
+      const unsigned long long mvalid = wave_ballot(valid);
+      const unsigned long long mca = wave_ballot(sa2 < rj2) & mvalid, mcb = wave_ballot(sb2 < rj2) & mvalid;
       if ((mca | mcb) == 0ULL) {   // wave-uniform: all 128 nodes miss B_j
 #ifdef SHP_STATS   // a slab of this family is 128 nodes: counted as two, so that the counters compare across families
         if (lane == 0) atomicAdd(&P.dbg[0], 2ULL);
@@ -1341,8 +1343,8 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
         rja = za ? Rjl : rjae;
         rjb = zb ? Rjl : rjbe;
       }
-      const unsigned long long ma = mca & (__ballot(za) | __ballot(sa2 * inva < rja));
-      const unsigned long long mb = mcb & (__ballot(zb) | __ballot(sb2 * invb < rjb));
+      const unsigned long long ma = mca & (wave_ballot(za) | wave_ballot(sa2 * inva < rja));
+      const unsigned long long mb = mcb & (wave_ballot(zb) | wave_ballot(sb2 * invb < rjb));
       const int pa = k * npsi + l;
       if (qcount + __builtin_popcountll(ma) + __builtin_popcountll(mb) > kQueue) break;   // wave-uniform; qcount > 0 here
 #ifdef SHP_STATS
@@ -1395,7 +1397,7 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
       const double rj0 = szero ? fr[FR_RJ] : rj0e;
       // SPEC: inside iff s < r_j (s == 0 is inside); s = s2 / sqrt(s2)
       const bool inside = cand && (szero || s2 * inv < rj0);
-      const unsigned long long m = __ballot(inside);
+      const unsigned long long m = wave_ballot(inside);
 #ifdef SHP_STATS
       if (inside) atomicAdd(&P.dbg[3], 1ULL);
 #endif
@@ -1705,7 +1707,7 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
     if (lane == 0) o[0] = aVt;
   }
   // touched: V > 0, or (forces only) any component of S_n non-zero
-  const bool touched = NEEDV ? (aVt > 0.0) : (__ballot(!is_t && val != 0.0) != 0ULL);
+  const bool touched = NEEDV ? (aVt > 0.0) : (wave_ballot(!is_t && val != 0.0) != 0ULL);
   // statistics go through a byte per slot, summed by count_flags_kernel: one
   // atomic per pair on a shared counter costs more than the whole kernel
   if (E.flags && lane == 0) E.flags[w] = touched ? 2 : 1;
