@@ -702,12 +702,21 @@ def cpu_baseline(args, shp, rmax, gbed, il, of, jl):
     per_row = max(c_probe / probe_rows, 1e-9)
     nrows = int(min(len(il), max(probe_rows, 0.7 * args.cpu_seconds * rate / per_row)))
     t_main, c_main, _ = run(nrows, nthreads)
+    passes = 1
+    if nrows == len(il):
+        # the whole list is shorter than the budget (the tuned port does 100k particles in ~1 s on 16 threads): repeat the
+        # pass until ~0.6 of the budget is spent, so that the figure is the mean over several seconds of CPU work
+        while t_main < 0.6 * args.cpu_seconds and passes < 64:
+            t2, c2, _ = run(nrows, nthreads)
+            t_main += t2
+            c_main += c2
+            passes += 1
     rows1 = int(min(len(il), max(200, 0.15 * args.cpu_seconds * (rate / nthreads) / per_row)))
     t_one, c_one, _ = run(rows1, 1)
     out = {"value": c_main / t_main, "unit": "contact-pairs/s", "cores": nthreads, "kind": "port",
            "variant": "tuned (bench/cpu_tuned.c)" if tuned is not None else "plain oracle (the weighted rule has no tuned port)",
            "value_one_core": c_one / t_one,
-           "sample": f"first {nrows} rows of the same half list ({c_main} contact pairs, {t_main:.1f} s, "
+           "sample": f"first {nrows} rows of the same half list x {passes} pass(es) ({c_main} contact pairs, {t_main:.1f} s, "
                      f"OpenMP x{nthreads}; one core: first {rows1} rows, {t_one:.1f} s); own CPU implementation of "
                      "docs/SPEC.md, not the reference's PairSH (absent from the mount)"}
     if tuned is not None:

@@ -159,7 +159,9 @@ int shpair_compute_device(shpair_ctx *ctx, int nlocal, int nghost, const double 
  * are written once into a per-slot buffer and added per atom in list order by a gather pass through a reverse index
  * that is rebuilt on the device whenever a list is installed, instead of hardware FP64 atomics whose order of
  * arrival varies from run to run (last-bit differences, ~1e-16 relative per add); costs one more pass and 96 bytes per
- * list slot; the energy / virial tallies, global and per atom, keep their atomics; 0 (default): atomics).
+ * list slot; the ghost reverse sums of shstep / shhalo follow the option (no atomics, fixed order), so device-resident
+ * trajectories are reproducible too, on one rank and on several; the energy / virial tallies, global and per atom, keep
+ * their atomics; 0 (default): atomics).
  * Memory: the contact path keeps per-slot scratch in HBM — a 320-byte record and, for the "jpoly" family, two rotated
  * coefficient vectors of rot_stride(lmax) = (lmax+1)^2 rounded up to 8 doubles each: 1.2 KB per list slot at lmax = 6
  * (0.7 GB at 100k particles / 580k pairs, ~7 GB at 1 M), 3.0 KB at lmax = 12 (1.7 GB at 100k); +96 bytes per slot in

@@ -230,6 +230,24 @@ __global__ __launch_bounds__(kHaloBlock) void halo_runpack_kernel(int nsend, con
   }
 }
 
+// The same for ONE direction's block of send rows [off, off + n): an owner appears at most once per direction, so plain
+// adds have a single writer per row — no atomics; the 26 blocks are launched one after the other in code order, which
+// fixes the order in which an owner's contributions from its images are added (the deterministic mode, det_kernels.hpp).
+__global__ __launch_bounds__(kHaloBlock) void halo_runpack_block_kernel(int n, int off, const int* __restrict__ send_idx,
+                                                                         const double* __restrict__ rrecv, double* __restrict__ f,
+                                                                         double* __restrict__ tq)
+{
+  const int t = blockIdx.x * kHaloBlock + threadIdx.x;
+  if (t >= n) return;
+  const int e = off + t;
+  const int i = send_idx[e];
+  const double* r = rrecv + (size_t)kRevWidth * e;
+  for (int d = 0; d < 3; ++d) {
+    f[3 * i + d] += r[d];
+    tq[3 * i + d] += r[3 + d];
+  }
+}
+
 // ---- migration rows ----------------------------------------------------------------------------------------------
 struct HaloArrays {
   double *x, *v, *quat, *angmom;

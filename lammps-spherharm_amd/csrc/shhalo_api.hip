@@ -921,8 +921,16 @@ int shhalo_reverse_device(shhalo_ctx* h, double* f, double* torque, void* stream
     H_TR(h, h->tr->exchange(sends, recvs, st));
   }
   if (L.nsend > 0) {
-    hipLaunchKernelGGL(halo_runpack_kernel, dim3(nblk(L.nsend, kHaloBlock)), dim3(kHaloBlock), 0, st, L.nsend,
-                       (const int*)h->d_send_idx.p, (const double*)h->d_rrecv.p, f, torque);
+    if (h->sp->opt_deterministic) {
+      // bitwise reproducible sums: one launch per direction (unique owners inside a block, plain adds), in code order
+      for (int c = 0; c < 27; ++c)
+        if (L.send_cnt[c] > 0)
+          hipLaunchKernelGGL(halo_runpack_block_kernel, dim3(nblk(L.send_cnt[c], kHaloBlock)), dim3(kHaloBlock), 0, st,
+                             L.send_cnt[c], L.send_off[c], (const int*)h->d_send_idx.p, (const double*)h->d_rrecv.p, f, torque);
+    } else {
+      hipLaunchKernelGGL(halo_runpack_kernel, dim3(nblk(L.nsend, kHaloBlock)), dim3(kHaloBlock), 0, st, L.nsend,
+                         (const int*)h->d_send_idx.p, (const double*)h->d_rrecv.p, f, torque);
+    }
     H_HIP(h, hipGetLastError());
   }
   return SHPAIR_OK;

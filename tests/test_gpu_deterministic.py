@@ -118,3 +118,72 @@ def test_device_resident_trajectories_are_bitwise_reproducible():
         sp.close()
     assert out[0][2] == out[1][2] and out[0][2] > 1           # rebuilds happened
     assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+
+
+def test_multi_rank_trajectories_are_bitwise_reproducible():
+    """2 x 2 x 1 rank threads on the one GPU (in-process hub), deterministic mode: the pair accumulation, the list build,
+    the ghost order and the reverse unpack (one launch per direction, no atomics) all fix their order of summation, so two
+    runs of a moving bed with migration and rebuilds agree bit for bit."""
+    import threading
+    import torch
+    from shpair import ShPair, shapes, bed, mrank
+    lmax, nq, skin = 4, 8, 0.2
+    shp = [shapes.random_shape(lmax, 400 + s, amp=0.2) for s in range(2)]
+    per = (1, 1, 0)
+    pts, lo, hi = bed.periodic_hcp(4000, 1.9, per)
+    rng = np.random.default_rng(9)
+    n = pts.shape[0]
+    x = pts + rng.uniform(-0.15, 0.15, pts.shape)
+    quat = bed.random_quaternions(n, rng)
+    sht = rng.integers(0, 2, n).astype(np.int32)
+    tag = np.arange(n, dtype=np.int32)
+    v = 0.4 * rng.normal(size=x.shape)
+    world, grid = 4, (2, 2, 1)
+
+    def ctx():
+        sp = ShPair(0)
+        sp.settings(nq)
+        sp.set_ntypes(1, 2)
+        for s, a in enumerate(shp):
+            sp.set_shape(s, lmax, a)
+        sp.coeff(1, 1, 400.0, 1.25)
+        sp.set_option("deterministic", 1)
+        return sp
+    sp0 = ctx()
+    cut = 2.0 * max(sp0.rmax(s) for s in range(2)) + skin
+    sp0.close()
+    g0 = mrank.plan_geometry(grid, lo, hi, per, cut, 0)
+    xw, owner = mrank.plan_owner(g0, x)
+    runs = []
+    for _ in range(2):
+        hub = mrank.Hub(world)
+        out, errs = [None] * world, []
+
+        def body(rank):
+            try:
+                sp = ctx()
+                halo = mrank.Halo(sp, rank, world, grid, lo, hi, per, skin, hub=hub)
+                mine = owner == rank
+                run = mrank.RankRun(sp, halo, xw[mine], quat[mine], sht[mine], tag[mine], v=v[mine], dt=2e-3)
+                nreb = 0
+                for _ in range(6):
+                    nreb += run.run(20)
+                t, X, V, Q, F, T = run.owned()
+                out[rank] = (t, X, V, Q, F, T, nreb, halo.stats()["migrated_out"])
+                halo.close()
+                sp.close()
+            except BaseException:  # noqa: BLE001
+                import traceback
+                errs.append(traceback.format_exc())
+        th = [threading.Thread(target=body, args=(r,)) for r in range(world)]
+        for t_ in th:
+            t_.start()
+        for t_ in th:
+            t_.join()
+        hub.close()
+        assert not errs, errs[0]
+        runs.append(out)
+    assert sum(o[6] for o in runs[0]) > 0 and sum(o[7] for o in runs[0]) > 0      # rebuilds and migration happened
+    for a, b in zip(runs[0], runs[1]):
+        for k in range(6):
+            assert np.array_equal(a[k], b[k]), k
