@@ -163,7 +163,7 @@ int shpair_compute_device(shpair_ctx *ctx, int nlocal, int nghost, const double 
  * trajectories are reproducible too, on one rank and on several; the energy / virial tallies, global and per atom, keep
  * their atomics; 0 (default): atomics).
  * Memory: the contact path keeps per-slot scratch in HBM — a 320-byte record and, for the "jpoly" family, two rotated
- * coefficient vectors of rot_stride(lmax) = (lmax+1)^2 rounded up to 8 doubles each: 1.2 KB per list slot at lmax = 6
+ * coefficient vectors of (lmax+1)^2 doubles each (rounded up to 8 from lmax = 9 on): 1.1 KB per list slot at lmax = 6
  * (0.7 GB at 100k particles / 580k pairs, ~7 GB at 1 M), 3.0 KB at lmax = 12 (1.7 GB at 100k); +96 bytes per slot in
  * the deterministic mode. */
 int shpair_set_option(shpair_ctx *ctx, const char *key, int value);

@@ -75,8 +75,8 @@ struct PairParams {
   const double* jval;    // first stage, ELL: (2 lmax + 4)(lmax + 1) rows x (lmax/2+1) values (sh_tables.cpp build_jpoly_ell)
   const int* jcol;       // ... and indices into the rotated coefficient vector
   const double* trigj;   // (cos, sin)(m psi_l), m = 0..lmax + 1, of the first nq azimuths, l-major
-  const double* rot;     // compiled orders: [2 w + which][rot_stride(lmax)] rotated, scaled coefficient vectors of slot
-                         // w's particles (which 0: i, 1: j), written by pair_rotate_lane_kernel
+  const double* rot;     // compiled orders: rotated, scaled coefficient vectors of slot w's particles, rotation 2 w + which
+                         // (which 0: i, 1: j), in the tiled layout of rot_index(); written by pair_rotate_lane_kernel
   int jpoly;             // 1: the pair records carry the Euler angles of j's frame in the slots of FR_BJ1 / FR_BJ2
   int split;             // 1: two waves per pair (pair_contact_kernel<..., WPP = 2>); wave_lds_bytes is then the PAIR's LDS
   // per-pair records written by pair_setup_kernel (pair_setup.hpp), read here instead of redoing the scalar set-up on
@@ -481,9 +481,23 @@ __device__ __forceinline__ void cap_frame_rotate(const PairParams& P, double* __
 // free) between the steps that gather (X^T, X) and in registers for those that do not (the Z turns; cos/sin(m angle) of
 // the three angles sit in registers too), the X matrices are wave-uniform (scalar loads, SGPR operands) and every
 // loop is wave-uniform: ~20 instructions per rotation.  The arithmetic and its order are those of cap_frame_rotate.
-// Doubles between the rotated vectors of consecutive rotations: (L+1)^2 rounded up to whole 64-byte lines, so that no
-// line is shared by two rotations' rows (392-byte rows at L = 6 straddled lines: WRITE_SIZE 1.46x the payload, round 2).
-__host__ __device__ constexpr int rot_stride(const int L) { return ((L + 1) * (L + 1) + 7) & ~7; }
+// Layout of the rotated vectors: TILES of 64 rotations (one wave of the rotation kernel), inside a tile block-major —
+// [l-block][rotation][element of the block] — so that the 64 x (2l+1) doubles a wave produces for one l are contiguous
+// and leave as full 512-byte wave stores.  (Rotation-major rows were written in 49 store instructions of scattered
+// 8...104-byte runs per wave: WRITE_SIZE 1.3-1.5x the payload and a kernel bound by its own write pattern.)
+// Element e = l^2 + r of rotation T sits at rot_index(L, T, l, r).  Measured (profiles/r03_u_ab_rottile.txt): rotation
+// kernel 0.296 -> 0.220 ms at L = 6; the contact kernel's reads become 2L + 1 pieces per vector, which costs it more
+// than the rotation kernel gains from L = 9 on (L = 12: +1.2 % per step) — there the rows stay rotation-major, padded
+// to whole 64-byte lines.
+__host__ __device__ constexpr bool rot_tiled(const int L) { return L <= 8; }
+__host__ __device__ constexpr size_t rot_row_doubles(const int L) { return (size_t)(((L + 1) * (L + 1) + 7) & ~7); }
+__host__ __device__ constexpr size_t rot_tile_doubles(const int L) { return (size_t)64 * (rot_tiled(L) ? (size_t)(L + 1) * (L + 1) : rot_row_doubles(L)); }
+__host__ __device__ inline size_t rot_index(const int L, const int T, const int l, const int r)
+{
+  if (!rot_tiled(L)) return (size_t)T * rot_row_doubles(L) + (size_t)l * l + r;
+  return (size_t)(T >> 6) * rot_tile_doubles(L) + (size_t)64 * l * l + (size_t)(T & 63) * (2 * l + 1) + r;
+}
+__host__ __device__ inline size_t rot_buffer_doubles(const int L, const size_t nrot) { return ((nrot + 63) / 64) * rot_tile_doubles(L); }
 template <int L>
 struct RotLaneLds {
   static constexpr int NB = 2 * L + 1;
@@ -557,7 +571,11 @@ __device__ __forceinline__ void rotate_lane_block(const PairParams& P, double* _
   for (int it = 0; it < n; ++it) {
     const int idx = lane + 64 * it;   // < 64 n
     const int tk = idx / n, r = idx - tk * n;
-    if (task0 + tk < ntasks) rot[(size_t)(task0 + tk) * rot_stride(L) + base + r] = At[64 * r + tk];
+    // task0 is a multiple of 64 (one tile per workgroup): this is rot_index(L, task0 + tk, LB, r), consecutive in `idx`
+    if (task0 + tk < ntasks) {
+      if constexpr (rot_tiled(L)) rot[(size_t)(task0 >> 6) * rot_tile_doubles(L) + 64 * base + idx] = At[64 * r + tk];
+      else rot[(size_t)(task0 + tk) * rot_row_doubles(L) + base + r] = At[64 * r + tk];
+    }
   }
   wave_lds_sync();
   if constexpr (LB < L) rotate_lane_block<L, LB + 1>(P, sm, lane, cre, rot, task0, ntasks, T);
@@ -1015,12 +1033,21 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
   const double recv = P.rec[(size_t)kRecStride * w + (lane < kRecUsed ? lane : 0)];
   if constexpr (JPT && L >= 0 && !WEIGHTED) {
     constexpr int ns = (L + 1) * (L + 1);
-    const double* rv = P.rot + (size_t)(2 * w) * rot_stride(L);
+    // element e = l^2 + r of the slot's two rotations 2w (particle i) and 2w + 1 (particle j): adjacent in their tile
 #pragma unroll
     for (int t = 0; t < NSL; ++t) {
       const int e = tid + NT * t;
-      vi[t] = rv[e < ns ? e : 0];
-      vj[t] = rv[rot_stride(L) + (e < ns ? e : 0)];
+      const int ec = e < ns ? e : 0;
+      if constexpr (rot_tiled(L)) {
+        const int l = (int)__builtin_sqrtf((float)ec);   // exact for these small integers
+        const size_t at = rot_index(L, 2 * w, l, ec - l * l);
+        vi[t] = P.rot[at];
+        vj[t] = P.rot[at + (2 * l + 1)];
+      } else {
+        const size_t at = (size_t)(2 * w) * rot_row_doubles(L) + ec;
+        vi[t] = P.rot[at];
+        vj[t] = P.rot[at + rot_row_doubles(L)];
+      }
     }
     pre.fetch(P, lane, P.nq);
   }

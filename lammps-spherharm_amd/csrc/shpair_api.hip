@@ -438,7 +438,7 @@ hipError_t shp_size_pair_buffers(shpair_ctx* c, size_t np)
   for (int s = 0; s < c->nshapes; ++s)
     if (c->shapes[s].lmax > L) L = c->shapes[s].lmax;
   if (e == hipSuccess && L >= 0 && c->nq > 0) {
-    if (use_jpoly_at(c, L)) e = c->d_rot.ensure(np * 2 * (size_t)rot_stride(L));
+    if (use_jpoly_at(c, L)) e = c->d_rot.ensure(rot_buffer_doubles(L, 2 * np));
   }
   return e;
 }
@@ -799,7 +799,7 @@ int shpair_compute_device(shpair_ctx* c, int nlocal, int nghost, const double* x
   P.rec = c->d_rec.p;
   P.rec_i = c->d_rec_i.p;
   if (jpoly) {   // grows only when the list or the order grew: sized by shpair_prepare_tables() ahead of a stream capture
-    HIPCHK(c, c->d_rot.ensure((size_t)c->npairs * 2 * rot_stride(c->lmax)));
+    HIPCHK(c, c->d_rot.ensure(rot_buffer_doubles(c->lmax, 2 * (size_t)c->npairs)));
     P.rot = c->d_rot.p;
   } else {
     P.rot = nullptr;
