@@ -292,6 +292,15 @@ __device__ __forceinline__ v2d lds2(const double* p) { return *(const v2d*)__bui
 //   [epilogue scratch of both waves over everything behind the frame] | queue of wave 0 | queue of wave 1
 __host__ __device__ inline WaveLdsLayout pair_lds_layout2(const int L, const int rows, const int nq);
 
+// Integer products of the node loops through the 24-bit multiplier (v_mul_u32_u24 / v_mul_i32_i24: full rate;
+// v_mul_lo_u32 is a quarter-rate instruction).  Operands are node, ring and azimuth indices (< 2^15) and the
+// multiply-shift constants (< 2^24).  Only the JPT kernels take it: in four forces-only body-frame kernels the changed
+// instruction mix tips the register allocator into 2-4 spills.
+template <bool ON>
+__device__ __forceinline__ unsigned umul_sel(const unsigned a, const unsigned b) { return ON ? __umul24(a, b) : a * b; }
+template <bool ON>
+__device__ __forceinline__ int mul_sel(const int a, const int b) { return ON ? __mul24(a, b) : a * b; }
+
 // Wave votes as SCALAR mask arithmetic.  HIP's __any() goes through a 0 / 1 value per lane (v_cndmask + v_cmp, two
 // vector instructions per vote) and boolean algebra on lane predicates is materialised the same way; a ballot is the
 // compare's own SGPR pair, masks combine on the scalar unit, and lane_of() hands a mask back as a lane predicate
@@ -1131,6 +1140,8 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
 
   const int npsi = 2 * nq;
   const int Q = nq * npsi;
+  // (integer products here go through the 24-bit multiplier — v_mul_u32_u24, full rate; v_mul_lo_u32 is a quarter-rate
+  // instruction and the node loops had three to six of them per slab / batch)
   // p / npsi for 0 <= p < Q <= 2^15 as a multiply-shift: exact because
   // magic * npsi - 2^24 < npsi <= 256 < 2^24 / 2^15
   const unsigned magic = ((1u << 24) + (unsigned)npsi - 1u) / (unsigned)npsi;
@@ -1203,8 +1214,8 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
       if (t < nslabs) {  // wave-uniform
         const int p = (t << 6) + lane;
         const bool valid = p < Q;
-        const int k = valid ? (int)(((unsigned)p * magic) >> 24) : 0;
-        const int l = valid ? p - k * npsi : 0;
+        const int k = valid ? (int)(umul_sel<JP>((unsigned)p, magic) >> 24) : 0;
+        const int l = valid ? p - mul_sel<JP>(k, npsi) : 0;
         const double* row = fr + W.ring + (k - k0) * rowlen;
         const double mu = row[1], sig = row[3];
         const double c1 = P.cpsi[l], s1 = P.spsi[l];
@@ -1235,8 +1246,8 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
       if (t >= 1) {
         const int p1 = ((t - 1) << 6) + lane;
         const bool valid1 = p1 < Q;
-        const int k1 = valid1 ? (int)(((unsigned)p1 * magic) >> 24) : 0;
-        const int l1 = valid1 ? p1 - k1 * npsi : 0;
+        const int k1 = valid1 ? (int)(umul_sel<JP>((unsigned)p1, magic) >> 24) : 0;
+        const int l1 = valid1 ? p1 - mul_sel<JP>(k1, npsi) : 0;
         double nb[3];
         if (aligned) {
           // rings do not straddle slabs (n_psi divides 64): the azimuth neighbours sit in slab t-1 itself and the
@@ -1315,8 +1326,8 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
       fr = SHP_LDS();
       const int pp = (slab << 6) + lane;   // node pair: ring k, azimuths l and l + n_q
       const bool valid = pp < nq * per_ring;
-      const int k = valid ? (int)(((unsigned)pp * magicr) >> 24) : k0;   // idle lanes read a resident row
-      const int l = (valid ? pp - k * per_ring : 0) + half * per_ring;
+      const int k = valid ? (int)(umul_sel<JP>((unsigned)pp, magicr) >> 24) : k0;   // idle lanes read a resident row
+      const int l = (valid ? pp - mul_sel<JP>(k, per_ring) : 0) + half * per_ring;
       const double* row = fr + W.ring + (k - k0) * rowlen;
       const v2d r01 = lds2(row);   // (A_k0, mu_k)
       const double mu = r01[1], sig = row[3];
@@ -1372,7 +1383,7 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
       }
       const unsigned long long ma = mca & (wave_ballot(za) | wave_ballot(sa2 * inva < rja));
       const unsigned long long mb = mcb & (wave_ballot(zb) | wave_ballot(sb2 * invb < rjb));
-      const int pa = k * npsi + l;
+      const int pa = mul_sel<JP>(k, npsi) + l;
       if (qcount + __builtin_popcountll(ma) + __builtin_popcountll(mb) > kQueue) break;   // wave-uniform; qcount > 0 here
 #ifdef SHP_STATS
       if (lane == 0) atomicAdd(&P.dbg[0], 2ULL);
@@ -1393,8 +1404,8 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
       const int p = (slab << 6) + lane;
       ++slab;
       const bool valid = p < Q;
-      const int k = valid ? (int)(((unsigned)p * magic) >> 24) : 0;
-      const int l = valid ? p - k * npsi : 0;
+      const int k = valid ? (int)(umul_sel<JP>((unsigned)p, magic) >> 24) : 0;
+      const int l = valid ? p - mul_sel<JP>(k, npsi) : 0;
       const double* row = fr + W.ring + (k - k0) * rowlen;
       const double mu = row[1], sig = row[3];
       const double c1 = P.cpsi[l], s1 = P.spsi[l];
@@ -1462,8 +1473,8 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
 #endif
     int p = ((const unsigned short*)(fr + W.qp))[e];   // Q = 2 nq^2 <= 2^15
     double ri = fr[W.qri + e];
-    int k = (int)(((unsigned)p * magic) >> 24);
-    int l = p - k * npsi;
+    int k = (int)(umul_sel<JP>((unsigned)p, magic) >> 24);
+    int l = p - mul_sel<JP>(k, npsi);
     double omi = active ? fr[FR_WSC] * (JP ? fr[W.glw + k * jpoly_row(LJ)] : P.glw[k]) : 0.0;   // the node's plain weight
     bool outside = false;    // WEIGHTED: a node with g~ >= 0 has no ray segment inside j
     if (WEIGHTED) outside = !(fr[W.qw + e] > 0.0);
@@ -1616,8 +1627,8 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
         // The node is looked up a second time here (the root loop holds a row of particle j's table in 4L + 2
         // registers and has none to carry weight, psi, mu, sigma across), from LDS only.
         p = (int)launder_u32((unsigned)p);
-        k = (int)(((unsigned)p * magic) >> 24);
-        l = p - k * npsi;
+        k = (int)(umul_sel<JP>((unsigned)p, magic) >> 24);
+        l = p - mul_sel<JP>(k, npsi);
         omi = active ? fr[FR_WSC] * fr[W.glw + k * jpoly_row(LJ)] : 0.0;
         const double* row = fr + W.ring + (k - k0) * rowlen;
         mu = row[1];
@@ -1628,8 +1639,8 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
         // compiler cannot see through, instead of being carried across the loop — that is what keeps them free of
         // spills.  The sharp kernels have the room (A/B: the second lookup costs them 1.5 %).
         p = (int)launder_u32((unsigned)p);
-        k = (int)(((unsigned)p * magic) >> 24);
-        l = p - k * npsi;
+        k = (int)(umul_sel<JP>((unsigned)p, magic) >> 24);
+        l = p - mul_sel<JP>(k, npsi);
         omi = active ? fr[FR_WSC] * P.glw[k] : 0.0;
         c1 = P.cpsi[l];
         s1 = P.spsi[l];
