@@ -1333,7 +1333,7 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
       const double mu = r01[1], sig = row[3];
       // r_i at the two azimuths: psi + pi changes the sign of the odd orders
       // cos/sin(m psi_l): the first order from the lane's row of particle j's table, the rest by angle addition
-      const double* gr = fr + W.gh + l * jpoly_row(LJ);
+      const double* gr = fr + W.gh + mul_sel<JP>(l, jpoly_row(LJ));
       double re = r01[0], ro = 0.0;
       if constexpr (LJ >= 1) {
         const v2d cs1 = lds2(gr + jpoly_trig(LJ));
@@ -1373,7 +1373,7 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
       const bool za = !(sa2 > 0.0), zb = !(sb2 > 0.0);
       const double inva = rsqrt_nr1(fmax(sa2, 1e-300)), invb = rsqrt_nr1(fmax(sb2, 1e-300));
       double rjae, rjbe;   // one pass over the lane's row of particle j's table serves both nodes
-      jpoly_eval2<LJ>(fr + W.gh + l * jpoly_row(LJ), qa0 * inva, qa1 * inva, qb0 * invb, qb1 * invb, rjae, rjbe);
+      jpoly_eval2<LJ>(fr + W.gh + mul_sel<JP>(l, jpoly_row(LJ)), qa0 * inva, qa1 * inva, qb0 * invb, qb1 * invb, rjae, rjbe);
       const double Rjl = s_rj;
       double rja = rjae, rjb = rjbe;
       if (wave_any(za || zb)) {   // a node on x_j: measure zero; the volatile statement keeps this a branch
@@ -1475,7 +1475,7 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
     double ri = fr[W.qri + e];
     int k = (int)(umul_sel<JP>((unsigned)p, magic) >> 24);
     int l = p - mul_sel<JP>(k, npsi);
-    double omi = active ? fr[FR_WSC] * (JP ? fr[W.glw + k * jpoly_row(LJ)] : P.glw[k]) : 0.0;   // the node's plain weight
+    double omi = active ? fr[FR_WSC] * (JP ? fr[W.glw + mul_sel<JP>(k, jpoly_row(LJ))] : P.glw[k]) : 0.0;   // the node's plain weight
     bool outside = false;    // WEIGHTED: a node with g~ >= 0 has no ray segment inside j
     if (WEIGHTED) outside = !(fr[W.qw + e] > 0.0);
     double c1 = P.cpsi[l], s1 = P.spsi[l];
@@ -1493,7 +1493,7 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
       // the node's ray seen from x_j: compiled orders (axial, signed radial) = (lambda mu - rho, +-lambda sigma) in the
       // common frame; run-time-order kernel lambda u_j - d_j in j's body frame
       double uj0, uj1, uj2 = 0.0;
-      const int ghrow_ = W.gh + (l >= nq ? l - nq : l) * jpoly_row(LJ);
+      const int ghrow_ = W.gh + mul_sel<JP>(l >= nq ? l - nq : l, jpoly_row(LJ));
       if constexpr (JP) {
         uj0 = mu;
         uj1 = (l >= nq) ? -sig : sig;
@@ -1629,7 +1629,7 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
         p = (int)launder_u32((unsigned)p);
         k = (int)(umul_sel<JP>((unsigned)p, magic) >> 24);
         l = p - mul_sel<JP>(k, npsi);
-        omi = active ? fr[FR_WSC] * fr[W.glw + k * jpoly_row(LJ)] : 0.0;
+        omi = active ? fr[FR_WSC] * fr[W.glw + mul_sel<JP>(k, jpoly_row(LJ))] : 0.0;
         const double* row = fr + W.ring + (k - k0) * rowlen;
         mu = row[1];
         sig = row[3];
@@ -1659,7 +1659,7 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
     double r2, rmu, rpsi;
     if constexpr (JP) {
       const double sg = (l >= nq) ? -1.0 : 1.0;
-      const double* tg = fr + W.gh + (l >= nq ? l - nq : l) * jpoly_row(LJ) + jpoly_trig(LJ);
+      const double* tg = fr + W.gh + mul_sel<JP>(l >= nq ? l - nq : l, jpoly_row(LJ)) + jpoly_trig(LJ);
       if constexpr (LJ >= 1) {
         const v2d cs1 = lds2(tg);
         c1 = sg * cs1[0];
