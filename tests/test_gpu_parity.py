@@ -130,6 +130,40 @@ def test_two_waves_per_pair_match_oracle(oracle, lmax, nq, rows, expo):
     assert np.abs(out[1][0] - out[0][0]).max() < 1e-12 * fs
 
 
+def test_two_waves_per_pair_random_configurations_agree_with_one_wave(oracle):
+    """A wider net for the two-wave kernels' barriers, queues and ring groups: pseudo-random (order, even n_q, resident
+    rows, exponent) — including n_q / 2 that do not divide 64, single-slab caps and many short ring groups — each compared
+    with the one-wave kernels of the same library on the same bed (1e-12) and, for every third case, with the oracle."""
+    rng = np.random.default_rng(20261004)
+    for case_no in range(18):
+        lmax = int(rng.integers(7, 13))
+        nq = int(2 * rng.integers(4, 21))                      # 8 .. 40, even
+        per_slab = (64 + nq // 2 - 1) // (nq // 2)
+        rows = int(rng.choice([0, 0, 2 * per_slab, 3 * per_slab, nq]))
+        expo = float(rng.choice([1.0, 1.25, 1.5]))
+        case = make_case(90, lmax, 2, seed=500 + case_no, rmax_fn=oracle.shape_rmax)
+        K, E = coeff_tables(1, 700.0, expo)
+        b = case["bed"]
+        res = {}
+        for split in (1, 0):
+            sp = make_ctx(case, nq, K, E)
+            sp.set_option("jpoly", 1)
+            sp.set_option("split", split)
+            if rows:
+                sp.set_option("ring_rows", min(rows, nq))
+            f, tq, eng, _ = sp.compute(case["n"], b["x"], b["quat"], b["type"], b["shtype"], eflag=True)
+            assert sp.kernel_info()["waves_per_pair"] == (2 if split else 1), (lmax, nq)
+            res[split] = (f, tq, eng)
+            sp.close()
+        fs = np.abs(res[0][0]).max()
+        assert fs > 0, (lmax, nq, rows)
+        assert np.abs(res[1][0] - res[0][0]).max() < 1e-12 * fs, (lmax, nq, rows, expo)
+        assert np.abs(res[1][1] - res[0][1]).max() < 1e-12 * max(fs, np.abs(res[0][1]).max()), (lmax, nq, rows, expo)
+        assert abs(res[1][2] - res[0][2]) < 1e-11 * abs(res[0][2]), (lmax, nq, rows, expo)
+        if case_no % 3 == 0:
+            check(res[1][0], res[1][1], oracle_compute(oracle, case, nq, K, E))
+
+
 def test_split_option_is_ignored_where_it_does_not_apply(oracle):
     """Odd n_q, orders below 7 and the body-frame family have no two-wave form: the option must fall back silently."""
     for lmax, nq, jp in ((8, 9, 1), (6, 16, 1), (9, 16, 0)):
