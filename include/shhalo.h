@@ -134,6 +134,11 @@ int shhalo_exchange_device(shhalo_ctx *h, shhalo_arrays *a, void *stream);
  * valid until the next call. */
 int shhalo_borders_device(shhalo_ctx *h, const shhalo_arrays *a, int *nghost, void *stream);
 
+/* Neighbor::build of the bound shpair context over the brick plus its ghost shell (shstep_neighbor_build_device with
+ * the global ids as tags), collective like the two calls above: a shape index outside the table found by one rank's
+ * build fails the call on every rank.  Blocks. */
+int shhalo_neighbor_build_device(shhalo_ctx *h, const shhalo_arrays *a, int nghost, int *npairs, void *stream);
+
 /* Comm::forward_comm: owners' x (+ shift) and quat -> the ghost rows of every neighbour.  Enqueues one pack
  * kernel, one RCCL group and one unpack kernel on `stream`; does not wait. */
 int shhalo_forward_device(shhalo_ctx *h, double *x_dev, double *quat_dev, void *stream);

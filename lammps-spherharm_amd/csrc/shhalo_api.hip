@@ -857,6 +857,22 @@ int shhalo_borders_device(shhalo_ctx* h, const shhalo_arrays* a, int* nghost, vo
   return SHPAIR_OK;
 }
 
+// Neighbor::build over the brick plus its ghost shell.  The list build reports shape indices outside the table (they
+// may have arrived with migrated atoms or ghost rows): a rank-local failure between two exchanges, so the ranks agree
+// on it before anyone posts the forward exchange.
+int shhalo_neighbor_build_device(shhalo_ctx* h, const shhalo_arrays* a, int nghost, int* npairs, void* stream)
+{
+  if (!h) return SHPAIR_EINVAL;
+  H_RC(h, check_arrays(h, a));
+  if (!npairs || nghost < 0) H_FAIL(h, SHPAIR_EINVAL, "null npairs or negative nghost");
+  H_HIP(h, hipSetDevice(h->sp->device));
+  hipStream_t st = (hipStream_t)stream;
+  const int lrc = shstep_neighbor_build_device(h->sp, a->nlocal, nghost, a->x, a->shtype, a->tag, npairs, st);
+  if (lrc) h->err = h->sp->err;
+  else h->err.clear();
+  return agree(h, lrc, st);
+}
+
 int shhalo_forward_device(shhalo_ctx* h, double* x, double* quat, void* stream)
 {
   if (!h) return SHPAIR_EINVAL;
@@ -1003,10 +1019,7 @@ int shhalo_run_device(shhalo_ctx* h, shhalo_arrays* a, const shhalo_run_params* 
         if (!rc) {
           // the list build reports shape indices outside the table (they may have arrived with migrated atoms): a
           // rank-local failure in the middle of the step, so the ranks agree on it before the forward exchange
-          const int lrc = shstep_neighbor_build_device(sp, a->nlocal, nghost, a->x, a->shtype, a->tag, &np, st);
-          if (lrc) h->err = sp->err;
-          else h->err.clear();
-          rc = agree(h, lrc, st);
+          rc = shhalo_neighbor_build_device(h, a, nghost, &np, st);
         }
         if (rc) break;
         ++nreb;

@@ -149,6 +149,7 @@ SYMBOLS = {
     "shhalo_get_geometry": (C.c_int, [C.c_void_p, C.POINTER(HaloGeometry)]),
     "shhalo_exchange_device": (C.c_int, [C.c_void_p, C.POINTER(HaloArrays), C.c_void_p]),
     "shhalo_borders_device": (C.c_int, [C.c_void_p, C.POINTER(HaloArrays), _ip, C.c_void_p]),
+    "shhalo_neighbor_build_device": (C.c_int, [C.c_void_p, C.POINTER(HaloArrays), C.c_int, _ip, C.c_void_p]),
     "shhalo_forward_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "shhalo_reverse_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "shhalo_check_rebuild_device": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, _ip, C.c_void_p]),

@@ -131,6 +131,12 @@ class Halo:
         self._chk(self._lib.shhalo_borders_device(self._h, C.byref(arrays), C.byref(ng), stream))
         return ng.value
 
+    def neighbor_build(self, arrays, nghost, stream=None):
+        """shhalo_neighbor_build_device: the half list over the brick + ghosts; collective (failures are agreed on)."""
+        np_ = C.c_int(0)
+        self._chk(self._lib.shhalo_neighbor_build_device(self._h, C.byref(arrays), int(nghost), C.byref(np_), stream))
+        return np_.value
+
     def forward(self, x, quat, stream=None):
         self._chk(self._lib.shhalo_forward_device(self._h, x, quat, stream))
 
@@ -222,8 +228,7 @@ class RankRun:
         """Comm::exchange + Comm::borders + Neighbor::build."""
         self.halo.exchange(self.a, self.stream)
         self.nghost = self.halo.borders(self.a, self.stream)
-        self.npairs = self.sp.neighbor_build_device(self.a.nlocal, self.nghost, self.a.x, self.a.shtype, tag=self.a.tag,
-                                                    stream=self.stream)
+        self.npairs = self.halo.neighbor_build(self.a, self.nghost, self.stream)
         self.builds += 1
 
     def force(self, eflag=False):
