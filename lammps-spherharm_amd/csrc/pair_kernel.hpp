@@ -519,12 +519,27 @@ template <int L>
 struct RotTrig {
   double c[3 * (L > 0 ? L : 1)], s[3 * (L > 0 ? L : 1)];
 };
+typedef const int __attribute__((address_space(4))) * ciptr;
+__device__ __forceinline__ ciptr launder_uniform_i(const int* p)
+{
+  asm volatile("" : "+s"(p));
+  return (ciptr)p;
+}
 template <int L, int LB>
 __device__ __forceinline__ void rotate_lane_block(const PairParams& P, double* __restrict__ sm, const int lane,
                                                   const double* __restrict__ cre, double* __restrict__ rot,
                                                   const int task0, const int ntasks, const RotTrig<L>& T)
 {
   constexpr int ns = (L + 1) * (L + 1), n = 2 * LB + 1, base = LB * LB, XW = L / 2 + 1, XN = LB / 2 + 1;
+  // The X matrices, their column indices and the ring scale are the same for every lane: through constant-address-space
+  // pointers they are SCALAR loads into SGPRs (an SGPR can be the multiplier of a v_fma_f64).  Through the plain global
+  // pointers of the argument struct the compiler emits ~220 per-lane vector loads of them per wave (the kernel also
+  // stores to global memory, so it may not assume the tables unchanged).
+  // Measured on the tiled layout: L = 6 rotation kernel 0.220 -> 0.149 ms; at L = 12 (244 VGPRs, 1 100 scalar loads per
+  // wave) the step gets 3.9 % slower, so from L = 9 on the plain pointers stay (profiles/r03_z_ab_rot_scalar.txt).
+  const auto xval = [&] { if constexpr (rot_tiled(L)) return launder_uniform(P.xval); else return P.xval; }();
+  const auto gsc = [&] { if constexpr (rot_tiled(L)) return launder_uniform(P.gscale); else return P.gscale; }();
+  const auto xcol = [&] { if constexpr (rot_tiled(L)) return launder_uniform_i(P.xcol); else return P.xcol; }();
   double* A = sm + RotLaneLds<L>::a() + lane;
   double* B = sm + RotLaneLds<L>::b() + lane;
   // Z(alpha) on the way in: the pair (l, +m), (l, -m) turns by m alpha
@@ -543,7 +558,7 @@ __device__ __forceinline__ void rotate_lane_block(const PairParams& P, double* _
     const size_t ro = ((size_t)ns + base + r) * XW;
     double o = 0.0;
 #pragma unroll
-    for (int t = 0; t < XN; ++t) o = fma(P.xval[ro + t], A[64 * (P.xcol[ro + t] - base)], o);
+    for (int t = 0; t < XN; ++t) o = fma(xval[ro + t], A[64 * (xcol[ro + t] - base)], o);
     xb[r] = o;
   }
   // Z(beta), in registers
@@ -561,18 +576,18 @@ __device__ __forceinline__ void rotate_lane_block(const PairParams& P, double* _
     const size_t ro = ((size_t)base + r) * XW;
     double o = 0.0;
 #pragma unroll
-    for (int t = 0; t < XN; ++t) o = fma(P.xval[ro + t], B[64 * (P.xcol[ro + t] - base)], o);
+    for (int t = 0; t < XN; ++t) o = fma(xval[ro + t], B[64 * (xcol[ro + t] - base)], o);
     xb[r] = o;
   }
   // Z(gamma) and the ring scale, in registers; then the block leaves transposed through LDS: consecutive lanes
   // write consecutive elements of one rotation
-  A[64 * LB] = xb[LB] * P.gscale[base + LB];
+  A[64 * LB] = xb[LB] * gsc[base + LB];
 #pragma unroll
   for (int m = 1; m <= LB; ++m) {
     const double c = T.c[2 * L + m - 1], s = T.s[2 * L + m - 1];
     const double p = xb[LB + m], q = xb[LB - m];
-    A[64 * (LB + m)] = fma(c, p, s * q) * P.gscale[base + LB + m];
-    A[64 * (LB - m)] = fma(c, q, -(s * p)) * P.gscale[base + LB - m];
+    A[64 * (LB + m)] = fma(c, p, s * q) * gsc[base + LB + m];
+    A[64 * (LB - m)] = fma(c, q, -(s * p)) * gsc[base + LB - m];
   }
   wave_lds_sync();
   const double* At = sm + RotLaneLds<L>::a();
