@@ -651,7 +651,31 @@ __global__ void __launch_bounds__(64) pair_rotate_lane_kernel(const PairParams P
 // one table load, not for one per step (six dependent ~1000-cycle round trips at L = 6).
 // WPP = 2: `lane` is the thread index within the pair's two waves (0..127); with 128 lanes a group of <= 8 rings gets
 // 16 lanes per ring — at L <= 15 one order per lane, a single pass.
-template <int L, bool PRE = false, int WPP = 1>
+// DENSE map (one wave per pair, (L + 1) x rows <= 64): lane = (ring, order), L + 1 lanes per ring — every (ring, order)
+// of the group in ONE pass.  With power-of-two classes L = 4, n_q = 10 took two passes (orders 0-3, then order 4 alone
+// with the whole pass overhead): 213 of that kernel's 1 150 instructions per pair.
+// (JPT kernels only: in one forces-only body-frame kernel the extra map tips the register allocator into a spill.)
+template <int L, int WPP, bool DENSE>
+__device__ __forceinline__ void ring_lane_map(const int lane, const int nrows, int& krl, int& g, int& G, int& rpc, int& lg)
+{
+  const int lg1 = (nrows <= 8) ? 3 : (nrows <= 16) ? 2 : (nrows <= 32) ? 1 : 0;
+  lg = lg1 + (WPP == 2 ? 1 : 0);   // log2 G: as many lanes per ring as the NT lanes give the group's rows; uniform
+  G = 1 << lg;
+  krl = lane >> lg;
+  g = lane & (G - 1);
+  rpc = (64 * WPP) >> lg;
+  if constexpr (DENSE && L >= 1 && WPP == 1) {
+    if ((L + 1) * nrows <= 64) {   // wave-uniform
+      G = L + 1;
+      krl = lane / (L + 1);
+      g = lane - krl * (L + 1);
+      rpc = 64 / (L + 1);
+      lg = 0;
+    }
+  }
+}
+
+template <int L, bool PRE = false, int WPP = 1, bool DENSE = false>
 __device__ __forceinline__ void cap_frame_rings(const PairParams& P, double* __restrict__ lw, const WaveLdsLayout& W,
                                                 const int LL, const int lane, const int k0, const int nrows,
                                                 const double hw, const double hm, const bool have_first = false)
@@ -660,14 +684,11 @@ __device__ __forceinline__ void cap_frame_rings(const PairParams& P, double* __r
   // was requested at the start of the kernel and waits in the (empty) queue at lw[W.park + 128 + lane]
   const double* ch = lw + W.v0;
   double* ring = lw + W.ring;
-  constexpr int NT = 64 * WPP;
-  const int lg1 = (nrows <= 8) ? 3 : (nrows <= 16) ? 2 : (nrows <= 32) ? 1 : 0;
-  const int lg = lg1 + (WPP == 2 ? 1 : 0);   // log2 G: as many lanes per ring as the NT lanes give the group's rows; uniform
-  const int G = 1 << lg;
-  const int g = lane & (G - 1);
-  for (int kr0 = 0; kr0 < nrows; kr0 += (NT >> lg)) {
-    const int kr = kr0 + (lane >> lg);
-    const bool row_ok = kr < nrows;
+  int krl, g, G, rpc, lg;
+  ring_lane_map<L, WPP, DENSE>(lane, nrows, krl, g, G, rpc, lg);
+  for (int kr0 = 0; kr0 < nrows; kr0 += rpc) {
+    const int kr = kr0 + krl;
+    const bool row_ok = kr < nrows && krl < rpc;
     const double tk = (PRE && have_first && k0 == 0 && kr0 == 0) ? lw[W.park + 128 + lane] : P.glt[k0 + (row_ok ? kr : 0)];
     const double mu = fma(hw, tk, hm);
     const double sig2 = fmax(0.0, fma(-mu, mu, 1.0));
@@ -1078,8 +1099,8 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
   double glt_first = 0.0;
   if constexpr (JPT && L >= 0 && L <= 8 && !WEIGHTED && WPP == 1) {
     const int nr0 = P.ring_rows < P.nq ? P.ring_rows : P.nq;   // rings of the first group (cap_frame_rings' lane map)
-    const int lg0 = (nr0 <= 8) ? 3 : (nr0 <= 16) ? 2 : (nr0 <= 32) ? 1 : 0;
-    const int kr = lane >> lg0;
+    int kr, g0_, G0_, rpc0_, lg0_;
+    ring_lane_map<L, 1, true>(lane, nr0, kr, g0_, G0_, rpc0_, lg0_);
     glt_first = P.glt[kr < nr0 ? kr : 0];
   }
   const int status = rid[0];
@@ -1194,7 +1215,7 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
       double* park = lr + W.park + lane;
       park[0] = aT2; park[64] = NEEDV ? aV : aS0;
       if constexpr (WPP == 2) __syncthreads();   // the other wave has left the node loops of the previous group: its rows may go
-      cap_frame_rings<L, (L <= 8 && WPP == 1), WPP>(P, lr, W, LL, tid, k0, kend - k0, lr[FR_HW], lr[FR_HM], WPP == 1);
+      cap_frame_rings<L, (L <= 8 && WPP == 1), WPP, true>(P, lr, W, LL, tid, k0, kend - k0, lr[FR_HW], lr[FR_HM], WPP == 1);
       park = SHP_LDS() + W.park + lane;
       aT2 = park[0];
       if (NEEDV) aV = park[64]; else aS0 = park[64];
