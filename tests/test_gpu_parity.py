@@ -814,6 +814,41 @@ def test_peratom_energy_and_virial(oracle, newton):
     sp.close()
 
 
+def test_two_waves_per_pair_with_tallies_newton_off_and_deterministic_mode(oracle):
+    """The two-wave kernels' epilogue (wave 0 adds the other half's sums and finishes the pair) through every output it
+    feeds: global and per-atom energy / virial, newton off with ghosts, and the per-slot stores of the deterministic mode
+    (bitwise equal across two computes), against the oracle."""
+    case = make_case(240, 9, 2, seed=61, rmax_fn=oracle.shape_rmax)
+    nlocal = 150
+    case = dict(case)
+    case["ilist"] = case["ilist"][:nlocal]
+    case["jlist"] = case["jlist"][:case["offsets"][nlocal]]
+    case["offsets"] = case["offsets"][:nlocal + 1]
+    K, E = coeff_tables(1, 800.0, 1.25)
+    b = case["bed"]
+    n = case["n"]
+    o = oracle_compute(oracle, case, 16, K, E, nlocal=nlocal, newton_pair=False, eflag=True, vflag=True, want_peratom=True)
+    es, vs = o["eatom"].max(), np.abs(o["vatom"]).max()
+    runs = []
+    for det in (0, 1, 1):
+        sp = make_ctx(case, 16, K, E)
+        sp.set_option("jpoly", 1)
+        sp.set_option("split", 1)
+        sp.set_option("deterministic", det)
+        ea, va = np.zeros(n), np.zeros((n, 6))
+        sp.set_peratom_host(ea, va)
+        f, tq, eng, vir = sp.compute(nlocal, b["x"], b["quat"], b["type"], b["shtype"], newton_pair=False, eflag=True, vflag=True)
+        assert sp.kernel_info()["waves_per_pair"] == 2
+        check(f, tq, o)
+        assert abs(eng - o["eng_virial"][0]) < TOL * o["eng_virial"][0]
+        assert np.abs(vir - o["eng_virial"][1:]).max() < TOL * np.abs(o["eng_virial"][1:]).max()
+        assert np.abs(ea - o["eatom"]).max() < TOL * es and np.abs(va - o["vatom"]).max() < TOL * vs
+        assert ea[nlocal:].max() == 0.0
+        runs.append((f.copy(), tq.copy()))
+        sp.close()
+    assert np.array_equal(runs[1][0], runs[2][0]) and np.array_equal(runs[1][1], runs[2][1])
+
+
 def test_kernel_info_reports_the_launched_footprint(oracle):
     case = make_case(60, 6, 1, seed=46, rmax_fn=oracle.shape_rmax)
     K, E = coeff_tables(1, 900.0, 1.25)
