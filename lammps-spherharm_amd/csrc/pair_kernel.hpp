@@ -129,9 +129,12 @@ constexpr int kPairErrCoincident = 4;   // two centres coincide (rho = 0) or the
   ((NEEDV) ? (((L) == 0 || (L) == 1 || (L) == 6) ? 6 : 5) : (((L) >= 0 && (L) <= 6) ? 6 : 5))
 #endif
 // kernels that evaluate particle j from per-azimuth polynomials (JPT): the rows of j's table are read from LDS
+// (80 registers up to L = 4, 96 up to L = 6 and for the one-wave kernel of L = 9 — which keeps the one-iterate form of
+// the search loop for it, root_loop_unrolled() — 128 beyond; A/B per order: profiles/r03_zzzz_ab_root_loop.txt)
 #ifndef SHP_JMIN_WAVES
-#define SHP_JMIN_WAVES(L, NEEDV) (((L) <= 6) ? 5 : 4)
+#define SHP_JMIN_WAVES(L, NEEDV, WPP) (((L) <= 4) ? 6 : (((L) <= 6 || ((L) == 9 && (WPP) == 1)) ? 5 : 4))
 #endif
+constexpr bool root_loop_unrolled(const int L, const int WPP) { return !(L == 9 && WPP == 1); }
 
 // docs/SPEC.md §2.6: residual below which the inverse-quadratic extrapolation is accepted
 #ifndef SHP_TAU3
@@ -307,7 +310,16 @@ __device__ __forceinline__ int mul_sel(const int a, const int b) { return ON ? _
 // (s_and_saveexec on the mask itself).
 // (the HIP wrappers __ballot / __any take an int: the predicate is first turned into 0 / 1 per lane and compared again)
 __device__ __forceinline__ unsigned long long wave_ballot(const bool p) { return __builtin_amdgcn_ballot_w64(p); }
-__device__ __forceinline__ bool wave_any(const bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ULL; }
+// wave_any: the mask passes through an (empty) scalar asm operand — compared directly, LLVM turns `ballot != 0` back into
+// the 0 / 1-per-lane idiom (v_cndmask + v_cmp + branch on vccz); through the operand it is s_cmp_lg_u64 + a scalar branch
+template <bool SCALAR = true>
+__device__ __forceinline__ bool mask_any(unsigned long long m)
+{
+  if constexpr (SCALAR) asm("" : "+s"(m));
+  return m != 0ULL;
+}
+template <bool SCALAR = true>
+__device__ __forceinline__ bool wave_any(const bool p) { return mask_any<SCALAR>(__builtin_amdgcn_ballot_w64(p)); }
 __device__ __forceinline__ bool lane_of(const unsigned long long mask) { return __builtin_amdgcn_inverse_ballot_w64(mask); }
 
 __device__ __forceinline__ unsigned launder_u32(unsigned v)
@@ -386,7 +398,24 @@ __device__ __forceinline__ double sqrt_nr(const double x) { return (x > 0.0) ? x
 
 // sqrt(x) with the one-step root: 2-3 ulp.  For the brackets, first iterate and end-point residual of the inner-radius
 // search and wherever else 1e-15 relative is far inside what the value is used for.
-__device__ __forceinline__ double sqrt_nr1(const double x) { return (x > 0.0) ? x * rsqrt_nr1(x) : 0.0; }
+// (x <= 0 and NaN give 1e-150 for 0: one v_max_f64 — written as such, fmax() adds a canonicalising v_max_f64 under IEEE
+// mode — instead of a compare and two selects)
+__device__ __forceinline__ double max_raw(const double x, const double c)
+{
+  double r;
+  asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(x), "v"(c));
+  return r;
+}
+template <bool CLAMP = false>
+__device__ __forceinline__ double sqrt_nr1(const double x)
+{
+  if constexpr (CLAMP) {
+    const double t = max_raw(x, 1e-300);
+    return t * rsqrt_nr1(t);
+  } else {
+    return (x > 0.0) ? x * rsqrt_nr1(x) : 0.0;   // (the body-frame kernels have no register for the constant)
+  }
+}
 
 // 1/d to the last ulp or two: v_rcp_f64 + two Newton steps (5 VALU ops instead of
 // the ~12 of an IEEE division); 0 and denormals give inf/NaN, which the callers test.
@@ -977,8 +1006,8 @@ __device__ __forceinline__ void ring_grad_rec(const double* __restrict__ row, co
     const double A = ab[0], B = ab[1], dm = (double)m;
     rmu = fma(dab[0], cm, rmu);
     rmu = fma(dab[1], sm, rmu);
-    rpsi = fma(dm * B, cm, rpsi);
-    rpsi = fma(-dm * A, sm, rpsi);
+    const double t = fma(B, cm, -(A * sm));   // three instructions per order (m B and m A as products of their own: four)
+    rpsi = (m == 1) ? t : fma(dm, t, rpsi);
     if (m < L) {
       const double c = fma(tc, cm, -cp), s = fma(tc, sm, -sp);
       cp = cm;
@@ -1029,7 +1058,7 @@ __device__ __forceinline__ void jpoly_eval2(const double* __restrict__ row, cons
 // of the azimuths; every table build runs on 128 lanes and every hand-over between the waves is a workgroup barrier
 // that BOTH waves reach the same number of times (the ring-group loop advances identically in both).
 template <int L, bool NEEDV, bool WEIGHTED = false, bool JPT = false, int WPP = 1>
-__global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L, NEEDV) : (WEIGHTED ? SHP_WMIN_WAVES(L) : SHP_MIN_WAVES(L, NEEDV))) pair_contact_kernel(const PairParams P)
+__global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L, NEEDV, WPP) : (WEIGHTED ? SHP_WMIN_WAVES(L) : SHP_MIN_WAVES(L, NEEDV))) pair_contact_kernel(const PairParams P)
 {
   static_assert(WPP == 1 || (WPP == 2 && JPT && L >= 0 && !WEIGHTED), "two waves per pair: compiled-order JPT kernels only");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -1270,7 +1299,7 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
         const double sN = s2 * inv;
         g0 = sN - fr[FR_RJ];  // outside B_j: the stand-in of SPEC §2.8 (>= 0)
         double rj0 = fr[FR_RJ];
-        if (wave_any(cand)) {  // wave-uniform
+        if (wave_any<false>(cand)) {  // wave-uniform
           const double rj0e = sh_eval<L>(rc, cwj, lrt, q0 * inv, q1 * inv, q2 * inv);
           if (!szero) rj0 = rj0e;
           if (cand) g0 = szero ? -rj0 : sN - rj0;
@@ -1397,7 +1426,10 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
       const double qb0 = fma(rib, mu, -rho), qb1 = -rib * sig;
       const double sa2 = fma(qa0, qa0, qa1 * qa1), sb2 = fma(qb0, qb0, qb1 * qb1);
       // candidates, inside nodes: masks (scalar unit), not lane predicates
-      const unsigned long long mvalid = wave_ballot(valid);
+      // the valid lanes are the first (count - 64 slab) of the wave: the mask from scalar arithmetic (as a ballot of
+      // `valid` it goes through a 0 / 1 value per lane)
+      const int nvalid = nq * per_ring - (slab << 6);
+      const unsigned long long mvalid = nvalid >= 64 ? ~0ULL : ((1ULL << nvalid) - 1ULL);
       const unsigned long long mca = wave_ballot(sa2 < rj2) & mvalid, mcb = wave_ballot(sb2 < rj2) & mvalid;
       if ((mca | mcb) == 0ULL) {   // wave-uniform: all 128 nodes miss B_j
 #ifdef SHP_STATS   // a slab of this family is 128 nodes: counted as two, so that the counters compare across families
@@ -1407,12 +1439,13 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
         continue;
       }
       const bool za = !(sa2 > 0.0), zb = !(sb2 > 0.0);
-      const double inva = rsqrt_nr1(fmax(sa2, 1e-300)), invb = rsqrt_nr1(fmax(sb2, 1e-300));
+      // no clamp of sa2, sb2 (two v_max_f64 each under IEEE mode): a node on x_j leaves NaN in r_j, replaced below
+      const double inva = rsqrt_nr1(sa2), invb = rsqrt_nr1(sb2);
       double rjae, rjbe;   // one pass over the lane's row of particle j's table serves both nodes
       jpoly_eval2<LJ>(fr + W.gh + mul_sel<JP>(l, jpoly_row(LJ)), qa0 * inva, qa1 * inva, qb0 * invb, qb1 * invb, rjae, rjbe);
       const double Rjl = s_rj;
       double rja = rjae, rjb = rjbe;
-      if (wave_any(za || zb)) {   // a node on x_j: measure zero; the volatile statement keeps this a branch
+      if (mask_any(wave_ballot(za) | wave_ballot(zb))) {   // a node on x_j: measure zero; the volatile statement keeps this a branch
         asm volatile("; rare: a node on x_j");
         rja = za ? Rjl : rjae;
         rjb = zb ? Rjl : rjbe;
@@ -1461,7 +1494,7 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
       if (cand) atomicAdd(&P.dbg[1], 1ULL);
       { const bool a_ = __any(cand); if (lane == 0 && a_) atomicAdd(&P.dbg[2], 1ULL); }
 #endif
-      if (!wave_any(cand)) continue;  // wave-uniform: the whole 64-node slab misses B_j
+      if (!wave_any<false>(cand)) continue;  // wave-uniform: the whole 64-node slab misses B_j
 
       // s == 0 (the node sits on x_j) is inside by definition; clamping s2 keeps that lane
       // finite without a select per component (its direction is then the zero vector)
@@ -1556,21 +1589,28 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
           s2i = q0 * q0 + q1 * q1 + q2 * q2;
         }
         const double rho2l = JP ? s_rho2 : fr[FR_RHO2];
-        if (!centre_in_bj) lo = bp - sqrt_nr1(JP ? fma(bp, bp, -s_pj) : fma(bp, bp, -(rho2l - fr[FR_RJ2])));
-        lam = bp - sqrt_nr1(fma(bp, bp, -(rho2l - rj0 * rj0)));
+        if (!centre_in_bj) lo = bp - sqrt_nr1<JP>(JP ? fma(bp, bp, -s_pj) : fma(bp, bp, -(rho2l - fr[FR_RJ2])));
+        lam = bp - sqrt_nr1<JP>(fma(bp, bp, -(rho2l - rj0 * rj0)));
         if (!(lam > lo && lam < hi)) lam = 0.5 * (lo + hi);
-        ga = gb = sqrt_nr1(s2i) - rj0;
+        ga = gb = sqrt_nr1<JP>(s2i) - rj0;
       }
       if (!act) lam = ri;
       // JPT: the byte address of the node's row of particle j's table, laundered (no instruction) at every iteration so
       // that the reads stay in the loop; re-deriving it from the wave's scalar LDS offset cost three vector instructions
       unsigned jrow_addr = wave_off + 8u * (unsigned)ghrow_;
-      for (int it = 0; it < 60; ++it) {
-        if (!wave_any(act)) break;
+      // the lanes still searching, as a scalar mask: the votes and the loop's exit are scalar compares, the loop counter
+      // a scalar register (as a lane predicate the exit counts as divergent: counter and tests become vector code)
+      unsigned long long mact = wave_ballot(act);
+      // One iterate of the search.  The three most recent points live in three (x, g) slots that trade roles from one
+      // iterate to the next — (xa,ga) oldest, (xb,gb) middle, lam the point evaluated now, gc its residual — and the
+      // loop below is written three iterates long, so that no slot is ever copied into another (as a shift of the
+      // history the loop carried five 64-bit moves per iterate, each an issue slot beside the FP64 work).
+      auto iterate = [&](double& xa, double& ga, const double xb, const double gb, const double lam, double& gc,
+                         const bool have3) __attribute__((always_inline)) {
         if constexpr (!JP) fr = SHP_LDS();
 #ifdef SHP_STATS
         if (lane == 0) atomicAdd(&P.dbg[5], 1ULL);
-        if (act) atomicAdd(&P.dbg[6], 1ULL);
+        if (lane_of(mact)) atomicAdd(&P.dbg[6], 1ULL);
 #endif
         double y0, y1, y2 = 0.0, ss2;
         if constexpr (JP) {
@@ -1584,7 +1624,7 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
           ss2 = y0 * y0 + y1 * y1 + y2 * y2;
         }
         const bool z0 = !(ss2 > 0.0);
-        const double iv = rsqrt_nr1(fmax(ss2, 1e-300));
+        const double iv = rsqrt_nr1(ss2);   // ss2 = 0: NaN in r_j and g, replaced in the rare branch below
         double rj;
         if constexpr (JP) {   // the node's row, read at every iteration
           jrow_addr = launder_u32(jrow_addr);
@@ -1594,7 +1634,7 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
         }
         const double Rjl = JP ? s_rj : fr[FR_RJ];
         double gl = ss2 * iv - rj;
-        if (wave_any(z0)) {   // the point sits on x_j (measure zero): a wave-uniform branch, not two selects per iteration
+        if (wave_any<JP>(z0)) {   // the point sits on x_j (measure zero): a wave-uniform branch, not two selects per iteration
           asm volatile("; rare: a point on x_j");   // ... which the volatile statement keeps a branch (no if-conversion)
           gl = z0 ? -Rjl : gl;
         }
@@ -1608,7 +1648,7 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
           const bool pos = gl >= 0.0;
           lo = pos ? lam : lo;
           hi = pos ? hi : lam;
-          const bool have3 = it >= 1;  // wave-uniform
+          // have3: wave-uniform (false on the first iterate only)
           const double dbl = gb - gl;
           // extrapolation to g = 0: secant through two points on the first iterate, inverse
           // quadratic interpolation (one common denominator) through three afterwards
@@ -1625,8 +1665,8 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
           const bool accept = JP ? (fabs(gl) <= (have3 ? s_tol3 : s_tol1)) : (fabs(gl) <= (have3 ? SHP_TAU3 : 1e-7) * Rjl);
           const bool tiny = JP ? (hi - lo <= s_tiny) : (hi - lo <= 1e-14 * Rjl);
           double res = ext, nxt = ext;
-          bool stop = accept;
-          if (wave_any(act && (!inb || tiny))) {
+          unsigned long long mstop = wave_ballot(accept);
+          if (mask_any<JP>(mact & (wave_ballot(tiny) | ~(wave_ballot(ext > lo) & wave_ballot(ext < hi))))) {
             // the general case, lane by lane with selects: the secant is the fallback of the interpolation, the
             // midpoint the fallback of both; an accepted point is clamped to the bracket
             double sec = ext, e2 = ext;
@@ -1642,11 +1682,32 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
             const double accv = (fabs(e2) <= 1e300) ? fmin(fmax(e2, lo), hi) : lam;
             res = accept ? accv : (tiny ? mid : n2);
             nxt = n2;
-            stop = accept || tiny;
+            mstop |= wave_ballot(tiny);
           }
-          rin = act ? res : rin;
-          act = act && !stop;
-          xa = xb; ga = gb; xb = lam; gb = gl; lam = nxt;
+          rin = lane_of(mact) ? res : rin;
+          mact &= ~mstop;
+          gc = gl;    // the point just evaluated stays where it is ...
+          xa = nxt;   // ... and the next one takes the place of the oldest: nothing moves
+        }
+      };
+      double gl0 = 0.0;
+      if constexpr (JP && root_loop_unrolled(L, WPP)) {
+        for (int it = 0; it < 60; it = __builtin_amdgcn_readfirstlane(it + 3)) {   // (a scalar counter, said so)
+          if (!mask_any(mact)) break;
+          iterate(xa, ga, xb, gb, lam, gl0, it >= 1);
+          if (!mask_any(mact)) break;
+          iterate(xb, gb, lam, gl0, xa, ga, true);
+          if (!mask_any(mact)) break;
+          iterate(lam, gl0, xa, ga, xb, gb, true);
+        }
+      } else {
+        // body-frame kernels (and L = 9 with one wave per pair): one iterate per trip and the history shifted — their
+        // registers are spoken for: three copies of the iterate, each with a full evaluation, spill or cost a wave
+        for (int it = 0; it < 60; it = __builtin_amdgcn_readfirstlane(it + 1)) {
+          if (!mask_any<JP>(mact)) break;
+          iterate(xa, ga, xb, gb, lam, gl0, it >= 1);
+          const double nx = xa;
+          xa = xb; ga = gb; xb = lam; gb = gl0; lam = nx;
         }
       }
       // a node outside j contributes exactly nothing (r^3 - r^3 under FMA contraction is a rounding residue, and
