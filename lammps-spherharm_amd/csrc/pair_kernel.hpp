@@ -568,7 +568,6 @@ __device__ __forceinline__ void rotate_lane_block(const PairParams& P, double* _
   // wave) the step gets 3.9 % slower, so from L = 9 on the plain pointers stay (profiles/r03_z_ab_rot_scalar.txt).
   const auto xval = [&] { if constexpr (rot_tiled(L)) return launder_uniform(P.xval); else return P.xval; }();
   const auto gsc = [&] { if constexpr (rot_tiled(L)) return launder_uniform(P.gscale); else return P.gscale; }();
-  const auto xcol = [&] { if constexpr (rot_tiled(L)) return launder_uniform_i(P.xcol); else return P.xcol; }();
   double* A = sm + RotLaneLds<L>::a() + lane;
   double* B = sm + RotLaneLds<L>::b() + lane;
   // Z(alpha) on the way in: the pair (l, +m), (l, -m) turns by m alpha
@@ -586,8 +585,17 @@ __device__ __forceinline__ void rotate_lane_block(const PairParams& P, double* _
   for (int r = 0; r < n; ++r) {
     const size_t ro = ((size_t)ns + base + r) * XW;
     double o = 0.0;
+    // the columns of row (LB, r - LB) are known at compile time (sh_const::xpat_*): immediate LDS offsets, no index loads
+    // (constants once the loops are unrolled)
+    const int first = sh_const::xpat_first(LB, r - LB), count = sh_const::xpat_count(LB, r - LB);
 #pragma unroll
-    for (int t = 0; t < XN; ++t) o = fma(xval[ro + t], A[64 * (xcol[ro + t] - base)], o);
+    for (int t = 0; t < XN; ++t) {
+      if constexpr (rot_tiled(L)) {
+        if (t < count) o = fma(xval[ro + t], A[64 * (LB + first + 2 * t)], o);
+      } else {
+        o = fma(xval[ro + t], A[64 * (P.xcol[ro + t] - base)], o);   // L >= 9: the table's own columns (see below)
+      }
+    }
     xb[r] = o;
   }
   // Z(beta), in registers
@@ -604,33 +612,69 @@ __device__ __forceinline__ void rotate_lane_block(const PairParams& P, double* _
   for (int r = 0; r < n; ++r) {
     const size_t ro = ((size_t)base + r) * XW;
     double o = 0.0;
+    const int first = sh_const::xpat_first(LB, r - LB), count = sh_const::xpat_count(LB, r - LB);
 #pragma unroll
-    for (int t = 0; t < XN; ++t) o = fma(xval[ro + t], B[64 * (xcol[ro + t] - base)], o);
+    for (int t = 0; t < XN; ++t) {
+      if constexpr (rot_tiled(L)) {
+        if (t < count) o = fma(xval[ro + t], B[64 * (LB + first + 2 * t)], o);
+      } else {
+        o = fma(xval[ro + t], B[64 * (P.xcol[ro + t] - base)], o);   // L >= 9: the table's own columns (see below)
+      }
+    }
     xb[r] = o;
   }
-  // Z(gamma) and the ring scale, in registers; then the block leaves transposed through LDS: consecutive lanes
-  // write consecutive elements of one rotation
-  A[64 * LB] = xb[LB] * gsc[base + LB];
-#pragma unroll
-  for (int m = 1; m <= LB; ++m) {
-    const double c = T.c[2 * L + m - 1], s = T.s[2 * L + m - 1];
-    const double p = xb[LB + m], q = xb[LB - m];
-    A[64 * (LB + m)] = fma(c, p, s * q) * gsc[base + LB + m];
-    A[64 * (LB - m)] = fma(c, q, -(s * p)) * gsc[base + LB - m];
-  }
-  wave_lds_sync();
-  const double* At = sm + RotLaneLds<L>::a();
-#pragma unroll
-  for (int it = 0; it < n; ++it) {
-    const int idx = lane + 64 * it;   // < 64 n
-    const int tk = idx / n, r = idx - tk * n;
-    // task0 is a multiple of 64 (one tile per workgroup): this is rot_index(L, task0 + tk, LB, r), consecutive in `idx`
-    if (task0 + tk < ntasks) {
-      if constexpr (rot_tiled(L)) rot[(size_t)(task0 >> 6) * rot_tile_doubles(L) + 64 * base + idx] = At[64 * r + tk];
-      else rot[(size_t)(task0 + tk) * rot_row_doubles(L) + base + r] = At[64 * r + tk];
+  if constexpr (rot_tiled(L)) {
+    // Z(gamma) and the ring scale, in registers; then the block leaves through LDS in ROTATION-major order (lane's row of
+    // n numbers at lane n: odd stride, the plain two passes of a 64-bit write), so that consecutive lanes read — and
+    // store to global memory — consecutive elements with no index arithmetic at all: element idx = lane + 64 it of the
+    // tile's block is LDS cell idx.  (Read back from the column layout it was a division, a multiply and an exec-masked
+    // branch per store: 490 of the kernel's 1 755 vector instructions at L = 6.)
+    double* A2 = sm + RotLaneLds<L>::a() + lane * n;
+    A2[LB] = xb[LB] * gsc[base + LB];
+  #pragma unroll
+    for (int m = 1; m <= LB; ++m) {
+      const double c = T.c[2 * L + m - 1], s = T.s[2 * L + m - 1];
+      const double p = xb[LB + m], q = xb[LB - m];
+      A2[LB + m] = fma(c, p, s * q) * gsc[base + LB + m];
+      A2[LB - m] = fma(c, q, -(s * p)) * gsc[base + LB - m];
     }
+    wave_lds_sync();
+    const double* At = sm + RotLaneLds<L>::a() + lane;
+    double* out = rot + (size_t)(task0 >> 6) * rot_tile_doubles(L) + 64 * base + lane;
+    if (task0 + 64 <= ntasks) {   // a full tile (every workgroup but the last): wave-uniform
+  #pragma unroll
+      for (int it = 0; it < n; ++it) out[64 * it] = At[64 * it];
+    } else {
+  #pragma unroll
+      for (int it = 0; it < n; ++it) {
+        const int idx = lane + 64 * it;   // < 64 n
+        // task0 is a multiple of 64 (one tile per workgroup): cell idx is rot_index(L, task0 + idx / n, LB, idx % n)
+        if (task0 + idx / n < ntasks) out[64 * it] = At[64 * it];
+      }
+    }
+    wave_lds_sync();
+  } else {
+    // L >= 9 (rotation-major rows in memory, 244 vector registers: two waves per SIMD): the block leaves transposed
+    // through LDS from the column layout; compile-time columns and the lane-major block push these kernels past 256
+    // registers — one wave per SIMD, L = 12 / n_q = 32 2 % slower (profiles/r03_zzzzz_ab_rot.txt)
+    A[64 * LB] = xb[LB] * gsc[base + LB];
+  #pragma unroll
+    for (int m = 1; m <= LB; ++m) {
+      const double c = T.c[2 * L + m - 1], s = T.s[2 * L + m - 1];
+      const double p = xb[LB + m], q = xb[LB - m];
+      A[64 * (LB + m)] = fma(c, p, s * q) * gsc[base + LB + m];
+      A[64 * (LB - m)] = fma(c, q, -(s * p)) * gsc[base + LB - m];
+    }
+    wave_lds_sync();
+    const double* At = sm + RotLaneLds<L>::a();
+  #pragma unroll
+    for (int it = 0; it < n; ++it) {
+      const int idx = lane + 64 * it;   // < 64 n
+      const int tk = idx / n, r = idx - tk * n;
+      if (task0 + tk < ntasks) rot[(size_t)(task0 + tk) * rot_row_doubles(L) + base + r] = At[64 * r + tk];
+    }
+    wave_lds_sync();
   }
-  wave_lds_sync();
   if constexpr (LB < L) rotate_lane_block<L, LB + 1>(P, sm, lane, cre, rot, task0, ntasks, T);
 }
 template <int L>

@@ -75,5 +75,21 @@ SHP_HD constexpr double aprime(int n, int m)
 // what the host multiplies (2 - delta_m0) a_nm with
 SHP_HD constexpr double coef_scale(int n, int m) { return scale(n, m) * pmm(m); }
 
+
+// Sparsity of X = the real-harmonic matrix of Rx(+90) (and of its transpose), degree l: row m (m < 0 the sin, m >= 0
+// the cos functions) couples to the columns m' = xpat_first, xpat_first + 2, ... (xpat_count of them, <= l / 2 + 1) —
+// one sign class and one parity, by the y- and z-parities of the two functions.  The host's ELL tables are laid out by
+// this rule and check it against the computed matrices (sh_tables.cpp build_xmats_ell).
+SHP_HD constexpr int xpat_first(int l, int m)
+{
+  if (m >= 0) return ((l - m) % 2 == 0) ? (l & 1) : -l;
+  return ((l - m) % 2 == 0) ? 1 - (l & 1) : -(l - 1);
+}
+SHP_HD constexpr int xpat_count(int l, int m)
+{
+  if (m >= 0) return ((l - m) % 2 == 0) ? l / 2 + 1 : (l + 1) / 2;
+  return ((l - m) % 2 == 0) ? (l + 1) / 2 : l / 2;
+}
+
 }  // namespace sh_const
 }  // namespace shp

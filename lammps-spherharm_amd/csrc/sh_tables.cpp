@@ -275,6 +275,10 @@ void build_xmats(int L, std::vector<double>& xp, std::vector<double>& xpt)
 
 void build_xmats_ell(int L, std::vector<double>& val, std::vector<int>& col, std::vector<int>& info)
 {
+  // Row (l, m) of X (and of X^T) couples to the columns m' = first, first + 2, ... of ONE parity class
+  // (sh_const::xpat_first / xpat_count): slot t of the row holds the entry of column first + 2 t whether or not it
+  // happens to vanish, so that the rotation kernel of the compiled orders can address the columns at compile time.
+  // Everything outside the pattern must be a structural zero: checked here, an empty `val` reports the failure.
   std::vector<double> xp, xpt;
   build_xmats(L, xp, xpt);
   const int ns = (L + 1) * (L + 1), W = L / 2 + 1;
@@ -289,20 +293,19 @@ void build_xmats_ell(int L, std::vector<double>& val, std::vector<int>& col, std
       for (int r = 0; r < n; ++r) {
         const int e = l * l + r;
         info[e] = l | (r << 8);
-        int t = 0;
+        const int first = sh_const::xpat_first(l, r - l), count = sh_const::xpat_count(l, r - l);
         for (int c = 0; c < n; ++c) {
           const double v = x[off + (size_t)r * n + c];
-          if (v == 0.0) continue;
-          if (t >= W) { t = -1; break; }
-          val[((size_t)which * ns + e) * W + t] = v;
-          col[((size_t)which * ns + e) * W + t] = l * l + c;
-          ++t;
+          const int d = (c - l) - first;
+          const bool inpat = d >= 0 && (d % 2) == 0 && d / 2 < count;
+          if (inpat) {
+            val[((size_t)which * ns + e) * W + d / 2] = v;
+          } else if (v != 0.0) {  // cannot happen for Rx(90): never truncate silently
+            val.clear();
+            return;
+          }
         }
-        if (t < 0) {  // cannot happen for Rx(90); keep the dense tail out of silent truncation
-          val.clear();
-          return;
-        }
-        for (; t < W; ++t) col[((size_t)which * ns + e) * W + t] = l * l;
+        for (int t = 0; t < W; ++t) col[((size_t)which * ns + e) * W + t] = (t < count) ? l * l + l + first + 2 * t : l * l;
       }
       off += (size_t)n * n;
     }
