@@ -129,12 +129,11 @@ constexpr int kPairErrCoincident = 4;   // two centres coincide (rho = 0) or the
   ((NEEDV) ? (((L) == 0 || (L) == 1 || (L) == 6) ? 6 : 5) : (((L) >= 0 && (L) <= 6) ? 6 : 5))
 #endif
 // kernels that evaluate particle j from per-azimuth polynomials (JPT): the rows of j's table are read from LDS
-// (80 registers up to L = 4, 96 up to L = 6 and for the one-wave kernel of L = 9 — which keeps the one-iterate form of
-// the search loop for it, root_loop_unrolled() — 128 beyond; A/B per order: profiles/r03_zzzz_ab_root_loop.txt)
+// (80 registers up to L = 4, 96 up to L = 6 and for the one-wave kernel of L = 9, 128 beyond — L = 5, 8 and the two-wave
+// kernel of L = 9 come out a step below their bound; A/B per order: profiles/r03_zzzz_ab_root_loop.txt, r03_zzzzzz_ab_lds_abs.txt)
 #ifndef SHP_JMIN_WAVES
 #define SHP_JMIN_WAVES(L, NEEDV, WPP) (((L) <= 4) ? 6 : (((L) <= 6 || ((L) == 9 && (WPP) == 1)) ? 5 : 4))
 #endif
-constexpr bool root_loop_unrolled(const int L, const int WPP) { return !(L == 9 && WPP == 1); }
 
 // docs/SPEC.md §2.6: residual below which the inverse-quadratic extrapolation is accepted
 #ifndef SHP_TAU3
@@ -322,6 +321,11 @@ template <bool SCALAR = true>
 __device__ __forceinline__ bool wave_any(const bool p) { return mask_any<SCALAR>(__builtin_amdgcn_ballot_w64(p)); }
 __device__ __forceinline__ bool lane_of(const unsigned long long mask) { return __builtin_amdgcn_inverse_ballot_w64(mask); }
 
+__device__ __forceinline__ unsigned launder_s32(unsigned v)   // ... of a wave-uniform value: it stays in a scalar register
+{
+  asm volatile("" : "+s"(v));
+  return v;
+}
 __device__ __forceinline__ unsigned launder_u32(unsigned v)
 {
   asm volatile("" : "+v"(v));
@@ -1132,8 +1136,14 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
   // in LDS to avoid.  Each loop iteration therefore re-derives its base pointer
   // from a byte offset laundered through an empty asm (an integer, so that the
   // compiler still sees an LDS address and emits ds_read, not flat loads).
+  // The wave's LDS as an ABSOLUTE 32-bit LDS address in a scalar register: pointers made from it are an inttoptr, so an
+  // address is one v_add with the scalar as an operand (through `smem_raw + offset` every re-derivation was a v_mov of
+  // the offset and a v_add of the array's link-time address, 0: two issue slots, several times per slab and batch).
+  typedef __attribute__((address_space(3))) unsigned char lds_byte_t;
   const unsigned wave_off = (WPP == 2) ? 0u : (unsigned)(wib * P.wave_lds_bytes);
-#define SHP_LDS() ((double*)(smem_raw + launder_u32(wave_off)))
+  const unsigned wave_abs = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_byte_t*)smem_raw + wave_off);
+  // (the body-frame kernels are out of scalar registers: they keep the array-relative form)
+#define SHP_LDS() (JP ? (double*)(lds_byte_t*)(size_t)launder_s32(wave_abs) : (double*)(smem_raw + launder_u32(wave_off)))
   double* lw = SHP_LDS();
 
   // the pair's record (pair_setup.hpp): scalar loads of the four ints, one coalesced vector load of the frame
@@ -1641,7 +1651,7 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
       if (!act) lam = ri;
       // JPT: the byte address of the node's row of particle j's table, laundered (no instruction) at every iteration so
       // that the reads stay in the loop; re-deriving it from the wave's scalar LDS offset cost three vector instructions
-      unsigned jrow_addr = wave_off + 8u * (unsigned)ghrow_;
+      unsigned jrow_addr = wave_abs + 8u * (unsigned)ghrow_;
       // the lanes still searching, as a scalar mask: the votes and the loop's exit are scalar compares, the loop counter
       // a scalar register (as a lane predicate the exit counts as divergent: counter and tests become vector code)
       unsigned long long mact = wave_ballot(act);
@@ -1672,7 +1682,7 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
         double rj;
         if constexpr (JP) {   // the node's row, read at every iteration
           jrow_addr = launder_u32(jrow_addr);
-          rj = jpoly_eval<LJ>((const double*)(smem_raw + jrow_addr), y0 * iv, y1 * iv);
+          rj = jpoly_eval<LJ>((const double*)(lds_byte_t*)(size_t)jrow_addr, y0 * iv, y1 * iv);
         } else {
           rj = sh_eval<L>(rc, cwj, lrt, y0 * iv, y1 * iv, y2 * iv);
         }
@@ -1735,7 +1745,7 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
         }
       };
       double gl0 = 0.0;
-      if constexpr (JP && root_loop_unrolled(L, WPP)) {
+      if constexpr (JP) {
         for (int it = 0; it < 60; it = __builtin_amdgcn_readfirstlane(it + 3)) {   // (a scalar counter, said so)
           if (!mask_any(mact)) break;
           iterate(xa, ga, xb, gb, lam, gl0, it >= 1);
@@ -1745,8 +1755,8 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
           iterate(lam, gl0, xa, ga, xb, gb, true);
         }
       } else {
-        // body-frame kernels (and L = 9 with one wave per pair): one iterate per trip and the history shifted — their
-        // registers are spoken for: three copies of the iterate, each with a full evaluation, spill or cost a wave
+        // body-frame kernels: one iterate per trip and the history shifted — their registers are spoken for: three
+        // copies of the iterate, each with a full evaluation, spill
         for (int it = 0; it < 60; it = __builtin_amdgcn_readfirstlane(it + 1)) {
           if (!mask_any<JP>(mact)) break;
           iterate(xa, ga, xb, gb, lam, gl0, it >= 1);
