@@ -1444,9 +1444,11 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
     while (qcount < 64 && slab < slab_end) {
       fr = SHP_LDS();
       const int pp = (slab << 6) + lane;   // node pair: ring k, azimuths l and l + n_q
-      const bool valid = pp < nq * per_ring;
-      const int k = valid ? (int)(umul_sel<JP>((unsigned)pp, magicr) >> 24) : k0;   // idle lanes read a resident row
-      const int l = (valid ? pp - mul_sel<JP>(k, per_ring) : 0) + half * per_ring;
+      // idle lanes (past the last node pair: in the last slab only, whose group holds the last ring) take the last node
+      // pair — a resident row, and one v_min instead of a compare, a masked region and two selects; mvalid drops them
+      const int ppc = min(pp, nq * per_ring - 1);
+      const int k = (int)(umul_sel<JP>((unsigned)ppc, magicr) >> 24);
+      const int l = ppc - mul_sel<JP>(k, per_ring) + half * per_ring;
       const double* row = fr + W.ring + (k - k0) * rowlen;
       const v2d r01 = lds2(row);   // (A_k0, mu_k)
       const double mu = r01[1], sig = row[3];
@@ -1493,19 +1495,20 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
         continue;
       }
       const bool za = !(sa2 > 0.0), zb = !(sb2 > 0.0);
+      const unsigned long long mza = wave_ballot(za), mzb = wave_ballot(zb);   // once: the compares' own scalar pairs
       // no clamp of sa2, sb2 (two v_max_f64 each under IEEE mode): a node on x_j leaves NaN in r_j, replaced below
       const double inva = rsqrt_nr1(sa2), invb = rsqrt_nr1(sb2);
       double rjae, rjbe;   // one pass over the lane's row of particle j's table serves both nodes
       jpoly_eval2<LJ>(fr + W.gh + mul_sel<JP>(l, jpoly_row(LJ)), qa0 * inva, qa1 * inva, qb0 * invb, qb1 * invb, rjae, rjbe);
       const double Rjl = s_rj;
       double rja = rjae, rjb = rjbe;
-      if (mask_any(wave_ballot(za) | wave_ballot(zb))) {   // a node on x_j: measure zero; the volatile statement keeps this a branch
+      if (mask_any(mza | mzb)) {   // a node on x_j: measure zero; the volatile statement keeps this a branch
         asm volatile("; rare: a node on x_j");
         rja = za ? Rjl : rjae;
         rjb = zb ? Rjl : rjbe;
       }
-      const unsigned long long ma = mca & (wave_ballot(za) | wave_ballot(sa2 * inva < rja));
-      const unsigned long long mb = mcb & (wave_ballot(zb) | wave_ballot(sb2 * invb < rjb));
+      const unsigned long long ma = mca & (mza | wave_ballot(sa2 * inva < rja));
+      const unsigned long long mb = mcb & (mzb | wave_ballot(sb2 * invb < rjb));
       const int pa = mul_sel<JP>(k, npsi) + l;
       if (qcount + __builtin_popcountll(ma) + __builtin_popcountll(mb) > kQueue) break;   // wave-uniform; qcount > 0 here
 #ifdef SHP_STATS
