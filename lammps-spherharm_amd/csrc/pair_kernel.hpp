@@ -1167,10 +1167,13 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
       const int e = tid + NT * t;
       const int ec = e < ns ? e : 0;
       if constexpr (rot_tiled(L)) {
-        const int l = (int)__builtin_sqrtf((float)ec);   // exact for these small integers
-        const size_t at = rot_index(L, 2 * w, l, ec - l * l);
-        vi[t] = P.rot[at];
-        vj[t] = P.rot[at + (2 * l + 1)];
+        // l = floor(sqrt(e)) from the bare v_sqrt_f32 (half an integer of margin against its last bits; sqrtf() is the
+        // IEEE sequence, ~18 instructions); the address as a scalar tile base plus a 32-bit lane offset = rot_index()
+        const int l = (int)__builtin_amdgcn_sqrtf((float)ec + 0.5f);
+        const double* tile = P.rot + (size_t)((2 * w) >> 6) * rot_tile_doubles(L);
+        const unsigned at = 64u * (unsigned)(l * l) + (unsigned)((2 * w) & 63) * (unsigned)(2 * l + 1) + (unsigned)(ec - l * l);
+        vi[t] = tile[at];
+        vj[t] = tile[at + (unsigned)(2 * l + 1)];
       } else {
         const size_t at = (size_t)(2 * w) * rot_row_doubles(L) + ec;
         vi[t] = P.rot[at];
@@ -1590,7 +1593,8 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
     fr = SHP_LDS();
     const int cnt = qcount < 64 ? qcount : 64;
     const bool active = lane < cnt;
-    const int e = (qhead + (active ? lane : 0)) & (kQueue - 1);
+    // (idle lanes repeat a queued node, with weight 0: the last one through a v_min in the per-azimuth kernels)
+    const int e = (qhead + (JP ? min(lane, cnt - 1) : (active ? lane : 0))) & (kQueue - 1);
     qhead = (qhead + cnt) & (kQueue - 1);
     qcount -= cnt;
 #ifdef SHP_STATS
@@ -1651,13 +1655,15 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
         if (!(lam > lo && lam < hi)) lam = 0.5 * (lo + hi);
         ga = gb = sqrt_nr1<JP>(s2i) - rj0;
       }
-      if (!act) lam = ri;
+      if constexpr (!JP) { if (!act) lam = ri; }   // (JP: an idle lane repeats a live node's search and is never read)
       // JPT: the byte address of the node's row of particle j's table, laundered (no instruction) at every iteration so
       // that the reads stay in the loop; re-deriving it from the wave's scalar LDS offset cost three vector instructions
       unsigned jrow_addr = wave_abs + 8u * (unsigned)ghrow_;
       // the lanes still searching, as a scalar mask: the votes and the loop's exit are scalar compares, the loop counter
       // a scalar register (as a lane predicate the exit counts as divergent: counter and tests become vector code)
-      unsigned long long mact = wave_ballot(act);
+      unsigned long long mact;
+      if constexpr (JP) mact = centre_inside ? 0ULL : (cnt >= 64 ? ~0ULL : ((1ULL << cnt) - 1ULL));   // scalar arithmetic
+      else mact = wave_ballot(act);
       // One iterate of the search.  The three most recent points live in three (x, g) slots that trade roles from one
       // iterate to the next — (xa,ga) oldest, (xb,gb) middle, lam the point evaluated now, gc its residual — and the
       // loop below is written three iterates long, so that no slot is ever copied into another (as a shift of the
