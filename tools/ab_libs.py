@@ -17,7 +17,8 @@ ap.add_argument("--lmax", type=int, default=6)
 ap.add_argument("--nq", type=int, default=16)
 ap.add_argument("--expo", type=float, default=1.25)
 ap.add_argument("--n", type=int, default=100000)
-ap.add_argument("--rounds", type=int, default=5)
+ap.add_argument("--rounds", type=int, default=8)
+ap.add_argument("--reps", type=int, default=4, help="launches per sample")
 ap.add_argument("--rule", type=int, default=0, help="0 sharp, 1 weighted (docs/SPEC.md §2.8)")
 ap.add_argument("--wpb", type=int, nargs="*", default=[0], help="waves per workgroup per lib (0 = default)")
 ap.add_argument("--ring-rows", type=int, nargs="*", default=[0], help="one value per lib (0 = library default)")
@@ -72,14 +73,23 @@ a.libs = [f"{lib}#{rows}w{w}j{j}p{pad}s{sv}d{dv}" for lib, rows, w, j, pad, sv, 
 res = {lib: [] for lib in a.libs}
 fref = None
 for r in range(a.rounds + 1):
-    for lib, sp in zip(a.libs, ctxs):
-        f.zero_()
-        tq.zero_()
-        sp.compute_device(a.n, 0, x.data_ptr(), q.data_ptr(), ty.data_ptr(), sh.data_ptr(), f.data_ptr(),
-                          tq.data_ptr())
-        torch.cuda.synchronize()
+    # the order of the builds alternates from round to round (a build that always runs first, or always after the same
+    # neighbour, sees a different clock: measured bias of a fixed order ~2 % over 5-7 single-launch rounds), and a
+    # sample is the mean of --reps launches back to back
+    order = list(zip(a.libs, ctxs))
+    if r % 2 == 1:
+        order.reverse()
+    for lib, sp in order:
+        ks = []
+        for _ in range(a.reps if r > 0 else 1):
+            f.zero_()
+            tq.zero_()
+            sp.compute_device(a.n, 0, x.data_ptr(), q.data_ptr(), ty.data_ptr(), sh.data_ptr(), f.data_ptr(),
+                              tq.data_ptr())
+            torch.cuda.synchronize()
+            ks.append(sp.stats()["kernel_ms"])
         if r > 0:
-            res[lib].append(sp.stats()["kernel_ms"])
+            res[lib].append(float(np.mean(ks)))
         else:  # first round: all builds must agree on the forces
             fh = f.cpu().numpy()
             if fref is None:
