@@ -68,6 +68,15 @@ int main(int argc, char** argv)
           if (xcol[((size_t)ns + l * l + r) * XW + t] == l * l + c) et += xval[((size_t)ns + l * l + r) * XW + t];
         ell = fmax(ell, fabs(et - xpt[off + r * n + c]));
       }
+      // the layout the rotation kernel of the compiled orders addresses at compile time (sh_const::xpat_*): slot t of
+      // the row is column first + 2 t for t < count, empty beyond — in both tables
+      const int first = shp::sh_const::xpat_first(l, r - l), count = shp::sh_const::xpat_count(l, r - l);
+      for (int which = 0; which < 2; ++which)
+        for (int t = 0; t < XW; ++t) {
+          const size_t k = ((size_t)which * ns + l * l + r) * XW + t;
+          if (t < count ? (xcol[k] != l * l + l + first + 2 * t) : (xval[k] != 0.0)) ell = 2.0;
+        }
+      if (count > l / 2 + 1 || count < 1) ell = 3.0;
       if (nz - (l / 2 + 1) > maxnz_excess) maxnz_excess = nz - (l / 2 + 1);
       if (xinfo[l * l + r] != (l | (r << 8))) ell = 1.0;
     }
