@@ -311,6 +311,7 @@ __device__ __forceinline__ int mul_sel(const int a, const int b) { return ON ? _
 __device__ __forceinline__ unsigned long long wave_ballot(const bool p) { return __builtin_amdgcn_ballot_w64(p); }
 // wave_any: the mask passes through an (empty) scalar asm operand — compared directly, LLVM turns `ballot != 0` back into
 // the 0 / 1-per-lane idiom (v_cndmask + v_cmp + branch on vccz); through the operand it is s_cmp_lg_u64 + a scalar branch
+// (SCALAR = false, the plain comparison: the body-frame kernels, which have no scalar register to spare for it)
 template <bool SCALAR = true>
 __device__ __forceinline__ bool mask_any(unsigned long long m)
 {
