@@ -413,10 +413,11 @@ static bool use_split(const shpair_ctx* c, const bool jpoly)
 {
   if (!jpoly || !split_compiled(c->lmax) || c->lmax > kMaxUnrolledL || (c->nq & 1) || c->nq < 8) return false;
   if (c->opt_split >= 0) return c->opt_split == 1;
-  // measured (interleaved A/B over L = 7..12 x n_q = 8..32, profiles/r03_g_split_matrix.txt, r03_h_split_matrix.txt; the
-  // boxes' noise is +-3 %): two waves win by 4-13 % at n_q = 32 from L = 8 on and at L = 12 from n_q = 16 on, lose
-  // below (at n_q = 8 half of each wave's lanes have no node pair: +40 %)
-  return (c->lmax >= 8 && c->nq >= 32) || (c->lmax >= 12 && c->nq >= 16);
+  // measured (interleaved A/B over L = 7..12 x n_q = 8..32, profiles/r03_g/h_split_matrix.txt and, on the end-of-round
+  // kernels, r03_fin_split_matrix.txt; the boxes' noise is +-3 %): two waves win by 4-16 % at n_q = 32 from L = 8 on, at
+  // n_q = 24 from L = 10 on (4-9 %) and at L = 12 from n_q = 16 on (7-12 %); they lose below (at n_q = 8 half of each
+  // wave's lanes have no node pair: +40 %)
+  return (c->lmax >= 8 && c->nq >= 32) || (c->lmax >= 10 && c->nq >= 24) || (c->lmax >= 12 && c->nq >= 16);
 }
 
 }  // extern "C"
