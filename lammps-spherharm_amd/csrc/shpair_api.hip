@@ -686,7 +686,22 @@ int shpair_compute_device(shpair_ctx* c, int nlocal, int nghost, const double* x
     const int rows_min = 1 + (63 + per_ring - 1) / per_ring;
     int rows = nq;
     if (c->opt_ring_rows > 0) rows = c->opt_ring_rows;
-    else if (wave_lds_layout(c->lmax, nq, false, 0).bytes > 8 * 1024) {
+    else if (jpoly && !c->opt_rule) {
+      // Per-azimuth kernels, one wave per pair (sweeps of --ring-rows on the end-of-round kernels,
+      // profiles/r03_fin_ring_rows.txt): one ring group while the wave's LDS — particle j's table included — stays
+      // within 11.5 KB (13-14 waves per CU; L = 6, n_q = 24: one group of 24 rows beats two of 12 by 4 %); beyond, groups
+      // of at most 10 KB (16 waves per CU: L = 8, 9 / n_q = 24 -7...-9 % against 12-13 KB groups, L = 7 / 24 -4 %), as
+      // few as that takes and of equal size (the rule before sized the groups without j's table and left L = 9,
+      // n_q = 16 with groups of 14 + 2 rings: +6 %).  Known exception: L = 8, n_q = 20, where 17 + 3 rings measured
+      // 4 % faster than the 10 + 10 this rule picks.
+      const auto total = [&](const int r) { return wave_lds_layout(c->lmax, r, false, nqj).bytes; };
+      if (total(nq) > 11776) {
+        int rmax = rows_min;
+        while (rmax < nq && total(rmax + 1) <= 10 * 1024) ++rmax;
+        const int groups = (nq + rmax - 1) / rmax;
+        rows = (nq + groups - 1) / groups;
+      }
+    } else if (wave_lds_layout(c->lmax, nq, false, 0).bytes > 8 * 1024) {
       const int fixed = wave_lds_layout(c->lmax, 0, false, 0).bytes;
       rows = (8 * 1024 - fixed) / (32 * (c->lmax + 1));
     }

@@ -69,7 +69,7 @@ ty = torch.from_numpy(b["type"]).to(dev)
 sh = torch.from_numpy(b["shtype"]).to(dev)
 f = torch.zeros(a.n, 3, dtype=torch.float64, device=dev)
 tq = torch.zeros_like(f)
-a.libs = [f"{lib}#{rows}w{w}j{j}p{pad}s{sv}d{dv}" for lib, rows, w, j, pad, sv, dv in zip(a.libs, rr, wp, jp, lp, spl, det)]
+a.libs = [f"{lib}@{i}#{rows}w{w}j{j}p{pad}s{sv}d{dv}" for i, (lib, rows, w, j, pad, sv, dv) in enumerate(zip(a.libs, rr, wp, jp, lp, spl, det))]   # @i: the context's position (its buffers' place in memory can be worth a few per cent: a null A/B shows it)
 res = {lib: [] for lib in a.libs}
 fref = None
 for r in range(a.rounds + 1):
