@@ -414,10 +414,10 @@ static bool use_split(const shpair_ctx* c, const bool jpoly)
   if (!jpoly || !split_compiled(c->lmax) || c->lmax > kMaxUnrolledL || (c->nq & 1) || c->nq < 8) return false;
   if (c->opt_split >= 0) return c->opt_split == 1;
   // measured (interleaved A/B over L = 7..12 x n_q = 8..32, profiles/r03_g/h_split_matrix.txt and, on the end-of-round
-  // kernels, r03_fin_split_matrix.txt; the boxes' noise is +-3 %): two waves win by 4-16 % at n_q = 32 from L = 8 on, at
-  // n_q = 24 from L = 10 on (4-9 %) and at L = 12 from n_q = 16 on (7-12 %); they lose below (at n_q = 8 half of each
-  // wave's lanes have no node pair: +40 %)
-  return (c->lmax >= 8 && c->nq >= 32) || (c->lmax >= 10 && c->nq >= 24) || (c->lmax >= 12 && c->nq >= 16);
+  // kernels with their ring groups re-sized, r03_fin_split_matrix.txt; the boxes' noise is +-3 %): two waves win at
+  // n_q = 32 from L = 8 on (0...-7 %), at n_q = 24 from L = 11 on (-3 %; L = 10: +2.5 %) and at L = 12 from n_q = 16
+  // on (-11 %); they lose below (at n_q = 8 half of each wave's lanes have no node pair: +40 %)
+  return (c->lmax >= 8 && c->nq >= 32) || (c->lmax >= 11 && c->nq >= 24) || (c->lmax >= 12 && c->nq >= 16);
 }
 
 }  // extern "C"
@@ -690,17 +690,30 @@ int shpair_compute_device(shpair_ctx* c, int nlocal, int nghost, const double* x
       // Per-azimuth kernels, one wave per pair (sweeps of --ring-rows on the end-of-round kernels,
       // profiles/r03_fin_ring_rows.txt): one ring group while the wave's LDS — particle j's table included — stays
       // within 11.5 KB (13-14 waves per CU; L = 6, n_q = 24: one group of 24 rows beats two of 12 by 4 %); beyond, groups
-      // of at most 10 KB (16 waves per CU: L = 8, 9 / n_q = 24 -7...-9 % against 12-13 KB groups, L = 7 / 24 -4 %), as
-      // few as that takes and of equal size (the rule before sized the groups without j's table and left L = 9,
-      // n_q = 16 with groups of 14 + 2 rings: +6 %).  Known exception: L = 8, n_q = 20, where 17 + 3 rings measured
-      // 4 % faster than the 10 + 10 this rule picks.
+      // of about 10 KB (L = 8, 9 / n_q = 24 -7...-9 % against 12-13 KB groups, L = 7 / 24 -4 %), see below (the rule
+      // before sized the groups without j's table and left L = 9, n_q = 16 with groups of 14 + 2 rings: +6 %).  Known
+      // exception: L = 8, n_q = 20, where 17 + 3 rings measured 4 % faster than the 10 + 10 this rule picks.
       const auto total = [&](const int r) { return wave_lds_layout(c->lmax, r, false, nqj).bytes; };
       if (total(nq) > 11776) {
-        int rmax = rows_min;
-        while (rmax < nq && total(rmax + 1) <= 10 * 1024) ++rmax;
-        const int groups = (nq + rmax - 1) / rmax;
-        rows = (nq + groups - 1) / groups;
-      }
+        int step = 64, a = per_ring;
+        while (a) { const int t = step % a; step = a; a = t; }   // gcd(64, per_ring)
+        step = 64 / step;   // rings per whole number of slabs
+        if (2 * step <= nq) {
+          // groups that end on a slab boundary (no slab straddles a hand-over: at n_q = 24 every order measured,
+          // L = 7...11, wants 8 rings = 3 slabs, not the 12 a budget alone gives): the largest such group within 10 KB
+          // (16 waves per CU), the smallest if none fits; then as few groups as that takes, of equal aligned size
+          int rfit = step;
+          while (rfit + step <= nq && total(rfit + step) <= 10 * 1024) rfit += step;
+          const int groups = (nq + rfit - 1) / rfit;
+          rows = (((nq + groups - 1) / groups + step - 1) / step) * step;
+        } else {
+          int rmax = rows_min;
+          while (rmax < nq && total(rmax + 1) <= 10752) ++rmax;   // 15 waves per CU
+          const int groups = (nq + rmax - 1) / rmax;
+          rows = (nq + groups - 1) / groups;
+        }
+        if (rows < (nq + 3) / 4) rows = (nq + 3) / 4;   // never more than four groups (large L x n_q: j's table alone
+      }                                                  // fills the budget; those run two waves per pair anyway)
     } else if (wave_lds_layout(c->lmax, nq, false, 0).bytes > 8 * 1024) {
       const int fixed = wave_lds_layout(c->lmax, 0, false, 0).bytes;
       rows = (8 * 1024 - fixed) / (32 * (c->lmax + 1));
