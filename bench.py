@@ -2,7 +2,10 @@
 """bench.py — contact-pairs/s of the `pair_style sh` hot path on MI355X.
 
   python bench.py --gpus N --steps K --warmup W
-  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   — or the plain
+   command above: with N > 1 and no WORLD_SIZE in the environment this process makes no GPU call and starts the N rank
+   processes itself, fresh children with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, relays rank 0's line and
+   returns the worst exit code; `self_launch`)
 
 N = 1 — BASELINE.json configs[1]: 100k particles, one L_max = 6 shape, dense packed bed resident in HBM, n_q = 16
 (Q = 512 cap nodes per pair), general force law (exponent 1.25: the overlap-volume root finder runs for every
@@ -93,6 +96,8 @@ def parse():
     ap.add_argument("--no-verify", dest="verify", action="store_false")
     ap.add_argument("--multi", action="store_true", help="with --gpus 1: run the N > 1 body (configs[3] workload, shhalo_run_device, "
                     "RCCL self-communicator) instead of the configs[1] headline")
+    ap.add_argument("--launch", action="store_true", help="with --gpus 1 --multi: go through the self-launcher (this process starts "
+                    "the rank as a fresh child, as `--gpus N` without a launcher does for N > 1)")
     ap.add_argument("--scale-ref", type=int, default=1, help="N = 1 default line: add the `scale_ref` object (0 = skip)")
     ap.add_argument("--wait-s", type=float, default=240.0, help="bound of every wait on another rank (rendezvous, "
                     "ncclCommInitRank, barriers); the whole multi-rank run is bounded by 6 x this")
@@ -156,6 +161,13 @@ class Watchdog:
         return _P()
 
 
+def _library_name():
+    """Base name of the shared library this process computes with (a diagnostic build can only be selected with
+    SHPAIR_LIB + SHPAIR_DIAGNOSTIC=1, and then says so here)."""
+    from shpair import capi
+    return capi.library_name()
+
+
 def make_ctx(args, shp, device):
     from shpair import ShPair
     sp = ShPair(device)
@@ -183,7 +195,7 @@ def roofline_objects(args, sp, n_contact, kernel_ms, world):
         peak_meas = sp.fp64_peak(0, args.peak_ms)[0]
     roof = {
         "bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved_gbs / HBM_PEAK_GBS,
-        "traffic": traffic, "traffic_source": src,
+        "traffic": traffic, "traffic_source": src, "stale": stale,
         "traffic_all_pair_kernels": (ent.get("traffic_all_pair_kernels_bytes") if ent else None),
         "traffic_note": "traffic = pair_contact_kernel alone (the dominant kernel); traffic_all_pair_kernels adds the set-up and "
                         "rotation kernels that kernel_ms also covers (pair records and rotated coefficient vectors: a deliberate "
@@ -204,11 +216,25 @@ def roofline_objects(args, sp, n_contact, kernel_ms, world):
                 "v_mfma_f64 and v_fma_f64 share one FP64 datapath (side by side they add up to the single-pipe rate, "
                 "profiles/r02_a_fp64_peak.json)",
     }
-    occ = dict(sp.kernel_info(), note="static footprint of pair_contact_kernel as launched: one wave = one pair = one "
+    ki = sp.kernel_info()
+    from shpair import capi, codeobj
+    ksym, khash = codeobj.contact_kernel_hash(capi.library_path(), ki["lmax"] if ki["compiled_order"] else -1, ki["needv"], ki["weighted"],
+                                              ki["family"], ki["waves_per_pair"])
+    # is the static PMC table's entry a measurement of the code that just ran?  (hash of the kernel's machine code + the
+    # launch shape; tools/pmc_table.py stores both with every entry)
+    stale = None
+    if ent:
+        stale = not (ent.get("kernel_hash") == khash and ent.get("ring_rows") == ki["ring_rows"]
+                     and ent.get("waves_per_pair") == ki["waves_per_pair"])
+    occ = dict(ki, kernel_symbol=ksym, kernel_hash=khash, note="static footprint of pair_contact_kernel as launched: one wave = one pair = one "
                "workgroup; waves_per_cu = min(4 x VGPR limit, LDS limit) of a gfx950 CU; family 1 = neighbour radius from "
                "per-azimuth polynomials in the pair's common frame (DESIGN.md 4.7), 0 = body-frame Horner evaluation")
-    util = {"source": src}
+    util = {"source": src, "stale": stale,
+            "stale_note": "false: the table entry was measured on this very contact-kernel code (SHA-256 of its machine code, "
+                          "occupancy.kernel_hash) with the same ring groups / waves per pair; true: on another build — re-run "
+                          "tools/pmc_run.sh; null: no entry"}
     if ent:
+        util["measured_on"] = {k: ent.get(k) for k in ("kernel_hash", "commit", "ring_rows", "waves_per_pair")}
         for k in ("valu_busy", "lds_busy", "lds_bank_conflict_share", "fp64_instr_share", "int32_instr_share", "valu_instr_per_pair",
                   "fp64_flop_per_pair_executed", "kernel_ms_of_the_profiled_run"):
             util[k] = ent.get(k)
@@ -228,6 +254,10 @@ def roofline_objects(args, sp, n_contact, kernel_ms, world):
 def main_single(args):
     import torch
     from shpair import shapes, bed
+    if torch.cuda.device_count() < 1:    # counting devices does not initialise the GPU
+        print("bench.py: no GPU visible; the HIP path has no CPU fallback", file=sys.stderr)
+        sys.exit(3)
+    scale_ref = scale_ref_leg(args) if args.scale_ref else None   # a fresh child process, before this one's first GPU call
     if not torch.cuda.is_available():
         print("bench.py: no GPU visible; the HIP path has no CPU fallback", file=sys.stderr)
         sys.exit(3)
@@ -316,12 +346,12 @@ def main_single(args):
         "timestep_note": "one step = initial_integrate + clear + pair compute + final_integrate, "
                          f"dt = {dt:g} from rest, no list rebuild inside the timed steps (see the `timestep` object for whole "
                          "steps with rebuilds)",
-        "roofline": roof, "occupancy": occ, "valu_f64": valu, "utilisation": util,
+        "roofline": roof, "occupancy": occ, "valu_f64": valu, "utilisation": util, "library": _library_name(),
     }
     if args.ts_steps > 0:
         out["timestep"] = timestep_leg(args, shp)
-    if args.scale_ref:
-        out["scale_ref"] = scale_ref_leg(args)
+    if scale_ref is not None:
+        out["scale_ref"] = scale_ref
     if args.cpu_seconds > 0:
         out["cpu_baseline"] = cpu_baseline(args, shp, rmax, gbed, il, of, jl)
     print(json.dumps(out), flush=True)
@@ -379,25 +409,32 @@ def scale_ref_leg(args):
     """The N > 1 workload (BASELINE configs[3]: 125k particles per GPU, box periodic in x and y on a frozen floor,
     gravity, thermal start, whole timesteps of shhalo_run_device with rebuild tests, migration bookkeeping and ghost
     exchange) on ONE rank through the same code as `bench.py --gpus N`: RCCL self-communicator, grid 1x1x1.  The
-    like-for-like N = 1 point of the scaling curve: efficiency(N) = value(N) / (N x scale_ref.value)."""
-    import copy
-    a = copy.copy(args)
-    a.particles, a.gpus, a.multi, a.transport, a.verify, a.peak_ms = 125000, 1, True, "rccl", False, 0.0
-    result = {}
+    like-for-like N = 1 point of the scaling curve: efficiency(N) = value(N) / (N x scale_ref.value).
+
+    Runs as a FRESH child process (`bench.py --gpus 1 --multi`, started through the self-launcher's machinery) BEFORE
+    this process makes its first GPU call: the leg's watchdog ends a stalled ncclCommInitRank with os._exit(4), which
+    must never take the headline line with it, and two HIP contexts never share the card."""
+    argv = ["--gpus", "1", "--multi", "--particles", "125000", "--steps", str(args.steps), "--warmup", str(args.warmup),
+            "--ramp", str(args.ramp), "--lmax", str(args.lmax), "--nq", str(args.nq), "--nshapes", str(args.nshapes),
+            "--exponent", repr(float(args.exponent)), "--jpoly", str(args.jpoly), "--rule", args.rule, "--vthermal", repr(float(args.vthermal)),
+            "--no-verify", "--peak-ms", "0", "--wait-s", str(args.wait_s)]
     try:
-        from shpair import mrank
-        uid = mrank.unique_id()
-        multi_rank_body(a, 0, 1, 0, _Collective(1), None, uid, result, Watchdog())
-        ln = result["line"]
+        rc, out = run_rank_children(argv, 1, 3.0 * args.wait_s)
+        lines = [ln for ln in out.splitlines() if ln.startswith("{")]
+        if rc != 0 or not lines:
+            return {"error": f"child `bench.py {' '.join(argv)}` ended with exit code {rc} and {len(lines)} JSON line(s)"}
+        ln = json.loads(lines[-1])
         return {"value": ln["value"], "unit": ln["unit"], "ms_per_step": ln["ms_per_step"], "timesteps_per_sec": ln["timesteps_per_sec"],
                 "steps": ln["steps"], "particles": ln["config"]["particles_all_ranks"],
                 "contact_pairs": ln["config"]["contact_pairs_all_ranks"], "ghost_atoms": ln["config"]["ghost_atoms_rank0"],
                 "pair_kernel_ms": ln["roofline"]["kernel_ms"],
                 "transport": ln["halo"]["transport"], "ranks_reported_by_transport": ln["halo"]["ranks_reported_by_transport"],
                 "rebuilds_in_timed_steps": ln["halo"]["rebuilds_in_timed_steps"][0], "workload": ln["config"]["workload"],
+                "library": ln.get("library"), "cmd": "python bench.py " + " ".join(argv),
                 "use": "the N = 1 reference of the scaling curve: parallel efficiency of `bench.py --gpus N` = value(N) / (N x "
-                       "scale_ref.value) — same workload per GPU, same C++ loop, same transport code; the headline `value` of "
-                       "this line is BASELINE configs[1] (static bed, no halo) and is NOT that reference"}
+                       "scale_ref.value) — same workload per GPU, same C++ loop, same transport code, measured in a fresh child "
+                       "process before the headline; the headline `value` of this line is BASELINE configs[1] (static bed, no "
+                       "halo) and is NOT that reference"}
     except Exception as e:  # noqa: BLE001 — the headline line must not die with this leg
         return {"error": repr(e)}
 
@@ -576,7 +613,11 @@ def multi_rank_body(args, rank, world, device, coll, hub, uid, result, wd=None):
             "verify_rel_err": verify_err, "verify_ok": (None if verify_err is None else bool(verify_err < 1e-9)),
             "verify_note": "decomposed forces and torques of the initial configuration against a single-domain compute of the "
                            "whole bed on rank 0 (max abs difference / max |F|), untimed; bar 1e-9",
-            "roofline": roof, "occupancy": occ, "valu_f64": valu, "utilisation": util,
+            "roofline": roof, "occupancy": occ, "valu_f64": valu, "utilisation": util, "library": _library_name(),
+            "scale_ref_cmd": f"python bench.py --gpus 1 --multi --steps {args.steps} --warmup {args.warmup}",
+            "scale_ref_note": "parallel efficiency of this line = value / (n_gpus x value of scale_ref_cmd's line): the same workload "
+                              "per GPU through the same C++ loop and transport on one rank; the default N = 1 line carries that "
+                              "number as its `scale_ref` object",
         }
     with wd.phase("final barrier", args.wait_s):
         coll.barrier()
@@ -731,9 +772,116 @@ def cpu_baseline(args, shp, rmax, gbed, il, of, jl):
     return out
 
 
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def _rank_env(rank, world, port):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "GROUP_RANK",
+                                                            "LOCAL_WORLD_SIZE", "ROLE_RANK", "TORCHELASTIC_RUN_ID")}
+    env.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), LOCAL_WORLD_SIZE=str(world),
+               MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), SHPAIR_BENCH_CHILD="1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")    # the host driver only supports dmabuf IPC (RCCL between processes)
+    return env
+
+
+def run_rank_children(argv, world, bound_s, stdout_of_rank0=True, script=None):
+    """Starts `world` FRESH processes of this script — one rank per GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set —
+    waits for all of them within `bound_s`, ends the others (their exact PIDs) when one dies or the bound passes, and
+    returns (worst exit code, rank 0's stdout).  The caller has not touched the GPU: children are ordinary
+    fork + exec of the interpreter, never a re-exec of a process that holds a HIP context."""
+    import subprocess
+    port = _free_port()
+    cmd = [sys.executable, script or os.path.abspath(__file__)] + list(argv)
+    procs = []
+    for r in range(world):
+        procs.append(subprocess.Popen(cmd, env=_rank_env(r, world, port), cwd=ROOT, text=True,
+                                      stdout=(subprocess.PIPE if r == 0 else subprocess.DEVNULL), stderr=None))
+    out0 = []
+    reader = None
+    if stdout_of_rank0:
+        def _read():
+            for ln in procs[0].stdout:
+                out0.append(ln)
+        reader = threading.Thread(target=_read, daemon=True)
+        reader.start()
+    deadline = time.monotonic() + bound_s
+    codes = [None] * world
+    worst = 0
+    while any(c is None for c in codes):
+        for r, p in enumerate(procs):
+            if codes[r] is None:
+                codes[r] = p.poll()
+        failed = [r for r, c in enumerate(codes) if c not in (None, 0)]
+        late = time.monotonic() > deadline
+        if failed or late:
+            # the ranks that are left would wait for the dead one until their own watchdog fires: give them a moment to
+            # report by themselves, then end exactly the processes started here
+            grace = time.monotonic() + (0.0 if late else 10.0)
+            while time.monotonic() < grace and any(p.poll() is None for p in procs):
+                time.sleep(0.2)
+            ended_here = []
+            for r, p in enumerate(procs):
+                if p.poll() is None:
+                    ended_here.append(r)
+                    p.terminate()
+            t_kill = time.monotonic() + 5.0
+            for r, p in enumerate(procs):
+                try:
+                    p.wait(timeout=max(0.1, t_kill - time.monotonic()))
+                except subprocess.TimeoutExpired:
+                    p.kill()
+                    p.wait()
+            # the exit code reported is the worst among the ranks that ended BY THEMSELVES; the ones ended here only say so
+            codes = [(0 if r in ended_here else p.returncode) for r, p in enumerate(procs)]
+            if ended_here:
+                print(f"bench.py: ended rank process(es) {ended_here} after " + ("the time bound" if late and not failed else
+                      f"rank(s) {failed} failed"), file=sys.stderr, flush=True)
+            if late and not failed:
+                print(f"bench.py: the {world} rank processes did not finish within {bound_s:.0f} s", file=sys.stderr, flush=True)
+                worst = 4
+            break
+        time.sleep(0.2)
+    if reader is not None:
+        reader.join(timeout=10.0)
+    for c in codes:
+        if c is not None and c != 0:
+            worst = max(worst, c if c > 0 else 128 - c)   # a signal's negative code as the shell would print it
+    return worst, "".join(out0)
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it (WORLD_SIZE unset): this process becomes the
+    launcher.  It has made no GPU call (importing torch is all that happened) and makes none: it starts N fresh rank
+    processes, relays rank 0's single JSON line and returns the worst exit code.  The line carries `scale_ref_cmd` —
+    the command whose `value` is the like-for-like one-GPU point of the scaling curve (same workload per GPU, same C++
+    loop, same transport code)."""
+    argv = [a for a in sys.argv[1:] if a != "--launch"]
+    rc, out = run_rank_children(argv, args.gpus, 6.0 * args.wait_s + 120.0)
+    lines = [ln for ln in out.splitlines() if ln.startswith("{")]
+    for ln in out.splitlines():
+        if not ln.startswith("{"):
+            print(ln, file=sys.stderr)
+    if lines:
+        try:
+            d = json.loads(lines[-1])
+            d["launcher"] = "bench.py self-launch: N fresh rank processes (RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* set by the parent)"
+            print(json.dumps(d), flush=True)
+        except ValueError:
+            print(lines[-1], flush=True)
+    elif rc == 0:
+        rc = 1
+    sys.exit(rc)
+
+
 if __name__ == "__main__":
     _args = parse()
     if _args.gpus == 1 and not _args.multi:
         main_single(_args)
+    elif _args.transport == "rccl" and "WORLD_SIZE" not in os.environ and (_args.gpus > 1 or _args.launch):
+        self_launch(_args)
     else:
         main_multi(_args)

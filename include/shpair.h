@@ -182,6 +182,9 @@ typedef struct shpair_kernel_info {
                                  1: from per-azimuth polynomials in the pair's common frame (option "jpoly") */
   int waves_per_pair;         /* 1: one wave = one pair = one workgroup; 2: two waves share a pair's tables (option
                                  "split"); lds_bytes_per_wave is then the pair's LDS / 2 */
+  int needv, weighted;        /* the instance's other two template arguments: overlap-volume root finder compiled in;
+                                 covered-fraction rule.  (lmax, needv, weighted, family, waves_per_pair) name the
+                                 pair_contact_kernel instance that ran — profiles/pmc_traffic.json is keyed to its code */
 } shpair_kernel_info;
 int shpair_get_kernel_info(shpair_ctx *ctx, shpair_kernel_info *out);
 

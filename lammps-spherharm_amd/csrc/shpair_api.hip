@@ -983,6 +983,8 @@ int shpair_get_kernel_info(shpair_ctx* c, shpair_kernel_info* out)
   const int cu = (4 * w < by_lds) ? 4 * w : by_lds;
   out->waves_per_cu = cu;
   out->family = (compiled && c->last_jpoly) ? 1 : 0;
+  out->needv = c->last_needv ? 1 : 0;
+  out->weighted = (compiled && c->opt_rule != 0) ? 1 : 0;
   return SHPAIR_OK;
 }
 

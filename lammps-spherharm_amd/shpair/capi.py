@@ -30,7 +30,8 @@ class Stats(C.Structure):
 
 class KernelInfo(C.Structure):
     _fields_ = [(n, C.c_int) for n in ("lmax", "compiled_order", "vgprs", "scratch_bytes", "lds_bytes_per_wave", "ring_rows",
-                                       "waves_per_simd_vgpr", "waves_per_cu_lds", "waves_per_cu", "family", "waves_per_pair")]
+                                       "waves_per_simd_vgpr", "waves_per_cu_lds", "waves_per_cu", "family", "waves_per_pair",
+                                       "needv", "weighted")]
 
 
 class StepArrays(C.Structure):
@@ -162,8 +163,20 @@ SYMBOLS = {
 
 def library_path():
     """libshpair.so beside this file.  SHPAIR_LIB=<file name in this directory> selects a diagnostic build (ablation /
-    statistics libraries made by `make abl` / `make stats`) for profiling runs; there is no other fallback."""
-    return os.path.join(_HERE, os.environ.get("SHPAIR_LIB", "libshpair.so"))
+    statistics libraries made by `make abl` / `make stats`: some give WRONG results by construction) — honoured only
+    together with SHPAIR_DIAGNOSTIC=1, refused loudly otherwise; there is no other fallback."""
+    name = os.environ.get("SHPAIR_LIB")
+    if name and name != "libshpair.so":
+        if os.environ.get("SHPAIR_DIAGNOSTIC") != "1":
+            raise ImportError(f"SHPAIR_LIB={name} selects a diagnostic build of libshpair; set SHPAIR_DIAGNOSTIC=1 as well "
+                              "if that is what you mean (profiling tools do), or unset SHPAIR_LIB")
+        return os.path.join(_HERE, name)
+    return os.path.join(_HERE, "libshpair.so")
+
+
+def library_name():
+    """Base name of the library this process loaded (bench.py prints it in its JSON line)."""
+    return os.path.basename(library_path())
 
 
 def load_library():

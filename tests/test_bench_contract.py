@@ -47,6 +47,9 @@ def test_single_gpu_line_has_the_contract_fields():
     sr = d["scale_ref"]
     assert "error" not in sr, sr
     assert sr["transport"] == "rccl" and sr["ranks_reported_by_transport"] == 1 and sr["particles"] > 120000
+    assert sr["library"] == d["library"] == "libshpair.so" and "--multi" in sr["cmd"]
+    assert d["occupancy"]["kernel_hash"] and d["occupancy"]["kernel_symbol"].startswith("_ZN3shp19pair_contact_kernel")
+    assert d["roofline"]["stale"] in (None, True, False) and d["utilisation"]["stale"] == d["roofline"]["stale"]
     assert sr["value"] > 1e7 and sr["steps"] == 5 and "configs[3]" in sr["workload"] and sr["ghost_atoms"] > 0
     assert abs(sr["value"] * sr["ms_per_step"] * 1e-3 - sr["contact_pairs"]) < 1e-6 * sr["contact_pairs"]
 
@@ -82,6 +85,32 @@ def test_rccl_body_at_world_1_under_torch_distributed_run():
                        env={k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")})
     assert r.returncode == 0, r.stderr[-3000:]
     assert _last_json(r.stdout)["halo"]["transport"] == "rccl"
+
+
+def test_self_launcher_gives_the_line_of_torch_distributed_run():
+    """`bench.py --gpus 1 --multi --launch`: the door `bench.py --gpus 8` goes through when nothing launched it — the
+    parent makes no GPU call, starts the rank as a fresh child with RANK / WORLD_SIZE / MASTER_* set and relays its
+    line.  Same workload, same fields, same physics as under torch.distributed.run (above); timing differs by noise."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    common = ["--gpus", "1", "--multi", "--particles", "20000", "--steps", "8", "--warmup", "1", "--ramp", "2", "--peak-ms", "0"]
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + common + ["--launch"], capture_output=True, text=True,
+                       timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    a = _last_json(r.stdout)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py")] + common
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=dict(env, MASTER_ADDR="127.0.0.1"))
+    assert r.returncode == 0, r.stderr[-3000:]
+    b = _last_json(r.stdout)
+    assert "self-launch" in a["launcher"] and "launcher" not in b
+    ca, cb = a["config"], b["config"]
+    assert set(b) <= set(a) and set(ca) == set(cb) and a["halo"]["owned_atoms"] == b["halo"]["owned_atoms"]
+    assert all(ca[k] == cb[k] for k in ("workload", "particles_all_ranks", "proc_grid", "backend", "lmax", "nq"))
+    # atomics order the sums differently from run to run and the bed is chaotic: the contact counts agree closely, not exactly
+    assert abs(ca["contact_pairs_all_ranks"] - cb["contact_pairs_all_ranks"]) < 0.01 * cb["contact_pairs_all_ranks"]
+    assert a["verify_ok"] is True and b["verify_ok"] is True and a["halo"]["transport"] == "rccl"
+    assert a["scale_ref_cmd"] == b["scale_ref_cmd"] and a["library"] == b["library"] == "libshpair.so"
+    assert 0.5 < a["value"] / b["value"] < 2.0
 
 
 def test_a_rank_that_never_arrives_ends_the_run_with_a_message():

@@ -22,7 +22,9 @@ for set in "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_I
 done
 python3 "$root/tools/pmc_summary.py" "$out"/${tag}_pmc_* > "$out/${tag}_pmc.txt"
 # the table entry bench.py reports from (profiles/pmc_traffic.json): printed, to be pasted / merged with tools/pmc_table.py --merge
-python3 "$root/tools/pmc_table.py" "$out/${tag}_pmc.txt" "$out/${tag}_bench.json" > "$out/${tag}_table.json" || true
+# .commit: `git rev-parse --short HEAD` written before the gpurun call (the box has no .git)
+commit=$(cat "$root/.commit" 2>/dev/null || echo unknown)
+python3 "$root/tools/pmc_table.py" "$out/${tag}_pmc.txt" "$out/${tag}_bench.json" --files "profiles/${tag}_pmc.txt" --commit "$commit" > "$out/${tag}_table.json" || true
 find "$out/${tag}_trace" -name '*kernel_stats.csv' -exec cp {} "$out/${tag}_kernel_stats.csv" \;
 # the raw per-dispatch CSVs are large: keep the summaries
 rm -rf "$out"/${tag}_pmc_* "$out/${tag}_trace"

@@ -1,5 +1,5 @@
 """One entry of profiles/pmc_traffic.json from the summaries tools/pmc_run.sh leaves behind.
-  python tools/pmc_table.py <tag>_pmc.txt <tag>_bench.json [--merge profiles/pmc_traffic.json --files profiles/<tag>_pmc.txt]
+  python tools/pmc_table.py <tag>_pmc.txt <tag>_bench.json [--merge profiles/pmc_traffic.json --files profiles/<tag>_pmc.txt --commit <sha>]
 Everything bench.py prints as measured-but-static utilisation comes from here: HBM-side bytes per launch of the three
 pair kernels (FETCH_SIZE / WRITE_SIZE x 1024), VALU instructions per pair, VALU busy = SQ_ACTIVE_INST_VALU x 4 /
 (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs), LDS busy = SQ_LDS_IDX_ACTIVE / (GRBM_GUI_ACTIVE / 8 x 256 CUs), share of LDS-active
@@ -51,14 +51,29 @@ def entry(pmc, bench):
                                             + c["SQ_INSTS_VALU_TRANS_F64"]) * 64.0 / pairs
         e["int32_instr_share"] = c["SQ_INSTS_VALU_INT32"] / c["SQ_INSTS_VALU"]
     e["kernel_ms_of_the_profiled_run"] = b["roofline"]["kernel_ms"]
+    # what the counters were measured ON: bench.py compares these with the library it runs and prints "stale" when they differ
+    occ = b["occupancy"]
+    for k in ("kernel_symbol", "kernel_hash", "ring_rows", "waves_per_pair", "vgprs", "lds_bytes_per_wave"):
+        e[k] = occ.get(k)
+    e["library"] = b.get("library")
     return key, e
 
 
 if __name__ == "__main__":
+    if sys.argv[1] == "--merge-json":   # pmc_table.py --merge-json profiles/pmc_traffic.json <tag>_table.json ...: entries made on the box
+        tab = json.load(open(sys.argv[2]))
+        for f in sys.argv[3:]:
+            for k, e in json.load(open(f)).items():
+                tab[k] = e
+                print(f"merged {k} from {f}")
+        json.dump(tab, open(sys.argv[2], "w"), indent=1)
+        sys.exit(0)
     pmc = parse(sys.argv[1])
     key, e = entry(pmc, sys.argv[2])
     if "--files" in sys.argv:
         e["files"] = sys.argv[sys.argv.index("--files") + 1]
+    if "--commit" in sys.argv:   # the commit whose build was profiled (git rev-parse --short HEAD; "+dirty" if the tree had changes)
+        e["commit"] = sys.argv[sys.argv.index("--commit") + 1]
     if "--merge" in sys.argv:
         path = sys.argv[sys.argv.index("--merge") + 1]
         tab = json.load(open(path))
