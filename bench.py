@@ -193,6 +193,16 @@ def roofline_objects(args, sp, n_contact, kernel_ms, world):
     peak_meas = None
     if args.peak_ms > 0:
         peak_meas = sp.fp64_peak(0, args.peak_ms)[0]
+    ki = sp.kernel_info()
+    from shpair import capi, codeobj
+    ksym, khash = codeobj.contact_kernel_hash(capi.library_path(), ki["lmax"] if ki["compiled_order"] else -1, ki["needv"], ki["weighted"],
+                                              ki["family"], ki["waves_per_pair"])
+    # is the static PMC table's entry a measurement of the code that just ran?  (hash of the kernel's machine code + the
+    # launch shape; tools/pmc_table.py stores both with every entry)
+    stale = None
+    if ent:
+        stale = not (ent.get("kernel_hash") == khash and ent.get("ring_rows") == ki["ring_rows"]
+                     and ent.get("waves_per_pair") == ki["waves_per_pair"])
     roof = {
         "bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved_gbs / HBM_PEAK_GBS,
         "traffic": traffic, "traffic_source": src, "stale": stale,
@@ -216,16 +226,6 @@ def roofline_objects(args, sp, n_contact, kernel_ms, world):
                 "v_mfma_f64 and v_fma_f64 share one FP64 datapath (side by side they add up to the single-pipe rate, "
                 "profiles/r02_a_fp64_peak.json)",
     }
-    ki = sp.kernel_info()
-    from shpair import capi, codeobj
-    ksym, khash = codeobj.contact_kernel_hash(capi.library_path(), ki["lmax"] if ki["compiled_order"] else -1, ki["needv"], ki["weighted"],
-                                              ki["family"], ki["waves_per_pair"])
-    # is the static PMC table's entry a measurement of the code that just ran?  (hash of the kernel's machine code + the
-    # launch shape; tools/pmc_table.py stores both with every entry)
-    stale = None
-    if ent:
-        stale = not (ent.get("kernel_hash") == khash and ent.get("ring_rows") == ki["ring_rows"]
-                     and ent.get("waves_per_pair") == ki["waves_per_pair"])
     occ = dict(ki, kernel_symbol=ksym, kernel_hash=khash, note="static footprint of pair_contact_kernel as launched: one wave = one pair = one "
                "workgroup; waves_per_cu = min(4 x VGPR limit, LDS limit) of a gfx950 CU; family 1 = neighbour radius from "
                "per-azimuth polynomials in the pair's common frame (DESIGN.md 4.7), 0 = body-frame Horner evaluation")

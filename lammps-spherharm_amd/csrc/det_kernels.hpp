@@ -74,4 +74,55 @@ __global__ __launch_bounds__(kDetBlock) void det_gather_kernel(const int nall, c
   *o += s;
 }
 
+// ---- global energy / virial tally: ordered reduction of the per-slot rows (pair_kernel.hpp epilogue) ----
+// Stage 1: block b adds the rows of slots [b * kTallyChunk, (b + 1) * kTallyChunk) — each thread a fixed strided subset
+// in ascending order, then a fixed LDS tree — and writes its 7 sums to part[b][0..6].  Stage 2 (one block) adds the block
+// sums in ascending order with the same tree and ADDS the result into ev[0..6].  The partition depends on the number of
+// slots only: the sums are bitwise reproducible, in the default (atomic) mode as well as in the deterministic one.
+constexpr int kTallyBlock = 256;
+constexpr int kTallyChunk = 8192;   // slots per block of stage 1
+
+__device__ __forceinline__ void tally_block_tree(double (*sh)[kTallyBlock], const int t)
+{
+  for (int half = kTallyBlock / 2; half > 0; half >>= 1) {
+    __syncthreads();
+    if (t < half)
+      for (int c = 0; c < 7; ++c) sh[c][t] += sh[c][t + half];
+  }
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(kTallyBlock) void tally_partial_kernel(const int np, const double* __restrict__ pair_ev,
+                                                                   double* __restrict__ part)
+{
+  __shared__ double sh[7][kTallyBlock];
+  const int t = threadIdx.x;
+  const int lo = blockIdx.x * kTallyChunk;
+  const int hi = (lo + kTallyChunk < np) ? lo + kTallyChunk : np;
+  double s[7] = {0, 0, 0, 0, 0, 0, 0};
+  for (int w = lo + t; w < hi; w += kTallyBlock) {
+    const double4* r = (const double4*)(pair_ev + 8 * (size_t)w);
+    const double4 a = r[0], b = r[1];
+    s[0] += a.x; s[1] += a.y; s[2] += a.z; s[3] += a.w;
+    s[4] += b.x; s[5] += b.y; s[6] += b.z;
+  }
+  for (int c = 0; c < 7; ++c) sh[c][t] = s[c];
+  tally_block_tree(sh, t);
+  if (t < 7) part[8 * (size_t)blockIdx.x + t] = sh[t][0];
+}
+
+__global__ __launch_bounds__(kTallyBlock) void tally_final_kernel(const int nblocks, const double* __restrict__ part,
+                                                                 double* __restrict__ ev, const int eflag, const int vflag)
+{
+  __shared__ double sh[7][kTallyBlock];
+  const int t = threadIdx.x;
+  double s[7] = {0, 0, 0, 0, 0, 0, 0};
+  for (int b = t; b < nblocks; b += kTallyBlock)
+    for (int c = 0; c < 7; ++c) s[c] += part[8 * (size_t)b + c];
+  for (int c = 0; c < 7; ++c) sh[c][t] = s[c];
+  tally_block_tree(sh, t);
+  if (t == 0 && eflag) ev[0] += sh[0][0];
+  if (t >= 1 && t < 7 && vflag) ev[t] += sh[t][0];
+}
+
 }  // namespace shp

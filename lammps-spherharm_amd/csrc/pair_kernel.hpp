@@ -100,7 +100,8 @@ struct PairParams {
   int trig_stride;      // doubles between consecutive azimuths (l-major: 2 (lmax - 1)) / orders (m-major: 4 nq)
   int nq;
   // outputs / flags
-  double* ev;           // 7 doubles or null
+  double* ev;           // 7 doubles or null: where tally_reduce_kernel adds the sums of pair_ev (the pair kernels do not touch it)
+  double* pair_ev;      // eflag / vflag: 8 doubles per slot, E xx yy zz xy xz yz -, zeroed before the launch; or null
   double* pair_out;     // 7 doubles per slot or null
   double* pair_ft;      // deterministic mode (det_kernels.hpp): 12 doubles per slot, F_i tau_i | F_j tau_j, written instead
                         // of the atomics; null in the default mode
@@ -1934,11 +1935,26 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
     if (det) det[12 * (size_t)w + 6 + lane] = vj;
     else atomicAdd((is_t ? E.torque : E.f) + 3 * (size_t)j + comp, vj);
   }
+  // Global energy / virial tally (thermo steps): each of the six lanes owns ONE virial component and stores it, with
+  // lane 0 adding the energy, into the pair's own 64-byte row of a per-slot buffer; tally_reduce_kernel (det_kernels.hpp)
+  // adds the rows in slot order.  Round 3 had lane 0 issue 1 + 6 atomics on the same seven addresses for every touching
+  // pair (~3.5 M same-address atomics per launch at the headline) and a sum whose last bits changed from run to run.
+  if ((E.eflag || E.vflag) && E.pair_ev) {
+    const double share = E.newton_pair ? 1.0 : (0.5 + (j < E.nlocal ? 0.5 : 0.0));
+    double* row = E.pair_ev + 8 * (size_t)w;
+    if (E.vflag) {
+      // ev_tally_xyz with del = x_i - x_j = -d and the force on i: xx yy zz xy xz yz = d_a F_b, (a, b) per lane
+      const int a = (lane < 3) ? lane : ((lane == 5) ? 1 : 0);
+      const int b = (lane < 3) ? lane : ((lane == 3) ? 1 : 2);
+      row[1 + lane] = share * (-fr[FR_D + a]) * fcomp[b];
+    }
+    if (E.eflag && lane == 0) row[0] = share * knij * (vm1 * aVt);
+  }
   if (lane != 0) return;
-  // the tallies (only when asked for) stay with lane 0
-  const double F0 = fcomp[0], F1 = fcomp[1], F2 = fcomp[2];
-  const double d0 = fr[FR_D], d1 = fr[FR_D + 1], d2 = fr[FR_D + 2];
+  // the per-atom tallies (only when asked for) stay with lane 0
   if (E.eatom || E.vatom) {
+    const double F0 = fcomp[0], F1 = fcomp[1], F2 = fcomp[2];
+    const double d0 = fr[FR_D], d1 = fr[FR_D + 1], d2 = fr[FR_D + 2];
     // ev_tally_xyz per-atom part: half of the pair's energy / virial to each atom this rank tallies for
     const bool owni = E.newton_pair || i < E.nlocal;
     if (E.eatom) {
@@ -1953,19 +1969,6 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
         if (owni) atomicAdd(&E.vatom[6 * (size_t)i + a], v[a]);
         if (applyj) atomicAdd(&E.vatom[6 * (size_t)j + a], v[a]);
       }
-    }
-  }
-  if ((E.eflag || E.vflag) && E.ev) {
-    const double share = E.newton_pair ? 1.0 : (0.5 + (j < E.nlocal ? 0.5 : 0.0));
-    if (E.eflag) atomicAdd(&E.ev[0], share * knij * (vm1 * aVt));
-    if (E.vflag) {
-      // ev_tally_xyz with del = x_i - x_j = -d and the force on i
-      atomicAdd(&E.ev[1], share * (-d0) * F0);
-      atomicAdd(&E.ev[2], share * (-d1) * F1);
-      atomicAdd(&E.ev[3], share * (-d2) * F2);
-      atomicAdd(&E.ev[4], share * (-d0) * F1);
-      atomicAdd(&E.ev[5], share * (-d0) * F2);
-      atomicAdd(&E.ev[6], share * (-d1) * F2);
     }
   }
 }

@@ -133,7 +133,7 @@ void shpair_destroy(shpair_ctx* c)
   c->d_x.release(); c->d_quat.release(); c->d_f.release(); c->d_torque.release(); c->d_ev.release();
   c->d_type.release(); c->d_shtype.release(); c->d_counters.release(); c->d_flags.release();
   c->d_eatom.release(); c->d_vatom.release(); c->d_list.release(); c->d_err.release(); c->d_rec.release(); c->d_rec_i.release(); c->d_rot.release();
-  c->d_pair_ft.release(); c->d_rev_start.release(); c->d_rev_cur.release(); c->d_rev_ent.release();
+  c->d_pair_ft.release(); c->d_pair_ev.release(); c->d_rev_start.release(); c->d_rev_cur.release(); c->d_rev_ent.release();
   if (c->h_list) (void)hipHostFree(c->h_list);
   if (c->h_err) (void)hipHostFree(c->h_err);
   if (c->h_ev) (void)hipHostFree(c->h_ev);
@@ -435,6 +435,7 @@ hipError_t shp_size_pair_buffers(shpair_ctx* c, size_t np)
     if (e == hipSuccess) e = c->d_rev_ent.ensure(np * 2);
   }
   if (e == hipSuccess) e = c->d_rec_i.ensure(np * 4);
+  if (e == hipSuccess) e = c->d_pair_ev.ensure(8 * (np + (np + kTallyChunk - 1) / kTallyChunk));   // 64 B per slot: thermo steps
   int L = c->lmax;
   for (int s = 0; s < c->nshapes; ++s)
     if (c->shapes[s].lmax > L) L = c->shapes[s].lmax;
@@ -810,6 +811,14 @@ int shpair_compute_device(shpair_ctx* c, int nlocal, int nghost, const double* x
     P.pair_ft = c->d_pair_ft.p;
   }
   P.ev = ev; P.pair_out = c->pair_out;
+  P.pair_ev = nullptr;
+  const int tally_blocks = (c->npairs + kTallyChunk - 1) / kTallyChunk;
+  if (eflag || vflag) {
+    // per-slot rows + the block sums behind them (sized with the list, shp_size_pair_buffers: nothing is allocated in a capture)
+    HIPCHK(c, c->d_pair_ev.ensure(8 * ((size_t)c->npairs + (size_t)tally_blocks)));
+    HIPCHK(c, hipMemsetAsync(c->d_pair_ev.p, 0, 8 * (size_t)c->npairs * sizeof(double), st));
+    P.pair_ev = c->d_pair_ev.p;
+  }
   P.flags = nullptr;
   P.dbg = c->dbg;
   P.eflag = eflag ? 1 : 0; P.vflag = vflag ? 1 : 0;
@@ -846,6 +855,13 @@ int shpair_compute_device(shpair_ctx* c, int nlocal, int nghost, const double* x
     const int nall_idx = c->max_atom_index + 1;
     hipLaunchKernelGGL(det_gather_kernel, dim3((6 * nall_idx + kDetBlock - 1) / kDetBlock), dim3(kDetBlock), 0, st, nall_idx,
                        (const int*)c->d_rev_start.p, (const int*)c->d_rev_ent.p, (const double*)c->d_pair_ft.p, f, torque);
+    HIPCHK(c, hipGetLastError());
+  }
+  if (eflag || vflag) {
+    double* part = c->d_pair_ev.p + 8 * (size_t)c->npairs;
+    hipLaunchKernelGGL(tally_partial_kernel, dim3(tally_blocks), dim3(kTallyBlock), 0, st, c->npairs, (const double*)c->d_pair_ev.p, part);
+    hipLaunchKernelGGL(tally_final_kernel, dim3(1), dim3(kTallyBlock), 0, st, tally_blocks, (const double*)part, ev, eflag ? 1 : 0,
+                       vflag ? 1 : 0);
     HIPCHK(c, hipGetLastError());
   }
   if (c->opt_timing) {

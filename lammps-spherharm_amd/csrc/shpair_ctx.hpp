@@ -102,6 +102,7 @@ struct shpair_ctx {
   // deterministic accumulation (det_kernels.hpp): per-slot results + reverse index (atom -> its list slots)
   int opt_deterministic = 0;
   shp::DevBuf<double> d_pair_ft;
+  shp::DevBuf<double> d_pair_ev;    // eflag / vflag: 8 doubles per slot (E, 6 virial terms, pad) + the block sums of the ordered reduce
   shp::DevBuf<int> d_rev_start, d_rev_cur, d_rev_ent;
   bool rev_dirty = true;
   int rev_nall = 0;

@@ -20,7 +20,7 @@ def _last_json(out):
 
 
 def test_single_gpu_line_has_the_contract_fields():
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--particles", "20000", "--steps", "5", "--warmup", "1",
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--particles", "20000", "--steps", "20", "--warmup", "1",
                         "--ramp", "2", "--cpu-seconds", "2", "--ts-steps", "10"], capture_output=True, text=True, timeout=600,
                        cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
@@ -28,7 +28,7 @@ def test_single_gpu_line_has_the_contract_fields():
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "timestep", "occupancy"):
         assert k in d, k
-    assert d["n_gpus"] == 1 and d["steps"] == 5 and d["warmup"] == 1 and d["dtype"] == "f64" and d["vs_baseline"] is None
+    assert d["n_gpus"] == 1 and d["steps"] == 20 and d["warmup"] == 1 and d["dtype"] == "f64" and d["vs_baseline"] is None
     assert d["unit"] == "contact-pairs/s" and d["value"] > 1e7 and d["higher_is_better"] is True
     assert "workload" in d["config"] and "model" not in d["config"]
     rf = d["roofline"]
@@ -50,7 +50,7 @@ def test_single_gpu_line_has_the_contract_fields():
     assert sr["library"] == d["library"] == "libshpair.so" and "--multi" in sr["cmd"]
     assert d["occupancy"]["kernel_hash"] and d["occupancy"]["kernel_symbol"].startswith("_ZN3shp19pair_contact_kernel")
     assert d["roofline"]["stale"] in (None, True, False) and d["utilisation"]["stale"] == d["roofline"]["stale"]
-    assert sr["value"] > 1e7 and sr["steps"] == 5 and "configs[3]" in sr["workload"] and sr["ghost_atoms"] > 0
+    assert sr["value"] > 1e7 and sr["steps"] == 20 and "configs[3]" in sr["workload"] and sr["ghost_atoms"] > 0
     assert abs(sr["value"] * sr["ms_per_step"] * 1e-3 - sr["contact_pairs"]) < 1e-6 * sr["contact_pairs"]
 
 
