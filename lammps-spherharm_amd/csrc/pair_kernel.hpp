@@ -133,7 +133,7 @@ constexpr int kPairErrCoincident = 4;   // two centres coincide (rho = 0) or the
 // (80 registers up to L = 4, 96 up to L = 6 and for the one-wave kernel of L = 9, 128 beyond — L = 5, 8 and the two-wave
 // kernel of L = 9 come out a step below their bound; A/B per order: profiles/r03_zzzz_ab_root_loop.txt, r03_zzzzzz_ab_lds_abs.txt)
 #ifndef SHP_JMIN_WAVES
-#define SHP_JMIN_WAVES(L, NEEDV, WPP) (((L) <= 4) ? 6 : (((L) <= 6 || ((L) == 9 && (WPP) == 1)) ? 5 : 4))
+#define SHP_JMIN_WAVES(L, NEEDV, WPP) (((L) <= 4) ? 6 : (((L) <= 6 || ((L) == 9 && (WPP) == 1 && !(NEEDV))) ? 5 : 4))
 #endif
 
 // docs/SPEC.md §2.6: residual below which the inverse-quadratic extrapolation is accepted
@@ -176,8 +176,12 @@ struct WaveLdsLayout {
   int qw;                                        // weighted rule only: the queued nodes' weights
   int coef;                                      // end of the queue region (the table of particle j starts here)
   int pj, gh;                                    // particle j's polynomials: first-stage scratch, per-azimuth table
+  int pi, v0i;                                   // JPT kernels: particle i's first-stage polynomials PJ^i (they stay for every ring
+                                                 // group); particle i's rotated vector beside particle j's (both in the rows of
+                                                 // the per-azimuth table, which is built after the first stage has read them)
   int glw;                                       // JPT kernels: the Gauss-Legendre weights (nqj doubles)
-  int park;                                      // JPT kernels: 2 x 64 parked sums + 64 prefetched Gauss nodes (over the queue)
+  int park;                                      // JPT kernels with ring groups: 2 x 64 sums parked around the builds of the later groups (in the empty queue)
+  int stash;                                     // JPT kernels: 64 prefetched Gauss nodes for the first pass of the first ring build
   int qstride;                                   // two waves per pair: doubles between the waves' private queue regions
 };
 // Row of the per-azimuth table: G_l (L + 1 coefficients, descending powers), H_l (L), cos(psi_l), sin(psi_l) (the
@@ -190,6 +194,8 @@ __host__ __device__ constexpr int jpoly_trig(const int L) { return 2 * L + 2; } 
 __host__ __device__ constexpr int jpoly_glw(const int L) { return 2 * L + 1; }    // offset of the weight of ring `row index` (the odd slot behind the 2L + 1 coefficients)
 // Rows of the first-stage table PJ: (order m, part) for m = 0..L+1 — the order L + 1 is empty (zeros), see jpoly_build.
 __host__ __device__ constexpr int jpoly_rows(const int L) { return 2 * L + 4; }
+// ... of which particle i needs the real orders only: PJ^i, (2L + 2) polynomials of L + 1 coefficients (an even count)
+__host__ __device__ constexpr int jpoly_pi_doubles(const int L) { return (2 * L + 2) * (L + 1); }
 __host__ __device__ inline WaveLdsLayout wave_lds_layout(const int L, const int rows, const bool weighted = false,
                                                          const int nqj = 0)
 {
@@ -204,12 +210,17 @@ __host__ __device__ inline WaveLdsLayout wave_lds_layout(const int L, const int 
   // polynomials of particle j.
   const bool alias = SHP_ALIAS_FROM_L <= L;
   w.trig = kFrame;
-  // JPT kernels with all rings resident (one ring group): the rotated vector lies over the queue (below); with ring
-  // groups particle i's vector has to survive the groups' node loops and keeps a place of its own behind the frame
-  const bool v0_over_queue = nqj > 0 && rows >= nqj;
+  w.pi = w.v0i = 0;
+  // JPT kernels (nqj > 0), round 4: the ring tables are Horner evaluations of particle i's first-stage polynomials
+  // PJ^i (cap_frame_rings_poly), (2L + 2)(L + 1) doubles that replace the rotated vector as what has to survive for the
+  // ring builds.  With all rings resident (one ring group) they lie over the queue, which is empty while rings are
+  // built; with ring groups they keep a place of their own behind the frame.  Both rotated vectors wait for the first
+  // stage in the rows of particle j's table.
+  const int npi = jpoly_pi_doubles(L);
+  const bool one_group = nqj > 0 && rows >= nqj;
   w.v0 = (alias || nqj > 0) ? kFrame : w.trig + 6 * (L + 1);
   w.v1 = w.v0 + ns;
-  w.ring = (nqj > 0) ? (v0_over_queue ? kFrame : w.v0 + ns) : (alias ? w.v0 + ns : w.v1 + ns);
+  w.ring = (nqj > 0) ? (one_group ? kFrame : kFrame + npi) : (alias ? w.v0 + ns : w.v1 + ns);
   w.ring += w.ring & 1;  // 16-byte aligned rows for ds_read_b128
   // the first stage of particle j's polynomials ((2L+4)(L+1) doubles, +2: a read one past a row's end) lies over the ring rows, which are built later
   int ringsz = 4 * rows * (L + 1);
@@ -221,16 +232,20 @@ __host__ __device__ inline WaveLdsLayout wave_lds_layout(const int L, const int 
   w.qw = w.qp + kQueue / 4;
   w.park = w.qri;
   w.coef = w.qw + (weighted ? kQueue : 0);
+  w.stash = w.qri + 128;
   if (nqj > 0) {
-    // the rotated vector (of j, then of i) lies over the queue: it is read while the queue is empty (first-stage
-    // table build, ring builds at the start of a ring group); parked sums and the prefetched Gauss node share the
-    // queue's second array meanwhile (the kernel's park / stash offsets)
+    // PJ^i over the queue (one ring group: a single build, before any sum exists — nothing is parked) or behind the
+    // frame (ring groups: the later builds park two sums in the empty queue).  The prefetched Gauss nodes of the first
+    // pass wait at the end of the ring rows where the first pass (entries 0..63 = doubles 0..255) does not write and
+    // particle j's first stage does not reach, else behind the polynomials / the parked sums.
+    w.pi = one_group ? w.qri : kFrame;
     w.park = w.qri;
-    if (v0_over_queue) {
-      w.v0 = w.qri;
-      w.park = w.v0 + ns + (ns & 1);
-    }
-    if (w.park + 192 > w.coef) w.coef = w.park + 192;   // large L: vector + parking lot are longer than the queue
+    const int pjsz = jpoly_rows(L) * (L + 1) + 2;
+    if (ringsz - 64 >= 256 && ringsz - 64 >= pjsz) w.stash = w.ring + ringsz - 64;
+    else w.stash = one_group ? w.pi + npi : w.qri + 128;
+    int need = one_group ? w.pi + npi : w.park + 128;
+    if (w.stash >= w.qri && w.stash + 64 > need) need = w.stash + 64;
+    if (need > w.coef) w.coef = need;   // large L: the polynomials are longer than the queue
   }
   if (alias && nqj == 0) {
     w.trig = w.qri;
@@ -240,7 +255,13 @@ __host__ __device__ inline WaveLdsLayout wave_lds_layout(const int L, const int 
   w.coef += w.coef & 1;
   w.gh = w.coef;   // per-azimuth polynomials of particle j: nqj rows, resident for the whole pair
   w.glw = w.gh + jpoly_glw(L);   // weight of ring k at glw + k * jpoly_row(L)
-  w.bytes = 8 * (w.gh + nqj * jpoly_row(L));
+  int ghsz = nqj * jpoly_row(L);
+  if (nqj > 0) {
+    w.v0 = w.gh;         // particle j's rotated vector, then particle i's behind it: read by the first stage only
+    w.v0i = w.gh + ns;
+    if (ghsz < 2 * ns) ghsz = 2 * ns;
+  }
+  w.bytes = 8 * (w.gh + ghsz);
   // the epilogue's reduction scratch lies behind the frame, over everything that is dead by then
   if (w.bytes < 8 * (kFrame + kRedDoubles)) w.bytes = 8 * (kFrame + kRedDoubles);
   w.bytes = (w.bytes + 15) & ~15;
@@ -253,8 +274,8 @@ __host__ __device__ inline WaveLdsLayout pair_lds_layout2(const int L, const int
   WaveLdsLayout w;
   const int ns = (L + 1) * (L + 1);
   w.trig = w.v1 = w.qw = w.coef = 0;   // not used by the JPT kernels
-  w.v0 = kFrame;
-  w.ring = w.v0 + ns;
+  w.pi = kFrame;                        // particle i's first-stage polynomials: they stay for the ring groups
+  w.ring = w.pi + jpoly_pi_doubles(L);
   w.ring += w.ring & 1;
   int ringsz = 4 * rows * (L + 1);
   if (ringsz < jpoly_rows(L) * (L + 1) + 2) ringsz = jpoly_rows(L) * (L + 1) + 2;
@@ -262,7 +283,11 @@ __host__ __device__ inline WaveLdsLayout pair_lds_layout2(const int L, const int
   w.pj = w.ring;
   w.gh = w.ring + ringsz;
   w.glw = w.gh + jpoly_glw(L);
-  int shared_end = w.gh + nq * jpoly_row(L);
+  w.v0 = w.gh;        // both rotated vectors wait for the first stage in the rows of particle j's table
+  w.v0i = w.gh + ns;
+  int ghsz = nq * jpoly_row(L);
+  if (ghsz < 2 * ns) ghsz = 2 * ns;
+  int shared_end = w.gh + ghsz;
   // the epilogue's scratch (one block per wave) lies over everything behind the frame, the queues included: wave 0's
   // from the frame on, wave 1's at the end of the pair's LDS
   const int qs = 2 * kQueue + kQueue / 4;
@@ -271,7 +296,8 @@ __host__ __device__ inline WaveLdsLayout pair_lds_layout2(const int L, const int
   w.qri = shared_end;
   w.qrj = w.qri + kQueue;
   w.qp = w.qrj + kQueue;
-  w.park = w.qri;                          // 2 x 64 parked sums while the ring rows are built (the queue is empty then)
+  w.park = w.qri;                          // 2 x 64 parked sums while the ring rows of a later group are built (the queue is empty then)
+  w.stash = w.qri + 128;                   // (not used: two-wave kernels request their Gauss nodes where they use them)
   w.qstride = 2 * kQueue + kQueue / 4;     // 288
   w.bytes = (8 * (shared_end + 2 * w.qstride) + 15) & ~15;
   return w;
@@ -291,7 +317,7 @@ __device__ __forceinline__ v2d lds2(const double* p) { return *(const v2d*)__bui
 // with h n_q / 2 <= l < (h + 1) n_q / 2) with a node queue of its own.  For the orders and rules where one wave's
 // private copy of the tables leaves a CU too few waves: L = 12, n_q = 32 needs 14.6 KB per one-wave pair (11 waves per
 // CU, VALU 66 % busy, profiles/r03_e_L12_pmc.txt), 17.3 KB per two-wave pair (18 waves' worth; the registers allow 16).
-//   frame | v0 (particle i; stays for the ring groups) | ring rows (first: first stage of j's table) | j's table |
+//   frame | PJ^i (particle i's first-stage polynomials; stay for the ring groups) | ring rows (first: first stage of j's table) | j's table |
 //   [epilogue scratch of both waves over everything behind the frame] | queue of wave 0 | queue of wave 1
 __host__ __device__ inline WaveLdsLayout pair_lds_layout2(const int L, const int rows, const int nq);
 
@@ -760,7 +786,7 @@ __device__ __forceinline__ void cap_frame_rings(const PairParams& P, double* __r
                                                 const double hw, const double hm, const bool have_first = false)
 {
   // have_first (PRE kernels): the Gauss-Legendre node of this lane's ring in the first pass of the first ring group
-  // was requested at the start of the kernel and waits in the (empty) queue at lw[W.park + 128 + lane]
+  // was requested at the start of the kernel and waits in the (empty) queue at lw[W.stash + lane]
   const double* ch = lw + W.v0;
   double* ring = lw + W.ring;
   int krl, g, G, rpc, lg;
@@ -768,7 +794,7 @@ __device__ __forceinline__ void cap_frame_rings(const PairParams& P, double* __r
   for (int kr0 = 0; kr0 < nrows; kr0 += rpc) {
     const int kr = kr0 + krl;
     const bool row_ok = kr < nrows && krl < rpc;
-    const double tk = (PRE && have_first && k0 == 0 && kr0 == 0) ? lw[W.park + 128 + lane] : P.glt[k0 + (row_ok ? kr : 0)];
+    const double tk = (PRE && have_first && k0 == 0 && kr0 == 0) ? lw[W.stash + lane] : P.glt[k0 + (row_ok ? kr : 0)];
     const double mu = fma(hw, tk, hm);
     const double sig2 = fmax(0.0, fma(-mu, mu, 1.0));
     const double sig = sqrt_nr(sig2);
@@ -835,6 +861,77 @@ __device__ __forceinline__ void cap_frame_rings(const PairParams& P, double* __r
         }
       }
       sp *= sigG;
+    }
+  }
+  pair_sync<WPP>();
+}
+
+// Ring tables of the JPT kernels (round 4): HORNER EVALUATIONS of particle i's first-stage polynomials.
+//
+// jpoly_build leaves, for every order m and part (cos, sin), the polynomial PJ^i[2m + part](mu) with
+//   r_i(mu, psi) = sum_m s_m [cos(m psi) PJ^i[2m](mu) + sin(m psi) PJ^i[2m + 1](mu)],   s_m = 1 (m even), sigma (m odd)
+// (the host table folds (1 - mu^2)^floor(m / 2) into the polynomial: degree L for even m, L - 1 for odd m).  So
+//   A_km = s_m PJ^i[2m](mu_k),   dA_km/dmu = s_m PJ^i[2m]'(mu_k)  [- (mu_k / sigma_k) PJ^i[2m](mu_k) for odd m],   B likewise:
+// one lane per table entry (ring, order), value and derivative of both parts by Horner — 4L - 2 v_fma_f64 and L + 1
+// ds_read_b128 (the two parts' coefficients are adjacent: 2 (L + 1) doubles) — no recurrence constants, no sigma^m, no
+// division.  The associated-Legendre recurrence this replaces (cap_frame_rings: 8 FP64 operations per step, L - m steps
+// per entry, a pass per order class) was 256 of the headline kernel's 1 826 vector instructions per pair, 59 % of them
+// not FP64 (profiles/r04_d_headline_valu_sites.txt).
+// Entry e = ring * (L + 1) + order IS the ring table's own index: the store needs no address arithmetic beyond 32 e.
+template <int L, int WPP>
+__device__ __forceinline__ void cap_frame_rings_poly(const PairParams& P, double* __restrict__ lw, const WaveLdsLayout& W,
+                                                     const int lane, const int tid, const int k0, const int nrows,
+                                                     const double hw, const double hm, const bool have_first)
+{
+  constexpr int K = L + 1, NT = 64 * WPP;
+  const double* pi = lw + W.pi;
+  double* ring = lw + W.ring;
+  const int nent = nrows * K;
+  for (int e0 = 0; e0 < nent; e0 += NT) {   // wave-uniform
+    const int e = e0 + tid;
+    const int ec = min(e, nent - 1);   // idle lanes repeat the last entry and store nothing
+    const int kr = (int)((unsigned)ec / (unsigned)K), m = ec - kr * K;
+    // have_first: this lane's Gauss-Legendre node of the first pass of the first ring group was requested at the start
+    // of the kernel and waits in the (empty) queue
+    const double tk = (have_first && k0 == 0 && e0 == 0) ? lw[W.stash + lane] : P.glt[k0 + kr];
+    const double mu = fma(hw, tk, hm);
+    const double sig2 = max_raw(fma(-mu, mu, 1.0), 1e-300);
+    const double isig = rsqrt_nr(sig2);
+    const double sig = sig2 * isig;
+    const double* row = pi + (2 * K) * m;   // 16-byte aligned: 2K doubles per order, an aligned base
+    v2d c[K];
+#pragma unroll
+    for (int t = 0; t < K; ++t) c[t] = lds2(row + 2 * t);
+    // element j of the 2K doubles: cos-part coefficient of mu^p at j = p, sin-part at j = K + p
+#define SHP_EL(j) c[(j) >> 1][(j) & 1]
+    double pc = SHP_EL(L), ps = SHP_EL(K + L), dc = 0.0, ds = 0.0;
+    if constexpr (L >= 1) {
+      dc = pc;
+      ds = ps;
+      pc = fma(pc, mu, SHP_EL(L - 1));
+      ps = fma(ps, mu, SHP_EL(K + L - 1));
+#pragma unroll
+      for (int q = L - 2; q >= 0; --q) {
+        dc = fma(dc, mu, pc);
+        ds = fma(ds, mu, ps);
+        pc = fma(pc, mu, SHP_EL(q));
+        ps = fma(ps, mu, SHP_EL(K + q));
+      }
+    }
+#undef SHP_EL
+    const bool odd = (m & 1) != 0;
+    const double sm = odd ? sig : 1.0;            // s_m
+    const double tm = odd ? -mu * isig : 0.0;     // d s_m / d mu
+    const double A = sm * pc, dA = fma(tm, pc, sm * dc);
+    double B = sm * ps, dB = fma(tm, ps, sm * ds);
+    if (m == 0) {   // B_k0 = 0: the slots carry mu_k and sigma_k
+      B = mu;
+      dB = sig;
+    }
+    if (e < nent) {
+      double* o = ring + 4 * e;
+      *(v2d*)__builtin_assume_aligned(o, 16) = v2d{A, B};
+      *(v2d*)__builtin_assume_aligned(o + 2, 16) = v2d{dA, dB};
     }
   }
   pair_sync<WPP>();
@@ -941,33 +1038,48 @@ struct JPolyPre {
 // (wave h the passes h, h + 2, ...); `half` is the wave's index within the pair.
 template <int L, int WPP = 1>
 __device__ __forceinline__ void jpoly_build(const PairParams& P, double* __restrict__ lw, const WaveLdsLayout& W,
-                                            const int lane, const int nq, const JPolyPre<L>& pre, const int half = 0)
+                                            const int lane, const int nq, const JPolyPre<L>& pre, const double glw_first,
+                                            const int half = 0)
 {
   // K powers per polynomial; the tables carry one order more than exist (m = L + 1: empty rows of PJ, a real
   // cos/sin pair) so that the azimuth stage below needs no guard on its reads
-  constexpr int K = L + 1, NR = jpoly_rows(L) * K, XW = L / 2 + 1, RS = jpoly_row(L);
+  constexpr int K = L + 1, NR = jpoly_rows(L) * K, NRI = jpoly_pi_doubles(L), XW = L / 2 + 1, RS = jpoly_row(L);
+  // first stage for BOTH particles from one pass over the table rows: particle j's polynomials feed the azimuth stage
+  // below, particle i's (the real orders only) are what the ring tables are evaluated from (cap_frame_rings_poly)
   const double* v0 = lw + W.v0;
+  const double* v0i = lw + W.v0i;
   double* pj = lw + W.pj;
+  double* pi = lw + W.pi;
   if constexpr (JPolyPre<L>::on && WPP == 1) {
 #pragma unroll
     for (int ps = 0; ps < JPolyPre<L>::NP; ++ps) {
       const int o = lane + 64 * ps;
-      double acc = 0.0;
+      double acc = 0.0, aci = 0.0;
 #pragma unroll
-      for (int t = 0; t < XW; ++t) acc = fma(pre.val[ps * XW + t], v0[pre.col[ps * XW + t]], acc);
+      for (int t = 0; t < XW; ++t) {
+        acc = fma(pre.val[ps * XW + t], v0[pre.col[ps * XW + t]], acc);
+        aci = fma(pre.val[ps * XW + t], v0i[pre.col[ps * XW + t]], aci);
+      }
       if (o < NR) pj[o] = acc;
+      if (o < NRI) pi[o] = aci;
     }
   } else {
     for (int o = lane + 64 * half; o < NR; o += 64 * WPP) {
       const double* val = P.jval + (size_t)o * XW;
       const int* col = P.jcol + (size_t)o * XW;
-      double acc = 0.0;
+      double acc = 0.0, aci = 0.0;
 #pragma unroll
-      for (int t = 0; t < XW; ++t) acc = fma(val[t], v0[col[t]], acc);
+      for (int t = 0; t < XW; ++t) {
+        acc = fma(val[t], v0[col[t]], acc);
+        aci = fma(val[t], v0i[col[t]], aci);
+      }
       pj[o] = acc;
+      if (o < NRI) pi[o] = aci;
     }
   }
   pair_sync<WPP>();
+  // the Gauss-Legendre weights go into the odd slot of the table's rows now that the rotated vectors are out of them
+  for (int t = lane + 64 * half; t < nq; t += 64 * WPP) lw[W.glw + t * RS] = (t < 64 * WPP) ? glw_first : P.glw[t];
   // Azimuth stage.  Lanes are (azimuth l, parity of m, parity of k), 16 azimuths per pass: a lane loads the
   // cos/sin(m psi_l) of its orders m = par, par + 2, ... once and walks its powers k = kq, kq + 2, ...; every LDS
   // address is the lane's base plus an immediate.  G (par = 0) has the powers 0..L, H (par = 1) the powers 0..L-1.
@@ -1184,12 +1296,12 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
     }
     pre.fetch(P, lane, P.nq);
   }
-  double glt_first = 0.0;
+  double glt_first = 0.0, glw_first = 0.0;
+  if constexpr (JPT && L >= 0 && !WEIGHTED) glw_first = P.glw[tid < P.nq ? tid : 0];   // the weight of ring `tid`, stored after the first stage
   if constexpr (JPT && L >= 0 && L <= 8 && !WEIGHTED && WPP == 1) {
-    const int nr0 = P.ring_rows < P.nq ? P.ring_rows : P.nq;   // rings of the first group (cap_frame_rings' lane map)
-    int kr, g0_, G0_, rpc0_, lg0_;
-    ring_lane_map<L, 1, true>(lane, nr0, kr, g0_, G0_, rpc0_, lg0_);
-    glt_first = P.glt[kr < nr0 ? kr : 0];
+    const int nr0 = P.ring_rows < P.nq ? P.ring_rows : P.nq;   // rings of the first group
+    const int kr = lane / (L + 1);                             // cap_frame_rings_poly's lane map: entry = ring (L + 1) + order
+    glt_first = P.glt[kr < nr0 ? kr : nr0 - 1];
   }
   const int status = rid[0];
   if (status == 0) return;   // bounding spheres apart (SPEC §2.1) or a shape index outside the table; wave-uniform
@@ -1210,14 +1322,16 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
     s_tiny = rs[FR_JTINY];
   }
   const bool centre_in_bj = rid[3] != 0;  // rho < Rj
-  if constexpr (JP)
-    for (int t = tid; t < nq; t += NT) lw[W.glw + t * jpoly_row(LJ)] = P.glw[t];
   if (tid < kRecUsed) lw[tid] = recv;
-  if constexpr (JP && L <= 8 && WPP == 1) lw[W.park + 128 + lane] = glt_first;
+  if constexpr (JP && L <= 8 && WPP == 1) lw[W.stash + lane] = glt_first;
   if constexpr (JP) {
+    // both rotated vectors, side by side in the (not yet built) rows of particle j's table: the first stage reads them
 #pragma unroll
     for (int t = 0; t < NSL; ++t)
-      if (tid + NT * t < (LJ + 1) * (LJ + 1)) lw[W.v0 + tid + NT * t] = vj[t];
+      if (tid + NT * t < (LJ + 1) * (LJ + 1)) {
+        lw[W.v0 + tid + NT * t] = vj[t];
+        lw[W.v0i + tid + NT * t] = vi[t];
+      }
   }
   pair_sync<WPP>();
 #if defined(SHP_ABL) && SHP_ABL == 1   // timing-only build: stop after the pair prologue
@@ -1225,17 +1339,12 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
   return;
 #endif
   if constexpr (JP) {
-    // particle j first: its vector shares the place of particle i's, which has to stay for the ring groups
-    jpoly_build<LJ, WPP>(P, lw, W, lane, nq, pre, half);
-#pragma unroll
-    for (int t = 0; t < NSL; ++t)
-      if (tid + NT * t < (LJ + 1) * (LJ + 1)) lw[W.v0 + tid + NT * t] = vi[t];
-    pair_sync<WPP>();
+    jpoly_build<LJ, WPP>(P, lw, W, lane, nq, pre, glw_first, half);
   } else {
     cap_frame_rotate<L>(P, lw, W, LL, si, lane);
   }
 #if defined(SHP_ABL) && SHP_ABL == 4   // timing-only build: stop after the coefficient rotation
-  asm volatile("" ::"v"(lw[W.v0 + lane]));
+  asm volatile("" ::"v"(lw[(JP ? W.pi : W.v0) + lane]));
   return;
 #endif
 
@@ -1277,6 +1386,14 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
   const int nslabs = (nq * per_ring + 63) >> 6;
   const int rowlen = 4 * (LL + 1);
 
+  // JPT kernels: the ring tables of the FIRST group are built here, before any of the seven sums exists — with all
+  // rings resident (the common case) that is the only build of the pair, and nothing has to be parked around it (round
+  // 3 parked two sums in the queue for every build: 128 doubles of LDS beside the polynomials the build reads)
+  if constexpr (JP) {
+    const int kend0 = (P.ring_rows < nq) ? P.ring_rows : nq;
+    cap_frame_rings_poly<LJ, WPP>(P, SHP_LDS(), W, lane, tid, 0, kend0, fr[FR_HW], fr[FR_HM], L <= 8 && WPP == 1);
+  }
+  bool first_group = true;   // wave-uniform
   double aV = 0.0, aS0 = 0.0, aS1 = 0.0, aS2 = 0.0, aT0 = 0.0, aT1 = 0.0, aT2 = 0.0;
   int qhead = 0, qcount = 0, slab = 0;  // wave-uniform
   double wg1 = 0.0, wg2 = 0.0, wri1 = 0.0, wrj1 = 0.0;  // WEIGHTED: residuals of slabs t-1, t-2; r_i, r_j of slab t-1
@@ -1299,15 +1416,18 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
     double* lr = SHP_LDS();
     // the queue is empty between ring groups: four of the seven sums wait there while the ring tables are built
     // (eight registers the build has for its recurrences instead of spilling)
-    if constexpr (JP) {   // 128 registers: two sums wait in the empty queue (they would be spilled otherwise)
-      double* park = lr + W.park + lane;
-      park[0] = aT2; park[64] = NEEDV ? aV : aS0;
-      if constexpr (WPP == 2) __syncthreads();   // the other wave has left the node loops of the previous group: its rows may go
-      cap_frame_rings<L, (L <= 8 && WPP == 1), WPP, true>(P, lr, W, LL, tid, k0, kend - k0, lr[FR_HW], lr[FR_HM], WPP == 1);
-      park = SHP_LDS() + W.park + lane;
-      aT2 = park[0];
-      if (NEEDV) aV = park[64]; else aS0 = park[64];
-      wave_lds_sync();
+    if constexpr (JP) {
+      if (!first_group) {   // later groups (ring tables in pieces): two sums wait in the empty queue meanwhile (they would be spilled otherwise)
+        double* park = lr + W.park + lane;
+        park[0] = aT2; park[64] = NEEDV ? aV : aS0;
+        if constexpr (WPP == 2) __syncthreads();   // the other wave has left the node loops of the previous group: its rows may go
+        cap_frame_rings_poly<LJ, WPP>(P, lr, W, lane, tid, k0, kend - k0, lr[FR_HW], lr[FR_HM], false);
+        park = SHP_LDS() + W.park + lane;
+        aT2 = park[0];
+        if (NEEDV) aV = park[64]; else aS0 = park[64];
+        wave_lds_sync();
+      }
+      first_group = false;
     } else {
       double* park = lr + W.qri + lane;
       park[0] = aT0; park[64] = aT1; park[128] = aT2; park[192] = NEEDV ? aV : aS0;
