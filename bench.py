@@ -111,6 +111,9 @@ def parse():
                     "(16 = the host-core share of one GPU on the bench box)")
     ap.add_argument("--peak-ms", type=float, default=20.0, help="length of the v_fma_f64 peak measurement (0 = skip)")
     ap.add_argument("--vthermal", type=float, default=0.25, help="N > 1: initial velocity scale of the bed")
+    ap.add_argument("--halo-overlap", type=int, default=-1, choices=[-1, 0, 1],
+                    help="N > 1: option \"halo_overlap\" (1: the forward exchange runs on a stream of its own beside the pair "
+                         "kernels of the slots that touch owned atoms only); -1 = the library's default")
     ap.add_argument("--one-device", action="store_true", help="N > 1 with --transport rccl: every rank uses GPU 0 (only to probe "
                     "what RCCL does with several ranks on one device; RCCL normally refuses)")
     a = ap.parse_args()
@@ -507,6 +510,8 @@ def multi_rank_body(args, rank, world, device, coll, hub, uid, result, wd=None):
     torch.cuda.set_device(device)
     shp = [shapes.random_shape(args.lmax, bed.SEED0 + 2 + s) for s in range(args.nshapes)]
     sp = make_ctx(args, shp, device)
+    if args.halo_overlap >= 0:
+        sp.set_option("halo_overlap", args.halo_overlap)
     skin = 0.1
     grid = mrank.proc_grid(world)
     cfg = config4_bed(args, world, grid)
@@ -602,7 +607,7 @@ def multi_rank_body(args, rank, world, device, coll, hub, uid, result, wd=None):
             "halo": {
                 "transport": "rccl" if st["transport"] == 1 else "local",
                 "ranks_reported_by_transport": st["nranks_transport"], "rccl_version": st["rccl_version"],
-                "peers_rank0": st["npeers"], "send_rows_rank0": st["nsend_rows"], "ghost_rows_rank0": st["nghost_rows"],
+                "overlap_option": args.halo_overlap, "peers_rank0": st["npeers"], "send_rows_rank0": st["nsend_rows"], "ghost_rows_rank0": st["nghost_rows"],
                 "forward_bytes_per_step_rank0": st["forward_bytes_per_step"], "reverse_bytes_per_step_rank0": st["reverse_bytes_per_step"],
                 "rebuilds_in_timed_steps": [r["rebuilds"] for r in allr], "atoms_migrated_in_timed_steps": int(sum(r["migrated"] for r in allr)),
                 "owned_atoms": [r["nlocal"] for r in allr], "ghost_atoms": [r["nghost"] for r in allr],

@@ -20,8 +20,14 @@
  * two exchanges — a lost atom, nmax too small for the arrivals or the ghosts, a type or shape index outside its
  * table — are AGREED ON with one max-all-reduce of an error word before any further message is posted, so that every
  * rank returns a non-zero code from the same call (the failing rank its own code and message, the others
- * SHPAIR_ESTATE naming it) and none is left waiting inside ncclRecv, which has no timeout.  Any non-zero return of
- * any rank is fatal for the communicator: destroy the contexts (a HIP or RCCL call that failed in the middle of a
+ * SHPAIR_ESTATE naming it) and none is left waiting inside ncclRecv, which has no timeout.  What is covered: the
+ * failures of a reneighbouring (shhalo_exchange_device, shhalo_borders_device, the list build — inside
+ * shhalo_run_device too) and the pair / step kernels' error bits, which shhalo_run_device reads once at the end of a
+ * call.  NOT covered: argument and state errors of the per-step calls inside shhalo_run_device's loop (null arrays, a
+ * list that does not match the atoms) and of shhalo_forward_device / shhalo_reverse_device called directly — the
+ * contract is the same call sequence with like arguments on every rank, so these are raised by every rank in the same
+ * step or are a caller's bug; an all-reduce per step to agree on them would cost every step ~1 % for nothing.
+ * Any non-zero return of any rank is fatal for the communicator: destroy the contexts (a HIP or RCCL call that failed in the middle of a
  * step — SHPAIR_EHIP — cannot be agreed on, the peers are already inside their exchanges; treat it like a lost rank).
  *
  * Transports: RCCL (the product; librccl is bound at run time with dlopen, so a single-GPU host does not need

@@ -160,12 +160,16 @@ int shpair_compute_device(shpair_ctx *ctx, int nlocal, int nghost, const double 
  * that is rebuilt on the device whenever a list is installed, instead of hardware FP64 atomics whose order of
  * arrival varies from run to run (last-bit differences, ~1e-16 relative per add); costs one more pass and 96 bytes per
  * list slot; the ghost reverse sums of shstep / shhalo follow the option (no atomics, fixed order), so device-resident
- * trajectories are reproducible too, on one rank and on several; the energy / virial tallies, global and per atom, keep
- * their atomics; 0 (default): atomics).
+ * trajectories are reproducible too, on one rank and on several; 0 (default): atomics.  The GLOBAL energy / virial
+ * tallies are bitwise reproducible in both modes — per-slot rows added in slot order — the per-atom tallies keep their
+ * atomics), "halo_overlap" (1, the default: device-built lists are partitioned — slots whose two atoms are owned first, slots with a
+ * ghost behind them, each in list order — and shhalo_run_device runs the forward exchange of a step on a stream of its
+ * own beside the pair kernels of the owned-only slots; 0: the exchange and the pair kernels follow each other on the
+ * caller's stream; same forces, another order of the per-atom sums).
  * Memory: the contact path keeps per-slot scratch in HBM — a 320-byte record and, for the "jpoly" family, two rotated
  * coefficient vectors of (lmax+1)^2 doubles each (rounded up to 8 from lmax = 9 on): 1.1 KB per list slot at lmax = 6
  * (0.7 GB at 100k particles / 580k pairs, ~7 GB at 1 M), 3.0 KB at lmax = 12 (1.7 GB at 100k); +96 bytes per slot in
- * the deterministic mode. */
+ * the deterministic mode; +64 bytes per slot for the tally rows of thermo steps. */
 int shpair_set_option(shpair_ctx *ctx, const char *key, int value);
 
 /* Static footprint of the pair kernel the last compute launched (occupancy evidence): registers per lane, LDS

@@ -50,7 +50,9 @@ struct PairParams {
   // half list, expanded: one (i, j) per slot
   const int* pair_i;
   const int* pair_j;
-  int npairs;
+  int npairs;           // end of the slot range of this launch (exclusive); the whole list unless a caller splits it
+  int slot0;            // ... and its first slot: a multiple of 32 (rotation tiles hold 64 rotations = 32 slots).  The halo
+                        // loop runs the slots whose atoms are all owned before the forward exchange has landed (shhalo_api.hip)
   int nlocal;
   int newton_pair;
   // shape tables
@@ -715,7 +717,7 @@ __global__ void __launch_bounds__(64) pair_rotate_lane_kernel(const PairParams P
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_rl[];
   double* sm = (double*)smem_rl;
   const int lane = threadIdx.x;
-  const int task0 = blockIdx.x * 64, ntasks = 2 * P.npairs;
+  const int task0 = 2 * P.slot0 + blockIdx.x * 64, ntasks = 2 * P.npairs;   // slot0 is a multiple of 32: whole tiles
   const int task = task0 + lane;
   const int w = (task < ntasks ? task : ntasks - 1) >> 1, which = task & 1;
   const int* rid = P.rec_i + 4 * (size_t)w;
@@ -1226,7 +1228,7 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   int lane = threadIdx.x & 63;
   const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int w = (WPP == 2) ? (int)blockIdx.x : __builtin_amdgcn_readfirstlane((int)(blockIdx.x * P.waves_per_block)) + wib;
+  const int w = P.slot0 + ((WPP == 2) ? (int)blockIdx.x : __builtin_amdgcn_readfirstlane((int)(blockIdx.x * P.waves_per_block)) + wib);
   const int half = (WPP == 2) ? wib : 0;      // wave-uniform
   const int tid = lane + 64 * half;           // lane within the pair's waves
   constexpr int NT = 64 * WPP;
@@ -2136,9 +2138,10 @@ static inline void launch_contact_one(K kern, const dim3 grid, const dim3 block,
 template <int L>
 void launch_pair_contact(const PairParams& P, bool needv, hipStream_t st, hipEvent_t wait_before_contact = nullptr)
 {
-  if (P.npairs <= 0) return;
+  const int nslots = P.npairs - P.slot0;   // the launch covers the slots [slot0, npairs)
+  if (nslots <= 0) return;
   const int wpb = P.waves_per_block;
-  const dim3 grid((P.npairs + wpb - 1) / wpb), block(64 * wpb);
+  const dim3 grid((nslots + wpb - 1) / wpb), block(64 * wpb);
   const size_t lds = (size_t)wpb * P.wave_lds_bytes;
   if (P.rule) {
     // SPEC §2.8; one instantiation (with the volume path) serves both force laws
@@ -2149,12 +2152,12 @@ void launch_pair_contact(const PairParams& P, bool needv, hipStream_t st, hipEve
   if constexpr (L >= 0) {
     if (P.jpoly) {
       // both particles' coefficient rotations, one lane each, then the contact kernel that reads them
-      hipLaunchKernelGGL((pair_rotate_lane_kernel<L>), dim3((2 * (unsigned)P.npairs + 63) / 64), dim3(64),
+      hipLaunchKernelGGL((pair_rotate_lane_kernel<L>), dim3((2 * (unsigned)nslots + 63) / 64), dim3(64),
                          RotLaneLds<L>::bytes(), st, P, const_cast<double*>(P.rot));
       if (wait_before_contact) (void)hipStreamWaitEvent(st, wait_before_contact, 0);
       if constexpr (split_compiled(L)) {
         if (P.split) {   // two waves per pair: the workgroup is the pair
-          const dim3 grid2(P.npairs), block2(128);
+          const dim3 grid2(nslots), block2(128);
           if (needv) launch_contact_one(pair_contact_kernel<L, true, false, true, 2>, grid2, block2, (size_t)P.wave_lds_bytes, st, P);
           else launch_contact_one(pair_contact_kernel<L, false, false, true, 2>, grid2, block2, (size_t)P.wave_lds_bytes, st, P);
           return;

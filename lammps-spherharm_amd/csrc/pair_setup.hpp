@@ -55,7 +55,7 @@ __global__ __launch_bounds__(kSetupBlock) void pair_setup_kernel(const PairParam
                                                                   int* __restrict__ rec_i)
 {
   __shared__ double srec[kSetupBlock * kSetupPad];
-  const int base = blockIdx.x * kSetupBlock;
+  const int base = P.slot0 + blockIdx.x * kSetupBlock;   // the launch covers the slots [slot0, npairs)
   const int w = base + threadIdx.x;
   if (w < P.npairs) pair_setup_one(P, w, srec + threadIdx.x * kSetupPad, rec_i + 4 * (size_t)w);
   __syncthreads();
@@ -181,8 +181,8 @@ __device__ __forceinline__ void pair_setup_one(const PairParams& P, const int w,
 
 inline void launch_pair_setup(const PairParams& P, double* rec, int* rec_i, hipStream_t st)
 {
-  if (P.npairs <= 0) return;
-  hipLaunchKernelGGL(pair_setup_kernel, dim3((P.npairs + kSetupBlock - 1) / kSetupBlock), dim3(kSetupBlock), 0, st, P, rec, rec_i);
+  if (P.npairs <= P.slot0) return;
+  hipLaunchKernelGGL(pair_setup_kernel, dim3((P.npairs - P.slot0 + kSetupBlock - 1) / kSetupBlock), dim3(kSetupBlock), 0, st, P, rec, rec_i);
 }
 
 }  // namespace shp

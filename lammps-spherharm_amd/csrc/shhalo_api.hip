@@ -342,6 +342,10 @@ struct shhalo_ctx {
   DevBuf<int> d_blockcnt, d_start, d_totals, d_msg, d_msgin, d_flags, d_peer_of_slot;
   int* h_ints = nullptr;  // pinned: totals[28] | msgin[26*27] | flags[2]
   shhalo_stats stats{};
+  // option "halo_overlap" of the pair context: the forward exchange of a step runs on a stream of its own beside the
+  // pair kernels of the slots that touch owned atoms only (made on first use)
+  hipStream_t st2 = nullptr;
+  hipEvent_t ev_ready = nullptr, ev_ghosts = nullptr;
 };
 
 #define H_FAIL(h, code, ...)                \
@@ -659,6 +663,9 @@ void shhalo_destroy(shhalo_ctx* h)
   h->d_migrows.release(); h->d_migin.release(); h->d_blockcnt.release(); h->d_start.release();
   h->d_totals.release(); h->d_msg.release(); h->d_msgin.release(); h->d_flags.release(); h->d_peer_of_slot.release();
   if (h->h_ints) (void)hipHostFree(h->h_ints);
+  if (h->ev_ready) (void)hipEventDestroy(h->ev_ready);
+  if (h->ev_ghosts) (void)hipEventDestroy(h->ev_ghosts);
+  if (h->st2) (void)hipStreamDestroy(h->st2);
   delete h;
 }
 
@@ -997,6 +1004,11 @@ int shhalo_run_device(shhalo_ctx* h, shhalo_arrays* a, const shhalo_run_params* 
   H_HIP(h, hipSetDevice(h->sp->device));
   hipStream_t st = (hipStream_t)stream;
   shpair_ctx* sp = h->sp;
+  if (sp->opt_overlap && !h->st2) {
+    H_HIP(h, hipStreamCreateWithFlags(&h->st2, hipStreamNonBlocking));
+    H_HIP(h, hipEventCreateWithFlags(&h->ev_ready, hipEventDisableTiming));
+    H_HIP(h, hipEventCreateWithFlags(&h->ev_ghosts, hipEventDisableTiming));
+  }
   const bool body = p->gravity[0] != 0.0 || p->gravity[1] != 0.0 || p->gravity[2] != 0.0 || p->gamma_t != 0.0 || p->gamma_r != 0.0;
   int nghost = *nghost_io, nreb = 0;
   // pair-kernel time: one event pair per step (bounded pool; beyond it the steps are not timed)
@@ -1025,8 +1037,25 @@ int shhalo_run_device(shhalo_ctx* h, shhalo_arrays* a, const shhalo_run_params* 
         ++nreb;
       }
     }
-    rc = shhalo_forward_device(h, a->x, a->quat, st);
+    // "halo_overlap": the forward exchange (pack, ncclSend / ncclRecv per peer, unpack) goes to a second stream behind
+    // this step's positions, and the pair kernels of the slots whose atoms are all owned — the front segment of the
+    // partitioned list, down to a multiple of 32 slots — run beside it; the slots with a ghost wait for the exchange.
+    const bool overlap = sp->opt_overlap && h->st2 != nullptr;
+    hipStream_t sf = overlap ? h->st2 : st;
+    if (overlap) {
+      if (hipEventRecord(h->ev_ready, st) != hipSuccess || hipStreamWaitEvent(h->st2, h->ev_ready, 0) != hipSuccess) {
+        h->err = "hipEventRecord / hipStreamWaitEvent failed (halo_overlap)";
+        rc = SHPAIR_EHIP;
+        break;
+      }
+    }
+    rc = shhalo_forward_device(h, a->x, a->quat, sf);
     if (rc) break;
+    if (overlap && hipEventRecord(h->ev_ghosts, h->st2) != hipSuccess) {
+      h->err = "hipEventRecord failed (halo_overlap)";
+      rc = SHPAIR_EHIP;
+      break;
+    }
     const size_t nall = (size_t)a->nlocal + nghost;
     if (hipMemsetAsync(a->f, 0, 3 * nall * sizeof(double), st) != hipSuccess ||
         hipMemsetAsync(a->torque, 0, 3 * nall * sizeof(double), st) != hipSuccess) {
@@ -1036,8 +1065,22 @@ int shhalo_run_device(shhalo_ctx* h, shhalo_arrays* a, const shhalo_run_params* 
     }
     const int ef = (p->eflag_last && step == nsteps - 1) ? 1 : 0;
     if (step < ntimed) (void)hipEventRecord(ev[2 * step], st);
-    rc = shpair_compute_device(sp, a->nlocal, nghost, a->x, a->quat, a->type, a->shtype, 1, ef, ef, a->f, a->torque,
-                               ef ? p->ev_dev : nullptr, st);
+    if (overlap) {
+      const int split = sp->n_interior & ~31;
+      rc = shp_compute_range(sp, a->nlocal, nghost, a->x, a->quat, a->type, a->shtype, 1, ef, ef, a->f, a->torque,
+                             ef ? p->ev_dev : nullptr, st, 0, split, kPartPre);
+      if (!rc && hipStreamWaitEvent(st, h->ev_ghosts, 0) != hipSuccess) {
+        h->err = "hipStreamWaitEvent failed (halo_overlap)";
+        rc = SHPAIR_EHIP;
+        break;
+      }
+      if (!rc)
+        rc = shp_compute_range(sp, a->nlocal, nghost, a->x, a->quat, a->type, a->shtype, 1, ef, ef, a->f, a->torque,
+                               ef ? p->ev_dev : nullptr, st, split, sp->npairs, kPartPost);
+    } else {
+      rc = shpair_compute_device(sp, a->nlocal, nghost, a->x, a->quat, a->type, a->shtype, 1, ef, ef, a->f, a->torque,
+                                 ef ? p->ev_dev : nullptr, st);
+    }
     if (step < ntimed) (void)hipEventRecord(ev[2 * step + 1], st);
     if (rc) { h->err = sp->err; break; }
     rc = shhalo_reverse_device(h, a->f, a->torque, st);

@@ -280,6 +280,7 @@ static int upload_staged_list(shpair_ctx* c, int inum, size_t tot, int max_index
   }
   HIPCHK(c, shp_size_pair_buffers(c, tot));
   c->npairs = (int)tot;
+  c->n_interior = 0;   // a host-installed list: which slots touch ghosts is not known here
   c->max_atom_index = max_index;
   c->have_neighbors = true;
   ++c->list_gen;
@@ -382,6 +383,7 @@ int shpair_set_neighbors_device(shpair_ctx* c, int inum, const int* ilist, const
   }
   HIPCHK(c, shp_size_pair_buffers(c, (size_t)npairs));
   c->npairs = npairs;
+  c->n_interior = 0;
   c->max_atom_index = max_atom_index;
   c->have_neighbors = true;
   ++c->list_gen;
@@ -603,11 +605,30 @@ int shpair_check_device_errors(shpair_ctx* c, void* stream)
 
 extern "C" {
 
+// The pair path over a RANGE of list slots.  part & kPartPre: everything that has to happen once before the first slot
+// of a step (buffer memsets of the deterministic mode and the tallies, the reverse index, the start-of-timing event);
+// part & kPartPost: what follows the last slot (ordered gather, tally reduce, end-of-timing event, contact counts).
+// shpair_compute_device = both parts over the whole list; the halo loop (shhalo_api.hip) runs the slots whose atoms
+// are all owned — [0, split) — with kPartPre while the forward exchange is in flight, then [split, npairs) with
+// kPartPost.  `split` must be a multiple of 32 (rotation tiles).
 int shpair_compute_device(shpair_ctx* c, int nlocal, int nghost, const double* x, const double* quat, const int* type,
                           const int* shtype, int newton_pair, int eflag, int vflag, double* f, double* torque,
                           double* ev, void* stream)
 {
   if (!c) return SHPAIR_EINVAL;
+  return shp_compute_range(c, nlocal, nghost, x, quat, type, shtype, newton_pair, eflag, vflag, f, torque, ev, stream, 0,
+                           c->npairs, kPartPre | kPartPost);
+}
+
+int shp_compute_range(shpair_ctx* c, int nlocal, int nghost, const double* x, const double* quat, const int* type,
+                      const int* shtype, int newton_pair, int eflag, int vflag, double* f, double* torque, double* ev,
+                      void* stream, const int slot0, const int slot_end, const int part)
+{
+  if (!c) return SHPAIR_EINVAL;
+  if (slot0 < 0 || slot_end < slot0 || slot_end > c->npairs || (slot0 & 31) != 0)
+    CTX_FAIL(c, SHPAIR_EINVAL, "compute range [%d, %d) of a list of %d slots (the first slot must be a multiple of 32)", slot0,
+             slot_end, c->npairs);
+  const bool pre = (part & kPartPre) != 0, post = (part & kPartPost) != 0;
   if (nlocal < 0 || nghost < 0) CTX_FAIL(c, SHPAIR_EINVAL, "negative atom counts");
   if (!c->have_neighbors) CTX_FAIL(c, SHPAIR_ESTATE, "no neighbour list: call shpair_set_neighbors() first");
   if ((eflag || vflag) && !ev) CTX_FAIL(c, SHPAIR_EINVAL, "eflag/vflag set but ev_dev is null");
@@ -620,9 +641,11 @@ int shpair_compute_device(shpair_ctx* c, int nlocal, int nghost, const double* x
     const int rc = upload_quadrature(c);
     if (rc) return rc;
   }
-  c->timed_last = false;
-  c->counted_last = false;
-  c->stats.n_candidates = c->npairs;
+  if (pre) {
+    c->timed_last = false;
+    c->counted_last = false;
+    c->stats.n_candidates = c->npairs;
+  }
   if (c->npairs == 0) return SHPAIR_OK;
   if (!x || !quat || !type || !shtype || !f || !torque) CTX_FAIL(c, SHPAIR_EINVAL, "null atom array");
   if ((long long)c->max_atom_index >= (long long)nlocal + nghost)
@@ -651,7 +674,7 @@ int shpair_compute_device(shpair_ctx* c, int nlocal, int nghost, const double* x
 
   PairParams P;
   P.x = x; P.quat = quat; P.type = type; P.shtype = shtype; P.f = f; P.torque = torque;
-  P.pair_i = c->d_pair_i.p; P.pair_j = c->d_pair_j.p; P.npairs = c->npairs;
+  P.pair_i = c->d_pair_i.p; P.pair_j = c->d_pair_j.p; P.npairs = slot_end; P.slot0 = slot0;
   P.nlocal = nlocal; P.newton_pair = newton_pair ? 1 : 0;
   P.rc = c->d_rc.p; P.coef = c->d_coef.p; P.rmax = c->d_rmax.p; P.cstride = c->cstride; P.lmax = c->lmax;
   P.nshapes = c->nshapes; P.err = c->d_err.p;
@@ -807,7 +830,7 @@ int shpair_compute_device(shpair_ctx* c, int nlocal, int nghost, const double* x
       c->rev_dirty = false;
       c->rev_nall = nall_idx;
     }
-    HIPCHK(c, hipMemsetAsync(c->d_pair_ft.p, 0, (size_t)c->npairs * 12 * sizeof(double), st));
+    if (pre) HIPCHK(c, hipMemsetAsync(c->d_pair_ft.p, 0, (size_t)c->npairs * 12 * sizeof(double), st));
     P.pair_ft = c->d_pair_ft.p;
   }
   P.ev = ev; P.pair_out = c->pair_out;
@@ -816,7 +839,7 @@ int shpair_compute_device(shpair_ctx* c, int nlocal, int nghost, const double* x
   if (eflag || vflag) {
     // per-slot rows + the block sums behind them (sized with the list, shp_size_pair_buffers: nothing is allocated in a capture)
     HIPCHK(c, c->d_pair_ev.ensure(8 * ((size_t)c->npairs + (size_t)tally_blocks)));
-    HIPCHK(c, hipMemsetAsync(c->d_pair_ev.p, 0, 8 * (size_t)c->npairs * sizeof(double), st));
+    if (pre) HIPCHK(c, hipMemsetAsync(c->d_pair_ev.p, 0, 8 * (size_t)c->npairs * sizeof(double), st));
     P.pair_ev = c->d_pair_ev.p;
   }
   P.flags = nullptr;
@@ -824,8 +847,10 @@ int shpair_compute_device(shpair_ctx* c, int nlocal, int nghost, const double* x
   P.eflag = eflag ? 1 : 0; P.vflag = vflag ? 1 : 0;
   if (c->opt_count) {
     HIPCHK(c, c->d_flags.ensure(c->npairs));
-    HIPCHK(c, hipMemsetAsync(c->d_counters.p, 0, 2 * sizeof(unsigned long long), st));
-    HIPCHK(c, hipMemsetAsync(c->d_flags.p, 0, c->npairs, st));
+    if (pre) {
+      HIPCHK(c, hipMemsetAsync(c->d_counters.p, 0, 2 * sizeof(unsigned long long), st));
+      HIPCHK(c, hipMemsetAsync(c->d_flags.p, 0, c->npairs, st));
+    }
     P.flags = c->d_flags.p;
   }
   const bool needv = c->opt_force_volume || eflag || c->any_nonunit_exponent || c->eatom_dev != nullptr;
@@ -842,7 +867,7 @@ int shpair_compute_device(shpair_ctx* c, int nlocal, int nghost, const double* x
   } else {
     P.rot = nullptr;
   }
-  if (c->opt_timing) HIPCHK(c, hipEventRecord(c->ev0, st));
+  if (c->opt_timing && pre) HIPCHK(c, hipEventRecord(c->ev0, st));
   launch_pair_setup(P, c->d_rec.p, c->d_rec_i.p, st);
   if (c->lmax <= kMaxUnrolledL && c->opt_variant != 1) {
     P.coef = c->d_coefm.p;  // compiled orders read the monomial (Horner) table
@@ -851,6 +876,7 @@ int shpair_compute_device(shpair_ctx* c, int nlocal, int nghost, const double* x
     shp_launch_Lrt(P, needv, st, c->pre_contact_wait);
   }
   HIPCHK(c, hipGetLastError());
+  if (!post) return SHPAIR_OK;
   if (c->opt_deterministic) {
     const int nall_idx = c->max_atom_index + 1;
     hipLaunchKernelGGL(det_gather_kernel, dim3((6 * nall_idx + kDetBlock - 1) / kDetBlock), dim3(kDetBlock), 0, st, nall_idx,
@@ -1081,6 +1107,7 @@ int shpair_set_option(shpair_ctx* c, const char* key, int value)
     c->rev_dirty = true;
   }
   else if (!strcmp(key, "waves_per_block")) c->opt_wpb = value;
+  else if (!strcmp(key, "halo_overlap")) c->opt_overlap = value ? 1 : 0;
   else CTX_FAIL(c, SHPAIR_EINVAL, "unknown option '%s'", key);
   return SHPAIR_OK;
 }

@@ -96,6 +96,9 @@ struct shpair_ctx {
   unsigned long long* h_counters = nullptr;  // pinned 2
 
   int opt_force_volume = 0, opt_timing = 0, opt_count = 0, opt_variant = 0, opt_ring_rows = 0, opt_wpb = 0, opt_rule = 0;
+  int opt_overlap = 1;   // "halo_overlap" (default on: not slower in the one-GPU rehearsal of 8 ranks, profiles/r04_l_local8.txt): device-built lists are partitioned interior / boundary and shhalo_run_device runs
+                         // the interior slots while the forward exchange is in flight
+  int n_interior = 0;    // slots [0, n_interior) of the installed list touch owned atoms only (device-built lists)
   int opt_jpoly = -1;      // 1 / 0: compiled orders evaluate particle j from per-azimuth polynomials or not; -1: by the
                            // measured rule (shpair_api.hip use_jpoly)
   bool last_jpoly = false;
@@ -146,3 +149,8 @@ int shstep_enqueue_check(shpair_ctx* c, int nlocal, const double* x, int** flag_
 
 // shpair_api.hip: sizes the per-slot buffers of the pair kernels for a list of np slots (used by every list install)
 hipError_t shp_size_pair_buffers(shpair_ctx* c, size_t np);
+// the pair path over the slots [slot0, slot_end) of the installed list (shpair_api.hip; part: kPartPre | kPartPost)
+enum { kPartPre = 1, kPartPost = 2 };
+extern "C" int shp_compute_range(shpair_ctx* c, int nlocal, int nghost, const double* x, const double* quat, const int* type,
+                                 const int* shtype, int newton_pair, int eflag, int vflag, double* f, double* torque, double* ev,
+                                 void* stream, int slot0, int slot_end, int part);

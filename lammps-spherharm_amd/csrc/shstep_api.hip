@@ -31,6 +31,8 @@ struct shstep_state {
   int b_nlocal = 0, nghost = 0;
   // bins + list
   DevBuf<int> d_cell, d_cellcount, d_cellstart, d_atoms, d_nn, d_offs;
+  DevBuf<int> d_part_i, d_part_j, d_part_scan;   // "halo_overlap": the row-major list (kept for shstep_copy_neighbors) / scan scratch
+  bool partitioned = false;
   DevBuf<double> d_xhold;
   int l_nlocal = -1;
 
@@ -42,7 +44,7 @@ struct shstep_state {
   {
     d_mass.release(); d_flags.release(); d_cnt.release(); d_goff.release(); d_sums.release(); d_gowner.release();
     d_gcode.release(); d_cell.release(); d_cellcount.release(); d_cellstart.release(); d_atoms.release();
-    d_nn.release(); d_offs.release(); d_xhold.release(); s_x.release(); s_v.release(); s_q.release();
+    d_nn.release(); d_offs.release(); d_part_i.release(); d_part_j.release(); d_part_scan.release(); d_xhold.release(); s_x.release(); s_v.release(); s_q.release();
     s_L.release(); s_f.release(); s_t.release(); s_sh.release(); s_mask.release();
     if (h_flags) (void)hipHostFree(h_flags);
     h_flags = nullptr;
@@ -455,6 +457,29 @@ int shstep_neighbor_build_device(shpair_ctx* c, int nlocal, int nghost, const do
   hipLaunchKernelGGL(copy_x_kernel, dim3(nblk(3LL * nlocal, kStepBlock)), dim3(kStepBlock), 0, st, nlocal, x, s->d_xhold.p);
   HIPCHK(c, hipGetLastError());
   RC(check_device_flags(c, s, st));
+  c->n_interior = np;   // no ghost j, or no partition: every slot may run before the ghosts arrive only if there are none
+  s->partitioned = false;
+  if (c->opt_overlap && nghost > 0 && np > 0) {
+    // interior slots first (stable), ghost-j slots behind them: the context's list becomes the partitioned one, the
+    // row-major j list stays in d_part_j for shstep_copy_neighbors
+    HIPCHK(c, s->d_part_i.ensure((size_t)np));
+    HIPCHK(c, s->d_part_j.ensure((size_t)np));
+    HIPCHK(c, s->d_part_scan.ensure(2 * (size_t)np + 2));
+    int* flag = s->d_part_scan.p + np + 1;
+    hipLaunchKernelGGL(part_flag_kernel, dim3(nblk(np, kStepBlock)), dim3(kStepBlock), 0, st, np, nlocal, (const int*)c->d_pair_j.p, flag);
+    RC(exclusive_scan(c, s, flag, s->d_part_scan.p, np, st));
+    hipLaunchKernelGGL(part_scatter_kernel, dim3(nblk(np, kStepBlock)), dim3(kStepBlock), 0, st, np, nlocal, (const int*)c->d_pair_i.p,
+                       (const int*)c->d_pair_j.p, (const int*)s->d_part_scan.p, s->d_part_i.p, s->d_part_j.p);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(s->h_flags + 2, s->d_part_scan.p + np, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    c->n_interior = s->h_flags[2];
+    std::swap(c->d_pair_i, s->d_part_i);
+    std::swap(c->d_pair_j, s->d_part_j);
+    s->partitioned = true;
+  } else if (nghost > 0) {
+    c->n_interior = 0;   // ghosts but no partition: nothing may run ahead of the forward exchange
+  }
   c->npairs = np;
   c->max_atom_index = nall - 1;
   c->have_neighbors = true;
@@ -532,7 +557,9 @@ int shstep_copy_neighbors(shpair_ctx* c, int* offsets, int* jlist)
   if (s->l_nlocal < 0 || !c->have_neighbors) CTX_FAIL(c, SHPAIR_ESTATE, "no device-built neighbour list");
   HIPCHK(c, hipDeviceSynchronize());
   if (offsets) HIPCHK(c, hipMemcpy(offsets, s->d_offs.p, ((size_t)s->l_nlocal + 1) * sizeof(int), hipMemcpyDeviceToHost));
-  if (jlist && c->npairs > 0) HIPCHK(c, hipMemcpy(jlist, c->d_pair_j.p, (size_t)c->npairs * sizeof(int), hipMemcpyDeviceToHost));
+  // (with "halo_overlap" the context's list is partitioned interior / boundary; the row-major copy is kept beside it)
+  if (jlist && c->npairs > 0)
+    HIPCHK(c, hipMemcpy(jlist, s->partitioned ? s->d_part_j.p : c->d_pair_j.p, (size_t)c->npairs * sizeof(int), hipMemcpyDeviceToHost));
   return SHPAIR_OK;
 }
 

@@ -471,6 +471,26 @@ __global__ __launch_bounds__(kStepBlock) void half_list_kernel(int nlocal, int n
   if (!FILL) nn[i] = cntr;
 }
 
+// Interior / boundary partition of the expanded half list (option "halo_overlap"): slots whose j is an owned atom
+// first, slots with a ghost j behind them, both in their list order (a stable partition: flag -> exclusive scan ->
+// scatter).  The halo loop runs the interior slots while the forward exchange is in flight (shhalo_api.hip).
+__global__ __launch_bounds__(kStepBlock) void part_flag_kernel(int np, int nlocal, const int* __restrict__ pair_j, int* __restrict__ flag)
+{
+  const int w = blockIdx.x * kStepBlock + threadIdx.x;
+  if (w < np) flag[w] = pair_j[w] < nlocal ? 1 : 0;
+}
+__global__ __launch_bounds__(kStepBlock) void part_scatter_kernel(int np, int nlocal, const int* __restrict__ pair_i,
+                                                                  const int* __restrict__ pair_j, const int* __restrict__ scan,
+                                                                  int* __restrict__ out_i, int* __restrict__ out_j)
+{
+  const int w = blockIdx.x * kStepBlock + threadIdx.x;
+  if (w >= np) return;
+  const int j = pair_j[w], before = scan[w];   // interior slots in front of w
+  const int dst = (j < nlocal) ? before : scan[np] + (w - before);
+  out_i[dst] = pair_i[w];
+  out_j[dst] = j;
+}
+
 __global__ __launch_bounds__(kStepBlock) void copy_x_kernel(int n, const double* __restrict__ x, double* __restrict__ xhold)
 {
   const int k = blockIdx.x * kStepBlock + threadIdx.x;

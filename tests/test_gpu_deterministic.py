@@ -154,8 +154,11 @@ def test_device_resident_trajectories_are_bitwise_reproducible():
     assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
 
 
-def test_multi_rank_trajectories_are_bitwise_reproducible():
-    """2 x 2 x 1 rank threads on the one GPU (in-process hub), deterministic mode: the pair accumulation, the list build,
+@pytest.mark.parametrize("overlap", [0, 1])
+def test_multi_rank_trajectories_are_bitwise_reproducible(overlap):
+    """(overlap = 1: the partitioned list and the forward exchange on its own stream, option "halo_overlap" — the order of
+    the sums is another one, and as fixed.)
+    2 x 2 x 1 rank threads on the one GPU (in-process hub), deterministic mode: the pair accumulation, the list build,
     the ghost order and the reverse unpack (one launch per direction, no atomics) all fix their order of summation, so two
     runs of a moving bed with migration and rebuilds agree bit for bit."""
     import threading
@@ -182,6 +185,7 @@ def test_multi_rank_trajectories_are_bitwise_reproducible():
             sp.set_shape(s, lmax, a)
         sp.coeff(1, 1, 400.0, 1.25)
         sp.set_option("deterministic", 1)
+        sp.set_option("halo_overlap", overlap)
         return sp
     sp0 = ctx()
     cut = 2.0 * max(sp0.rmax(s) for s in range(2)) + skin

@@ -141,10 +141,12 @@ def test_static_forces_and_plan_match_single_domain(grid, periodic):
         hub.close()
 
 
+@pytest.mark.parametrize("overlap", [0, 1])
 @pytest.mark.parametrize("grid,periodic", [((2, 1, 1), (1, 1, 1)), ((2, 2, 1), (1, 1, 0)), ((1, 1, 1), (1, 1, 1)), ((2, 2, 2), (1, 1, 0))])
-def test_dynamic_run_matches_single_rank(grid, periodic):
+def test_dynamic_run_matches_single_rank(grid, periodic, overlap):
     """Atoms move fast enough to change owner; the C++ loop of every rank (exchange, borders, rebuilds, forward,
-    reverse) must reproduce the single-rank loop's trajectory."""
+    reverse) must reproduce the single-rank loop's trajectory.  overlap = 1: option "halo_overlap" — the list partitioned
+    into owned-only and ghost slots, the forward exchange on a stream of its own beside the owned-only pair kernels."""
     import torch
     from shpair import shapes, mrank
     from shpair.run import DeviceRun
@@ -164,6 +166,7 @@ def test_dynamic_run_matches_single_rank(grid, periodic):
 
     def body(rank):
         sp = _ctx(lmax, shp, nq)
+        sp.set_option("halo_overlap", overlap)
         halo = mrank.Halo(sp, rank, world, grid, lo, hi, periodic, skin, hub=hub)
         mine = owner == rank
         run = mrank.RankRun(sp, halo, xw[mine], quat[mine], sht[mine], tag[mine], v=v0[mine], mask=mask[mine], dt=dt, gravity=grav,
