@@ -880,8 +880,23 @@ __device__ __forceinline__ void cap_frame_rings(const PairParams& P, double* __r
 // per entry, a pass per order class) was 256 of the headline kernel's 1 826 vector instructions per pair, 59 % of them
 // not FP64 (profiles/r04_d_headline_valu_sites.txt).
 // Entry e = ring * (L + 1) + order IS the ring table's own index: the store needs no address arithmetic beyond 32 e.
-template <int L, int WPP>
-__device__ __forceinline__ void cap_frame_rings_poly(const PairParams& P, double* __restrict__ lw, const WaveLdsLayout& W,
+// Lane map of cap_frame_rings_poly for a group of `nrows` rings on NT lanes: -1 = DENSE, one lane per table entry (ring,
+// order), ceil(nrows (L + 1) / NT) passes; lg >= 1 = GROUPED, 2^lg lanes per ring, lane g of a ring takes the orders
+// g, g + 2^lg, ... — one pass, and what an entry shares with the other orders of its ring (the Gauss node, mu, sigma,
+// 1 / sigma: ~25 of a dense entry's ~69 vector instructions) is made once per lane.  Chosen by that instruction count.
+__host__ __device__ inline int ring_poly_map(const int nrows, const int K, const int NT)
+{
+  const int nent = nrows * K;
+  if (nent <= NT) return -1;
+  int lg = 0;
+  while ((NT >> (lg + 1)) >= nrows && (1 << lg) < K) ++lg;   // as many lanes per ring as one pass over the group allows
+  if (lg < 1) return -1;
+  const int E = (K + (1 << lg) - 1) >> lg, passes = (nent + NT - 1) / NT;
+  return (25 + 44 * E < 69 * passes) ? lg : -1;
+}
+
+template <int L, int WPP, class PP = PairParams>
+__device__ __forceinline__ void cap_frame_rings_poly(const PP& P, double* __restrict__ lw, const WaveLdsLayout& W,
                                                      const int lane, const int tid, const int k0, const int nrows,
                                                      const double hw, const double hm, const bool have_first)
 {
@@ -889,17 +904,10 @@ __device__ __forceinline__ void cap_frame_rings_poly(const PairParams& P, double
   const double* pi = lw + W.pi;
   double* ring = lw + W.ring;
   const int nent = nrows * K;
-  for (int e0 = 0; e0 < nent; e0 += NT) {   // wave-uniform
-    const int e = e0 + tid;
-    const int ec = min(e, nent - 1);   // idle lanes repeat the last entry and store nothing
-    const int kr = (int)((unsigned)ec / (unsigned)K), m = ec - kr * K;
-    // have_first: this lane's Gauss-Legendre node of the first pass of the first ring group was requested at the start
-    // of the kernel and waits in the (empty) queue
-    const double tk = (have_first && k0 == 0 && e0 == 0) ? lw[W.stash + lane] : P.glt[k0 + kr];
-    const double mu = fma(hw, tk, hm);
-    const double sig2 = max_raw(fma(-mu, mu, 1.0), 1e-300);
-    const double isig = rsqrt_nr(sig2);
-    const double sig = sig2 * isig;
+  const int lg = ring_poly_map(nrows, K, NT);   // wave-uniform
+  // one table entry: value and mu-derivative of both parts of order m at (mu, sigma), stored at entry e
+  auto entry = [&](const int m, const int e, const bool store, const double mu, const double sig, const double isig)
+                   __attribute__((always_inline)) {
     const double* row = pi + (2 * K) * m;   // 16-byte aligned: 2K doubles per order, an aligned base
     v2d c[K];
 #pragma unroll
@@ -930,10 +938,38 @@ __device__ __forceinline__ void cap_frame_rings_poly(const PairParams& P, double
       B = mu;
       dB = sig;
     }
-    if (e < nent) {
+    if (store) {
       double* o = ring + 4 * e;
       *(v2d*)__builtin_assume_aligned(o, 16) = v2d{A, B};
       *(v2d*)__builtin_assume_aligned(o + 2, 16) = v2d{dA, dB};
+    }
+  };
+  if (lg >= 1) {
+    // GROUPED: lane = (ring, g)
+    const int G = 1 << lg, kr = tid >> lg, g = tid & (G - 1);
+    const int krc = min(kr, nrows - 1);
+    const double tk = (have_first && k0 == 0) ? lw[W.stash + lane] : P.glt[k0 + krc];
+    const double mu = fma(hw, tk, hm);
+    const double sig2 = max_raw(fma(-mu, mu, 1.0), 1e-300);
+    const double isig = rsqrt_nr(sig2);
+    const double sig = sig2 * isig;
+    for (int m0 = 0; m0 < K; m0 += G) {   // wave-uniform trip count
+      const int m = m0 + g;
+      entry(min(m, K - 1), krc * K + m, kr < nrows && m < K, mu, sig, isig);
+    }
+  } else {
+    for (int e0 = 0; e0 < nent; e0 += NT) {   // DENSE: wave-uniform passes
+      const int e = e0 + tid;
+      const int ec = min(e, nent - 1);   // idle lanes repeat the last entry and store nothing
+      const int kr = (int)((unsigned)ec / (unsigned)K), m = ec - kr * K;
+      // have_first: this lane's Gauss-Legendre node of the first pass of the first ring group was requested at the start
+      // of the kernel and waits in the (empty) queue
+      const double tk = (have_first && k0 == 0 && e0 == 0) ? lw[W.stash + lane] : P.glt[k0 + kr];
+      const double mu = fma(hw, tk, hm);
+      const double sig2 = max_raw(fma(-mu, mu, 1.0), 1e-300);
+      const double isig = rsqrt_nr(sig2);
+      const double sig = sig2 * isig;
+      entry(m, e, e < nent, mu, sig, isig);
     }
   }
   pair_sync<WPP>();
@@ -1302,7 +1338,8 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
   if constexpr (JPT && L >= 0 && !WEIGHTED) glw_first = P.glw[tid < P.nq ? tid : 0];   // the weight of ring `tid`, stored after the first stage
   if constexpr (JPT && L >= 0 && L <= 8 && !WEIGHTED && WPP == 1) {
     const int nr0 = P.ring_rows < P.nq ? P.ring_rows : P.nq;   // rings of the first group
-    const int kr = lane / (L + 1);                             // cap_frame_rings_poly's lane map: entry = ring (L + 1) + order
+    const int lg0 = ring_poly_map(nr0, L + 1, 64);             // cap_frame_rings_poly's lane map of that group's first pass
+    const int kr = lg0 >= 1 ? (lane >> lg0) : lane / (L + 1);
     glt_first = P.glt[kr < nr0 ? kr : nr0 - 1];
   }
   const int status = rid[0];
@@ -1899,15 +1936,23 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
       }
       // a node outside j contributes exactly nothing (r^3 - r^3 under FMA contraction is a rounding residue, and
       // V^(m-1) turns a residue of 1e-22 into a visible force)
+      // CARRY: the node (ring, azimuth, weight, mu, sigma) stays in registers across the root loop where the kernel has
+      // them to spare; elsewhere it is looked up a second time below
+      // (from L = 6 on: six registers; up to L = 5 they would cost the sixth wave per SIMD, the one-wave kernel of L = 9
+      // its fifth.  A/B profiles/r04_n_ab_carry.txt: L = 6, 7, 8 / n_q = 16 -1.6 %, -1.8 %, -1.5 %)
+#ifndef SHP_CARRY_NODE
+#define SHP_CARRY_NODE(L, WPP) ((L) >= 6 && !((L) == 9 && (WPP) == 1))
+#endif
+      constexpr bool CARRY = JP && SHP_CARRY_NODE(L, WPP);
       if constexpr (JP) {
         // the batch's queue slots are untouched until the next phase 1: r_i and the node index are read again from
         // the slot instead of being carried through the root loop (three registers become one)
         const int e2 = (int)launder_u32((unsigned)e);
         ri = fr[W.qri + e2];
-        p = ((const unsigned short*)(fr + W.qp))[e2];
+        if constexpr (!CARRY) p = ((const unsigned short*)(fr + W.qp))[e2];
       }
       const double dv3 = (WEIGHTED && outside) ? 0.0 : ri * ri * ri - rin * rin * rin;
-      if constexpr (JP) {
+      if constexpr (JP && !CARRY) {
         // The node is looked up a second time here (the root loop holds a row of particle j's table in 4L + 2
         // registers and has none to carry weight, psi, mu, sigma across), from LDS only.
         p = (int)launder_u32((unsigned)p);
