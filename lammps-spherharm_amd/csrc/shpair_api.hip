@@ -973,7 +973,10 @@ int shpair_compute(shpair_ctx* c, int nlocal, int nghost, const double* x, const
                                        newton_pair, eflag, vflag, c->d_f.p, c->d_torque.p, c->d_ev.p, st);
   c->pre_contact_wait = nullptr;
   HIPCHK(c, hipStreamWaitEvent(st, c->ev_up, 0));   // whatever path the launch took (no pairs, an early error): st is behind the uploads
-  if (rc) return rc;
+  if (rc) {
+    (void)hipStreamSynchronize(st);   // stream_up may still be reading the caller's f / torque: not after this call has returned
+    return rc;
+  }
   if (pe) HIPCHK(c, hipMemcpyAsync(c->eatom_host, c->d_eatom.p, nall * sizeof(double), hipMemcpyDeviceToHost, st));
   if (pv) HIPCHK(c, hipMemcpyAsync(c->vatom_host, c->d_vatom.p, 6 * nall * sizeof(double), hipMemcpyDeviceToHost, st));
   HIPCHK(c, hipMemcpyAsync(f, c->d_f.p, 3 * nall * sizeof(double), hipMemcpyDeviceToHost, st));

@@ -344,6 +344,22 @@ void PairSH::compute(int eflag, int vflag)
   if (nall) {
     // the arrays keep their place until atom->nmax grows: page-locked once, copied by DMA every step
     const size_t rows = (size_t) (atom->nmax > nall ? atom->nmax : nall);
+    // When anything moved (atom->nmax grew), ALL six old registrations go first: x, f and torque have the same size, the
+    // allocator may hand one array another's old address, and a slot-by-slot update would then find "same pointer, same
+    // bytes" on a stale entry and later unpin the registration its neighbour believes it holds.
+    {
+      void *want[6] = {x0, q0, f0, t0, atom->type, shtype};
+      const size_t wbytes[6] = {rows * 3 * sizeof(double), rows * 4 * sizeof(double), rows * 3 * sizeof(double),
+                                rows * 3 * sizeof(double), rows * sizeof(int), rows * sizeof(int)};
+      bool moved = false;
+      for (int k = 0; k < 6; k++) moved = moved || pinned_ptr[k] != want[k] || pinned_bytes[k] != wbytes[k];
+      if (moved)
+        for (int k = 0; k < 6; k++) {
+          if (pinned_ptr[k]) shpair_unpin_host(ctx, pinned_ptr[k]);
+          pinned_ptr[k] = nullptr;
+          pinned_bytes[k] = 0;
+        }
+    }
     pin(0, x0, rows * 3 * sizeof(double));
     pin(1, q0, rows * 4 * sizeof(double));
     pin(2, f0, rows * 3 * sizeof(double));
