@@ -575,7 +575,10 @@ struct RotLaneLds {
   static constexpr int NB = 2 * L + 1;
   static constexpr int a() { return 0; }
   static constexpr int b() { return 0; }   // the second gather reads the block in place: a lane only ever touches its own column
-  static constexpr int bytes() { return 8 * (NB * 64); }
+  // L >= 9 (rows of the rotated vectors rotation-major in memory): the block's rows of X^T and of X wait in LDS behind
+  // the column block, 2 (2l + 1)(L / 2 + 1) doubles
+  static constexpr int xs() { return NB * 64; }
+  static constexpr int bytes() { return 8 * (NB * 64 + (rot_tiled(L) ? 0 : 2 * NB * (L / 2 + 1))); }
 };
 // cos / sin(m angle), m = 1..L, of a lane's three Euler angles: registers (every index is a compile-time constant)
 template <int L>
@@ -604,6 +607,24 @@ __device__ __forceinline__ void rotate_lane_block(const PairParams& P, double* _
   const auto gsc = [&] { if constexpr (rot_tiled(L)) return launder_uniform(P.gscale); else return P.gscale; }();
   double* A = sm + RotLaneLds<L>::a() + lane;
   double* B = sm + RotLaneLds<L>::b() + lane;
+  // L >= 9 (round 4): this block's rows of X^T and X are staged in LDS by the wave (contiguous in the ELL table: row =
+  // base + r) and read as broadcasts at immediate offsets, with the compile-time columns of the small orders — instead
+  // of two vector loads (value, column) and six integer instructions of address arithmetic per v_fma_f64 (4 353 of the
+  // L = 12 kernel's ~8 000 vector instructions per wave were 32-bit integer, 1 067 were vector memory reads).  With
+  // constant addresses the compiler forwards a lane's LDS stores to its own loads, so the block lives in registers
+  // (230-254 of them: two waves per SIMD as before).  L = 12: 0.926 -> 0.752 ms per launch, L = 9: 0.488 -> 0.457
+  // (profiles/r04_x_rot_kernel_times.txt).  Tried on top and dropped: the trig multiples by recurrence instead of the
+  // 6 L-double table (0.83 ms at two waves per SIMD; capped at three waves the kernel spills and runs 0.95 ms).
+  constexpr bool XLDS = !rot_tiled(L);
+  const double* xs = sm + RotLaneLds<L>::xs();
+  if constexpr (XLDS) {
+    double* xw = sm + RotLaneLds<L>::xs();
+    for (int i = lane; i < n * XW; i += 64) {
+      xw[i] = P.xval[((size_t)ns + base) * XW + i];
+      xw[n * XW + i] = P.xval[(size_t)base * XW + i];
+    }
+    wave_lds_sync();
+  }
   // Z(alpha) on the way in: the pair (l, +m), (l, -m) turns by m alpha
   A[64 * LB] = cre[base + LB];
 #pragma unroll
@@ -627,7 +648,7 @@ __device__ __forceinline__ void rotate_lane_block(const PairParams& P, double* _
       if constexpr (rot_tiled(L)) {
         if (t < count) o = fma(xval[ro + t], A[64 * (LB + first + 2 * t)], o);
       } else {
-        o = fma(xval[ro + t], A[64 * (P.xcol[ro + t] - base)], o);   // L >= 9: the table's own columns (see below)
+        if (t < count) o = fma(xs[r * XW + t], A[64 * (LB + first + 2 * t)], o);   // L >= 9: X from LDS
       }
     }
     xb[r] = o;
@@ -652,7 +673,7 @@ __device__ __forceinline__ void rotate_lane_block(const PairParams& P, double* _
       if constexpr (rot_tiled(L)) {
         if (t < count) o = fma(xval[ro + t], B[64 * (LB + first + 2 * t)], o);
       } else {
-        o = fma(xval[ro + t], B[64 * (P.xcol[ro + t] - base)], o);   // L >= 9: the table's own columns (see below)
+        if (t < count) o = fma(xs[(n + r) * XW + t], B[64 * (LB + first + 2 * t)], o);   // L >= 9: X from LDS
       }
     }
     xb[r] = o;
