@@ -113,6 +113,23 @@ def test_self_launcher_gives_the_line_of_torch_distributed_run():
     assert 0.5 < a["value"] / b["value"] < 2.0
 
 
+def test_self_launcher_with_more_ranks_than_gpus_ends_cleanly():
+    """`bench.py --gpus 2` on a box with ONE GPU: rank 1 finds no device of its own and leaves with exit code 3 while rank 0
+    sits in the rendezvous; the parent gives rank 0 ten seconds, ends it, and returns rank 1's code — no line, no hang."""
+    import time
+    import torch
+    if torch.cuda.device_count() != 1:
+        pytest.skip("needs exactly one visible GPU")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    t0 = time.monotonic()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--particles", "4000", "--steps", "2", "--wait-s", "60"],
+                       capture_output=True, text=True, timeout=400, cwd=ROOT, env=env)
+    assert r.returncode == 3, (r.returncode, r.stderr[-2000:])
+    assert "only 1 GPU(s) visible" in r.stderr and "ended rank process(es) [0]" in r.stderr, r.stderr[-2000:]
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert time.monotonic() - t0 < 200
+
+
 def test_a_rank_that_never_arrives_ends_the_run_with_a_message():
     """Bounded waits: WORLD_SIZE = 2 but only rank 0 exists.  The gloo rendezvous must give up within --wait-s with a
     message and a non-zero exit code instead of hanging (RCCL and the launcher have no timeout of their own here)."""
