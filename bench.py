@@ -111,9 +111,10 @@ def parse():
                     "(16 = the host-core share of one GPU on the bench box)")
     ap.add_argument("--peak-ms", type=float, default=20.0, help="length of the v_fma_f64 peak measurement (0 = skip)")
     ap.add_argument("--vthermal", type=float, default=0.25, help="N > 1: initial velocity scale of the bed")
-    ap.add_argument("--halo-overlap", type=int, default=-1, choices=[-1, 0, 1],
+    ap.add_argument("--halo-overlap", type=int, default=-1, choices=[-1, 0, 1, 2],
                     help="N > 1: option \"halo_overlap\" (1: the forward exchange runs on a stream of its own beside the pair "
-                         "kernels of the slots that touch owned atoms only); -1 = the library's default")
+                         "kernels of the slots that touch owned atoms only; 2: the reverse exchange hidden too, beside the second half of "
+                         "those slots); -1 = the library's default")
     ap.add_argument("--one-device", action="store_true", help="N > 1 with --transport rccl: every rank uses GPU 0 (only to probe "
                     "what RCCL does with several ranks on one device; RCCL normally refuses)")
     a = ap.parse_args()

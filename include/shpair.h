@@ -162,10 +162,13 @@ int shpair_compute_device(shpair_ctx *ctx, int nlocal, int nghost, const double 
  * list slot; the ghost reverse sums of shstep / shhalo follow the option (no atomics, fixed order), so device-resident
  * trajectories are reproducible too, on one rank and on several; 0 (default): atomics.  The GLOBAL energy / virial
  * tallies are bitwise reproducible in both modes — per-slot rows added in slot order — the per-atom tallies keep their
- * atomics), "halo_overlap" (1, the default: device-built lists are partitioned — slots whose two atoms are owned first, slots with a
+ * atomics), "halo_overlap" (1: device-built lists are partitioned — slots whose two atoms are owned first, slots with a
  * ghost behind them, each in list order — and shhalo_run_device runs the forward exchange of a step on a stream of its
- * own beside the pair kernels of the owned-only slots; 0: the exchange and the pair kernels follow each other on the
- * caller's stream; same forces, another order of the per-atom sums).
+ * own beside the pair kernels of the owned-only slots; 2, the default: the reverse exchange is hidden as well — half of the owned-only
+ * slots run beside the forward exchange, the ghost slots follow it, the other half runs beside the reverse exchange,
+ * whose unpack uses the same FP64 atomics (atomic accumulation only: with "deterministic" 2 behaves as 1); 0: the
+ * exchanges and the pair kernels follow each other on the caller's stream; same forces, another order of the per-atom
+ * sums).
  * Memory: the contact path keeps per-slot scratch in HBM — a 320-byte record and, for the "jpoly" family, two rotated
  * coefficient vectors of (lmax+1)^2 doubles each (rounded up to 8 from lmax = 9 on): 1.1 KB per list slot at lmax = 6
  * (0.7 GB at 100k particles / 580k pairs, ~7 GB at 1 M), 3.0 KB at lmax = 12 (1.7 GB at 100k); +96 bytes per slot in

@@ -345,7 +345,7 @@ struct shhalo_ctx {
   // option "halo_overlap" of the pair context: the forward exchange of a step runs on a stream of its own beside the
   // pair kernels of the slots that touch owned atoms only (made on first use)
   hipStream_t st2 = nullptr;
-  hipEvent_t ev_ready = nullptr, ev_ghosts = nullptr;
+  hipEvent_t ev_ready = nullptr, ev_ghosts = nullptr, ev_bdone = nullptr, ev_rev = nullptr;
 };
 
 #define H_FAIL(h, code, ...)                \
@@ -665,6 +665,8 @@ void shhalo_destroy(shhalo_ctx* h)
   if (h->h_ints) (void)hipHostFree(h->h_ints);
   if (h->ev_ready) (void)hipEventDestroy(h->ev_ready);
   if (h->ev_ghosts) (void)hipEventDestroy(h->ev_ghosts);
+  if (h->ev_bdone) (void)hipEventDestroy(h->ev_bdone);
+  if (h->ev_rev) (void)hipEventDestroy(h->ev_rev);
   if (h->st2) (void)hipStreamDestroy(h->st2);
   delete h;
 }
@@ -1008,6 +1010,8 @@ int shhalo_run_device(shhalo_ctx* h, shhalo_arrays* a, const shhalo_run_params* 
     H_HIP(h, hipStreamCreateWithFlags(&h->st2, hipStreamNonBlocking));
     H_HIP(h, hipEventCreateWithFlags(&h->ev_ready, hipEventDisableTiming));
     H_HIP(h, hipEventCreateWithFlags(&h->ev_ghosts, hipEventDisableTiming));
+    H_HIP(h, hipEventCreateWithFlags(&h->ev_bdone, hipEventDisableTiming));
+    H_HIP(h, hipEventCreateWithFlags(&h->ev_rev, hipEventDisableTiming));
   }
   const bool body = p->gravity[0] != 0.0 || p->gravity[1] != 0.0 || p->gravity[2] != 0.0 || p->gamma_t != 0.0 || p->gamma_r != 0.0;
   int nghost = *nghost_io, nreb = 0;
@@ -1065,10 +1069,17 @@ int shhalo_run_device(shhalo_ctx* h, shhalo_arrays* a, const shhalo_run_params* 
     }
     const int ef = (p->eflag_last && step == nsteps - 1) ? 1 : 0;
     if (step < ntimed) (void)hipEventRecord(ev[2 * step], st);
+    // "halo_overlap" 2 (atomic accumulation only): the REVERSE exchange is hidden too — the owned-only slots are cut in
+    // two, [0, a) runs beside the forward exchange, the ghost slots follow it, and [a, split) runs beside the reverse
+    // exchange, whose unpack adds into the owners' rows with the same FP64 atomics the pair kernels use.  (The
+    // deterministic mode adds in a fixed order with plain stores: there the reverse exchange stays behind the kernels.)
+    const bool overlap_rev = overlap && sp->opt_overlap >= 2 && !sp->opt_deterministic;
+    bool reverse_done = false;
     if (overlap) {
       const int split = sp->n_interior & ~31;
+      const int cut = overlap_rev ? ((split / 2) & ~31) : split;   // [0, cut) beside the forward exchange
       rc = shp_compute_range(sp, a->nlocal, nghost, a->x, a->quat, a->type, a->shtype, 1, ef, ef, a->f, a->torque,
-                             ef ? p->ev_dev : nullptr, st, 0, split, kPartPre);
+                             ef ? p->ev_dev : nullptr, st, 0, cut, kPartPre);
       if (!rc && hipStreamWaitEvent(st, h->ev_ghosts, 0) != hipSuccess) {
         h->err = "hipStreamWaitEvent failed (halo_overlap)";
         rc = SHPAIR_EHIP;
@@ -1076,15 +1087,41 @@ int shhalo_run_device(shhalo_ctx* h, shhalo_arrays* a, const shhalo_run_params* 
       }
       if (!rc)
         rc = shp_compute_range(sp, a->nlocal, nghost, a->x, a->quat, a->type, a->shtype, 1, ef, ef, a->f, a->torque,
-                               ef ? p->ev_dev : nullptr, st, split, sp->npairs, kPartPost);
+                               ef ? p->ev_dev : nullptr, st, split, sp->npairs, overlap_rev ? 0 : kPartPost);
+      if (!rc && overlap_rev) {
+        // every contribution to a ghost row is in: the reverse exchange starts on the second stream ...
+        if (hipEventRecord(h->ev_bdone, st) != hipSuccess || hipStreamWaitEvent(h->st2, h->ev_bdone, 0) != hipSuccess) {
+          h->err = "hipEventRecord / hipStreamWaitEvent failed (halo_overlap 2)";
+          rc = SHPAIR_EHIP;
+          break;
+        }
+        rc = shhalo_reverse_device(h, a->f, a->torque, h->st2);
+        if (rc) break;
+        if (hipEventRecord(h->ev_rev, h->st2) != hipSuccess) {
+          h->err = "hipEventRecord failed (halo_overlap 2)";
+          rc = SHPAIR_EHIP;
+          break;
+        }
+        // ... beside the second half of the owned-only slots
+        rc = shp_compute_range(sp, a->nlocal, nghost, a->x, a->quat, a->type, a->shtype, 1, ef, ef, a->f, a->torque,
+                               ef ? p->ev_dev : nullptr, st, cut, split, kPartPost);
+        if (!rc && hipStreamWaitEvent(st, h->ev_rev, 0) != hipSuccess) {
+          h->err = "hipStreamWaitEvent failed (halo_overlap 2)";
+          rc = SHPAIR_EHIP;
+          break;
+        }
+        reverse_done = true;
+      }
     } else {
       rc = shpair_compute_device(sp, a->nlocal, nghost, a->x, a->quat, a->type, a->shtype, 1, ef, ef, a->f, a->torque,
                                  ef ? p->ev_dev : nullptr, st);
     }
     if (step < ntimed) (void)hipEventRecord(ev[2 * step + 1], st);
     if (rc) { h->err = sp->err; break; }
-    rc = shhalo_reverse_device(h, a->f, a->torque, st);
-    if (rc) break;
+    if (!reverse_done) {
+      rc = shhalo_reverse_device(h, a->f, a->torque, st);
+      if (rc) break;
+    }
     if (body) {
       rc = shstep_post_force_device(sp, a->nlocal, p->gravity, p->gamma_t, p->gamma_r, a->v, a->quat, a->angmom, a->shtype, a->mask,
                                     p->groupbit, a->f, a->torque, st);

@@ -1110,7 +1110,7 @@ int shpair_set_option(shpair_ctx* c, const char* key, int value)
     c->rev_dirty = true;
   }
   else if (!strcmp(key, "waves_per_block")) c->opt_wpb = value;
-  else if (!strcmp(key, "halo_overlap")) c->opt_overlap = value ? 1 : 0;
+  else if (!strcmp(key, "halo_overlap")) c->opt_overlap = value <= 0 ? 0 : (value >= 2 ? 2 : 1);
   else CTX_FAIL(c, SHPAIR_EINVAL, "unknown option '%s'", key);
   return SHPAIR_OK;
 }

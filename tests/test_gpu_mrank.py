@@ -141,12 +141,13 @@ def test_static_forces_and_plan_match_single_domain(grid, periodic):
         hub.close()
 
 
-@pytest.mark.parametrize("overlap", [0, 1])
+@pytest.mark.parametrize("overlap", [0, 1, 2])
 @pytest.mark.parametrize("grid,periodic", [((2, 1, 1), (1, 1, 1)), ((2, 2, 1), (1, 1, 0)), ((1, 1, 1), (1, 1, 1)), ((2, 2, 2), (1, 1, 0))])
 def test_dynamic_run_matches_single_rank(grid, periodic, overlap):
     """Atoms move fast enough to change owner; the C++ loop of every rank (exchange, borders, rebuilds, forward,
     reverse) must reproduce the single-rank loop's trajectory.  overlap = 1: option "halo_overlap" — the list partitioned
-    into owned-only and ghost slots, the forward exchange on a stream of its own beside the owned-only pair kernels."""
+    into owned-only and ghost slots, the forward exchange on a stream of its own beside the owned-only pair kernels;
+    overlap = 2: the reverse exchange beside the second half of the owned-only slots as well."""
     import torch
     from shpair import shapes, mrank
     from shpair.run import DeviceRun
