@@ -183,7 +183,7 @@ typedef struct shpair_kernel_info {
   int vgprs, scratch_bytes;
   int lds_bytes_per_wave, ring_rows;
   int waves_per_simd_vgpr;    /* limit from registers */
-  int waves_per_cu_lds;       /* limit from LDS */
+  int waves_per_cu_lds;       /* limit from LDS (allocated in granules of 1 280 bytes) */
   int waves_per_cu;           /* min(4 x waves_per_simd_vgpr, waves_per_cu_lds) */
   int family;                 /* 0: particle j evaluated in its body frame (Horner, scalar-fed coefficients);
                                  1: from per-azimuth polynomials in the pair's common frame (option "jpoly") */

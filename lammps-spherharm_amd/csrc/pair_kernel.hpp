@@ -156,6 +156,12 @@ constexpr int kFrame = 40;
 constexpr int kRedStride = 72;    // epilogue reduction: doubles between the 64-entry rows of the seven sums (64 + 8: rows
                                   // four apart share banks, not all seven)
 constexpr int kRedDoubles = 7 * kRedStride + 56 + 7 + 6;   // scratch of the epilogue behind the frame
+// The per-azimuth kernels keep only the slots they read from LDS — E1 ... WSC (12..29) and RHO, KN, EXPO, IJ (36..39):
+// the Euler angles are the rotation kernel's, the pair's scalars arrive as scalar loads — packed to the front: 22
+// doubles instead of 40.  LDS is allocated in granules of 1 280 B (profiles/r04_ac_lds_granule.txt); the 128 B put
+// L = 7 / n_q = 16 and L = 10 / n_q = 16 a granule lower (18 instead of 16, 14 instead of 12 waves per CU).
+constexpr int kFrameJ = 24;
+__host__ __device__ constexpr int frj(const int slot) { return slot >= 36 ? slot - 18 : slot - 12; }
 constexpr int kRecStride = 40;   // doubles per pair record: the first kRecUsed are copied into the frame
 constexpr int kRecUsed = 40;
 // per-pair scalars live in the frame too: as VALU results they would sit in VGPR pairs for
@@ -222,7 +228,7 @@ __host__ __device__ inline WaveLdsLayout wave_lds_layout(const int L, const int 
   const bool one_group = nqj > 0 && rows >= nqj;
   w.v0 = (alias || nqj > 0) ? kFrame : w.trig + 6 * (L + 1);
   w.v1 = w.v0 + ns;
-  w.ring = (nqj > 0) ? (one_group ? kFrame : kFrame + npi) : (alias ? w.v0 + ns : w.v1 + ns);
+  w.ring = (nqj > 0) ? (one_group ? kFrameJ : kFrameJ + npi) : (alias ? w.v0 + ns : w.v1 + ns);
   w.ring += w.ring & 1;  // 16-byte aligned rows for ds_read_b128
   // the first stage of particle j's polynomials ((2L+4)(L+1) doubles, +2: a read one past a row's end) lies over the ring rows, which are built later
   int ringsz = 4 * rows * (L + 1);
@@ -240,7 +246,7 @@ __host__ __device__ inline WaveLdsLayout wave_lds_layout(const int L, const int 
     // frame (ring groups: the later builds park two sums in the empty queue).  The prefetched Gauss nodes of the first
     // pass wait at the end of the ring rows where the first pass (entries 0..63 = doubles 0..255) does not write and
     // particle j's first stage does not reach, else behind the polynomials / the parked sums.
-    w.pi = one_group ? w.qri : kFrame;
+    w.pi = one_group ? w.qri : kFrameJ;
     w.park = w.qri;
     const int pjsz = jpoly_rows(L) * (L + 1) + 2;
     if (ringsz - 64 >= 256 && ringsz - 64 >= pjsz) w.stash = w.ring + ringsz - 64;
@@ -265,8 +271,11 @@ __host__ __device__ inline WaveLdsLayout wave_lds_layout(const int L, const int 
   }
   w.bytes = 8 * (w.gh + ghsz);
   // the epilogue's reduction scratch lies behind the frame, over everything that is dead by then
-  if (w.bytes < 8 * (kFrame + kRedDoubles)) w.bytes = 8 * (kFrame + kRedDoubles);
+  if (w.bytes < 8 * ((nqj > 0 ? kFrameJ : kFrame) + kRedDoubles)) w.bytes = 8 * ((nqj > 0 ? kFrameJ : kFrame) + kRedDoubles);
   w.bytes = (w.bytes + 15) & ~15;
+#ifdef SHP_LDS_PAD   // experiment builds only (make variant): what do fewer resident waves cost?
+  if (nqj > 0) w.bytes += SHP_LDS_PAD;
+#endif
   w.qstride = 0;
   return w;
 }
@@ -276,7 +285,7 @@ __host__ __device__ inline WaveLdsLayout pair_lds_layout2(const int L, const int
   WaveLdsLayout w;
   const int ns = (L + 1) * (L + 1);
   w.trig = w.v1 = w.qw = w.coef = 0;   // not used by the JPT kernels
-  w.pi = kFrame;                        // particle i's first-stage polynomials: they stay for the ring groups
+  w.pi = kFrameJ;                       // particle i's first-stage polynomials: they stay for the ring groups
   w.ring = w.pi + jpoly_pi_doubles(L);
   w.ring += w.ring & 1;
   int ringsz = 4 * rows * (L + 1);
@@ -293,7 +302,7 @@ __host__ __device__ inline WaveLdsLayout pair_lds_layout2(const int L, const int
   // the epilogue's scratch (one block per wave) lies over everything behind the frame, the queues included: wave 0's
   // from the frame on, wave 1's at the end of the pair's LDS
   const int qs = 2 * kQueue + kQueue / 4;
-  if (shared_end + 2 * qs < kFrame + 2 * kRedPerWave) shared_end = kFrame + 2 * kRedPerWave - 2 * qs;
+  if (shared_end + 2 * qs < kFrameJ + 2 * kRedPerWave) shared_end = kFrameJ + 2 * kRedPerWave - 2 * qs;
   shared_end += shared_end & 1;
   w.qri = shared_end;
   w.qrj = w.qri + kQueue;
@@ -1297,6 +1306,8 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
   // run-time-order kernel keeps the body-frame evaluation sh_eval_rt
   constexpr bool JP = JPT && (L >= 0) && !WEIGHTED;
   constexpr int LJ = JP ? L : 0;
+  constexpr int FRAME = JP ? kFrameJ : kFrame;   // doubles of the frame in LDS; FRM(slot): where a record slot sits in it
+#define FRM(slot) (JP ? frj(slot) : (slot))
   WaveLdsLayout W = (WPP == 2) ? pair_lds_layout2(LL, P.ring_rows, nq) : wave_lds_layout(LL, P.ring_rows, WEIGHTED, JP ? nq : 0);
   if constexpr (WPP == 2) {   // this wave's queue
     W.qri += half * W.qstride;
@@ -1382,7 +1393,11 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
     s_tiny = rs[FR_JTINY];
   }
   const bool centre_in_bj = rid[3] != 0;  // rho < Rj
-  if (tid < kRecUsed) lw[tid] = recv;
+  if constexpr (JP) {
+    if ((tid >= 12 && tid < 30) || (tid >= 36 && tid < kRecUsed)) lw[frj(tid)] = recv;
+  } else {
+    if (tid < kRecUsed) lw[tid] = recv;
+  }
   if constexpr (JP && L <= 8 && WPP == 1) lw[W.stash + lane] = glt_first;
   if constexpr (JP) {
     // both rotated vectors, side by side in the (not yet built) rows of particle j's table: the first stage reads them
@@ -1419,7 +1434,7 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
   // SPEC §2.6: centre of i inside j (only possible when rho < Rj)
   bool centre_inside = false;
   if (NEEDV && centre_in_bj) {
-    const double rho = fr[FR_RHO];
+    const double rho = fr[FRM(FR_RHO)];
     double rj;
     if constexpr (JP) {
       // x_i seen from x_j lies on the axis, opposite to c: mu = -1, sigma = 0, any azimuth
@@ -1451,7 +1466,7 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
   // 3 parked two sums in the queue for every build: 128 doubles of LDS beside the polynomials the build reads)
   if constexpr (JP) {
     const int kend0 = (P.ring_rows < nq) ? P.ring_rows : nq;
-    cap_frame_rings_poly<LJ, WPP>(P, SHP_LDS(), W, lane, tid, 0, kend0, fr[FR_HW], fr[FR_HM], L <= 8 && WPP == 1);
+    cap_frame_rings_poly<LJ, WPP>(P, SHP_LDS(), W, lane, tid, 0, kend0, fr[FRM(FR_HW)], fr[FRM(FR_HM)], L <= 8 && WPP == 1);
   }
   bool first_group = true;   // wave-uniform
   double aV = 0.0, aS0 = 0.0, aS1 = 0.0, aS2 = 0.0, aT0 = 0.0, aT1 = 0.0, aT2 = 0.0;
@@ -1481,7 +1496,7 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
         double* park = lr + W.park + lane;
         park[0] = aT2; park[64] = NEEDV ? aV : aS0;
         if constexpr (WPP == 2) __syncthreads();   // the other wave has left the node loops of the previous group: its rows may go
-        cap_frame_rings_poly<LJ, WPP>(P, lr, W, lane, tid, k0, kend - k0, lr[FR_HW], lr[FR_HM], false);
+        cap_frame_rings_poly<LJ, WPP>(P, lr, W, lane, tid, k0, kend - k0, lr[FRM(FR_HW)], lr[FRM(FR_HM)], false);
         park = SHP_LDS() + W.park + lane;
         aT2 = park[0];
         if (NEEDV) aV = park[64]; else aS0 = park[64];
@@ -1787,7 +1802,7 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
     double ri = fr[W.qri + e];
     int k = (int)(umul_sel<JP>((unsigned)p, magic) >> 24);
     int l = p - mul_sel<JP>(k, npsi);
-    double omi = active ? fr[FR_WSC] * (JP ? fr[W.glw + mul_sel<JP>(k, jpoly_row(LJ))] : P.glw[k]) : 0.0;   // the node's plain weight
+    double omi = active ? fr[FRM(FR_WSC)] * (JP ? fr[W.glw + mul_sel<JP>(k, jpoly_row(LJ))] : P.glw[k]) : 0.0;   // the node's plain weight
     bool outside = false;    // WEIGHTED: a node with g~ >= 0 has no ray segment inside j
     if (WEIGHTED) outside = !(fr[W.qw + e] > 0.0);
     double c1 = P.cpsi[l], s1 = P.spsi[l];
@@ -1979,7 +1994,7 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
         p = (int)launder_u32((unsigned)p);
         k = (int)(umul_sel<JP>((unsigned)p, magic) >> 24);
         l = p - mul_sel<JP>(k, npsi);
-        omi = active ? fr[FR_WSC] * fr[W.glw + mul_sel<JP>(k, jpoly_row(LJ))] : 0.0;
+        omi = active ? fr[FRM(FR_WSC)] * fr[W.glw + mul_sel<JP>(k, jpoly_row(LJ))] : 0.0;
         const double* row = fr + W.ring + (k - k0) * rowlen;
         mu = row[1];
         sig = row[3];
@@ -2052,7 +2067,7 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
   if constexpr (WPP == 2) __syncthreads();   // both waves are through their node loops: the shared tables are dead
   {
     // [7][kRedStride] partial sums | [56] | [7] totals | [6] force components; two waves per pair: one such block each
-    double* red = SHP_LDS() + ((WPP == 2 && half) ? (int)(P.wave_lds_bytes >> 3) - kRedPerWave : kFrame);
+    double* red = SHP_LDS() + ((WPP == 2 && half) ? (int)(P.wave_lds_bytes >> 3) - kRedPerWave : FRAME);
     red[0 * kRedStride + lane] = aS0; red[1 * kRedStride + lane] = aS1; red[2 * kRedStride + lane] = aS2;
     red[3 * kRedStride + lane] = aT0; red[4 * kRedStride + lane] = aT1; red[5 * kRedStride + lane] = aT2;
     red[6 * kRedStride + lane] = NEEDV ? aV : 0.0;
@@ -2079,13 +2094,13 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
   if (lane >= 6) return;
   fr = SHP_LDS();
 #undef SHP_LDS
-  const double* tot = fr + kFrame + 7 * kRedStride + 56;
+  const double* tot = fr + FRAME + 7 * kRedStride + 56;
   double* fcomp = (double*)tot + 7;
   const int comp = (lane >= 3) ? lane - 3 : lane;   // 0..2
   const bool is_t = lane >= 3;                        // lanes 3-5: torque components
   // rotate the cap-frame integrals to the space frame (columns e1, e2, c): this lane's component of S_n or T_n
   const double a0 = tot[is_t ? 3 : 0], a1 = tot[is_t ? 4 : 1], a2 = tot[is_t ? 5 : 2];
-  const double val = fr[FR_E1 + comp] * a0 + fr[FR_E2 + comp] * a1 + fr[FR_C + comp] * a2;
+  const double val = fr[FRM(FR_E1) + comp] * a0 + fr[FRM(FR_E2) + comp] * a1 + fr[FRM(FR_C) + comp] * a2;
   const double aVt = tot[6];
 
   LateParams& E = *late_params();   // the first explicit argument starts the kernarg segment
@@ -2103,9 +2118,9 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
 
   // SPEC §2.7 force law
   // operands looked up (and the types range-checked) by the set-up kernel
-  const int* ij = (const int*)(fr + FR_IJ);
+  const int* ij = (const int*)(fr + FRM(FR_IJ));
   const int i = ij[0], j = ij[1];
-  const double knij = fr[FR_KN], mij = fr[FR_EXPO];
+  const double knij = fr[FRM(FR_KN)], mij = fr[FRM(FR_EXPO)];
   const double vm1 = (mij == 1.0) ? 1.0 : pow_quarter(aVt, mij - 1.0);  // V^(m-1)
   const double pn = knij * mij * vm1;
   const double Fm = -pn * val;   // lanes 0-2: F_i; lanes 3-5: tau_i
@@ -2119,7 +2134,7 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
     // F_j = -F_i ;  tau_j = -tau_i - d x F_j : component c needs d and F_j at c + 1, c + 2
     const int c1 = (comp == 2) ? 0 : comp + 1, c2 = (comp == 0) ? 2 : comp - 1;
     double vj = -Fm;
-    if (is_t) vj -= fr[FR_D + c1] * (-fcomp[c2]) - fr[FR_D + c2] * (-fcomp[c1]);
+    if (is_t) vj -= fr[FRM(FR_D) + c1] * (-fcomp[c2]) - fr[FRM(FR_D) + c2] * (-fcomp[c1]);
     if (det) det[12 * (size_t)w + 6 + lane] = vj;
     else atomicAdd((is_t ? E.torque : E.f) + 3 * (size_t)j + comp, vj);
   }
@@ -2134,7 +2149,7 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
       // ev_tally_xyz with del = x_i - x_j = -d and the force on i: xx yy zz xy xz yz = d_a F_b, (a, b) per lane
       const int a = (lane < 3) ? lane : ((lane == 5) ? 1 : 0);
       const int b = (lane < 3) ? lane : ((lane == 3) ? 1 : 2);
-      row[1 + lane] = share * (-fr[FR_D + a]) * fcomp[b];
+      row[1 + lane] = share * (-fr[FRM(FR_D) + a]) * fcomp[b];
     }
     if (E.eflag && lane == 0) row[0] = share * knij * (vm1 * aVt);
   }
@@ -2142,7 +2157,7 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
   // the per-atom tallies (only when asked for) stay with lane 0
   if (E.eatom || E.vatom) {
     const double F0 = fcomp[0], F1 = fcomp[1], F2 = fcomp[2];
-    const double d0 = fr[FR_D], d1 = fr[FR_D + 1], d2 = fr[FR_D + 2];
+    const double d0 = fr[FRM(FR_D)], d1 = fr[FRM(FR_D) + 1], d2 = fr[FRM(FR_D) + 2];
     // ev_tally_xyz per-atom part: half of the pair's energy / virial to each atom this rank tallies for
     const bool owni = E.newton_pair || i < E.nlocal;
     if (E.eatom) {

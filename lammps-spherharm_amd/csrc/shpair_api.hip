@@ -1022,7 +1022,10 @@ int shpair_get_kernel_info(shpair_ctx* c, shpair_kernel_info* out)
   const int vg = ((a.numRegs + 7) / 8) * 8;
   int w = vg > 0 ? 512 / vg : 8;
   if (w > 8) w = 8;
-  const int by_lds = wpp * ((160 * 1024) / c->last_lds_bytes);  // workgroups (= pairs) per CU x waves per pair
+  // LDS is allocated in granules of 1 280 B (160 KB / 128; measured: +448 B on 8 512 B is free, +512 B costs two waves,
+  // profiles/r04_ac_lds_granule.txt)
+  const int lds_alloc = ((c->last_lds_bytes + 1279) / 1280) * 1280;
+  const int by_lds = wpp * ((160 * 1024) / lds_alloc);  // workgroups (= pairs) per CU x waves per pair
   out->waves_per_simd_vgpr = w;
   out->waves_per_cu_lds = by_lds;
   const int cu = (4 * w < by_lds) ? 4 * w : by_lds;
