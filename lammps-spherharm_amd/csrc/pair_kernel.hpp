@@ -184,6 +184,7 @@ struct WaveLdsLayout {
   int qw;                                        // weighted rule only: the queued nodes' weights
   int coef;                                      // end of the queue region (the table of particle j starts here)
   int pj, gh;                                    // particle j's polynomials: first-stage scratch, per-azimuth table
+  int tr;                                        // even L: (cos, sin)(psi_l), l < n_q, 2 doubles each, behind the table's rows
   int pi, v0i;                                   // JPT kernels: particle i's first-stage polynomials PJ^i (they stay for every ring
                                                  // group); particle i's rotated vector beside particle j's (both in the rows of
                                                  // the per-azimuth table, which is built after the first stage has read them)
@@ -197,8 +198,12 @@ struct WaveLdsLayout {
 // RING with the row's index (n_q rows, n_q rings: the table doubles as the weight table), then padding to 16-byte
 // rows whose stride is 2 mod 4 doubles: sixteen lanes reading sixteen rows with ds_read_b128 then spread over all
 // banks (a 128-byte stride, 2L + 4 = 16 at L = 6, puts every row on the same banks: the kernel ran 3x slower).
-__host__ __device__ constexpr int jpoly_row(const int L) { return ((2 * L + 4) % 4 == 2) ? 2 * L + 4 : 2 * L + 6; }
-__host__ __device__ constexpr int jpoly_trig(const int L) { return 2 * L + 2; }   // offset of cos(psi_l) in a row; sin follows (one 16-byte pair)
+// Round 4: for EVEN L the 2L + 1 coefficients and the weight are 2L + 2 doubles — already 2 mod 4 — and (cos, sin)(psi_l)
+// live in an array of their own behind the rows (jpoly_trig_sep; W.tr): 4 doubles per row less than the padded
+// 2L + 6.  For odd L the row of 2L + 4 doubles holds all of it, as before.
+__host__ __device__ constexpr bool jpoly_trig_sep(const int L) { return (L % 2) == 0; }
+__host__ __device__ constexpr int jpoly_row(const int L) { return jpoly_trig_sep(L) ? 2 * L + 2 : 2 * L + 4; }
+__host__ __device__ constexpr int jpoly_trig(const int L) { return 2 * L + 2; }   // odd L: offset of cos(psi_l) in a row; sin follows (one 16-byte pair)
 __host__ __device__ constexpr int jpoly_glw(const int L) { return 2 * L + 1; }    // offset of the weight of ring `row index` (the odd slot behind the 2L + 1 coefficients)
 // Rows of the first-stage table PJ: (order m, part) for m = 0..L+1 — the order L + 1 is empty (zeros), see jpoly_build.
 __host__ __device__ constexpr int jpoly_rows(const int L) { return 2 * L + 4; }
@@ -264,7 +269,9 @@ __host__ __device__ inline WaveLdsLayout wave_lds_layout(const int L, const int 
   w.gh = w.coef;   // per-azimuth polynomials of particle j: nqj rows, resident for the whole pair
   w.glw = w.gh + jpoly_glw(L);   // weight of ring k at glw + k * jpoly_row(L)
   int ghsz = nqj * jpoly_row(L);
+  w.tr = w.gh + ghsz;   // (even L; 16-byte aligned: rows are an even number of doubles)
   if (nqj > 0) {
+    if (jpoly_trig_sep(L)) ghsz += 2 * nqj;
     w.v0 = w.gh;         // particle j's rotated vector, then particle i's behind it: read by the first stage only
     w.v0i = w.gh + ns;
     if (ghsz < 2 * ns) ghsz = 2 * ns;
@@ -297,6 +304,8 @@ __host__ __device__ inline WaveLdsLayout pair_lds_layout2(const int L, const int
   w.v0 = w.gh;        // both rotated vectors wait for the first stage in the rows of particle j's table
   w.v0i = w.gh + ns;
   int ghsz = nq * jpoly_row(L);
+  w.tr = w.gh + ghsz;
+  if (jpoly_trig_sep(L)) ghsz += 2 * nq;
   if (ghsz < 2 * ns) ghsz = 2 * ns;
   int shared_end = w.gh + ghsz;
   // the epilogue's scratch (one block per wave) lies over everything behind the frame, the queues included: wave 0's
@@ -1175,8 +1184,9 @@ __device__ __forceinline__ void jpoly_build(const PairParams& P, double* __restr
       }
     }
     if (lok && kq == 0 && par == 1) {   // the row's own cos(psi_l), sin(psi_l): the first order of the odd lanes
-      gh[l * RS + jpoly_trig(L)] = cs[0];
-      gh[l * RS + jpoly_trig(L) + 1] = sn[0];
+      double* tw = jpoly_trig_sep(L) ? lw + W.tr + 2 * l : gh + l * RS + jpoly_trig(L);
+      tw[0] = cs[0];
+      tw[1] = sn[0];
     }
     // column of the power k in a row: G: L - k; H: 2L - k  (descending powers, Horner order)
     double* out = gh + (lok ? l : 0) * RS + (par ? 2 * L : L) - kq;
@@ -1657,7 +1667,7 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
       const double* gr = fr + W.gh + mul_sel<JP>(l, jpoly_row(LJ));
       double re = r01[0], ro = 0.0;
       if constexpr (LJ >= 1) {
-        const v2d cs1 = lds2(gr + jpoly_trig(LJ));
+        const v2d cs1 = lds2(jpoly_trig_sep(LJ) ? fr + W.tr + 2 * l : gr + jpoly_trig(LJ));
         const double c1 = cs1[0], s1 = cs1[1];
         double cm = c1, sm = s1, cp = 1.0, sp = 0.0;   // three-term recurrence: one v_fma_f64 per cos / sin (ring_grad_rec)
         const double tc = c1 + c1;
@@ -2024,7 +2034,8 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
     double r2, rmu, rpsi;
     if constexpr (JP) {
       const double sg = (l >= nq) ? -1.0 : 1.0;
-      const double* tg = fr + W.gh + mul_sel<JP>(l >= nq ? l - nq : l, jpoly_row(LJ)) + jpoly_trig(LJ);
+      const int lrow = l >= nq ? l - nq : l;
+      const double* tg = jpoly_trig_sep(LJ) ? fr + W.tr + 2 * lrow : fr + W.gh + mul_sel<JP>(lrow, jpoly_row(LJ)) + jpoly_trig(LJ);
       if constexpr (LJ >= 1) {
         const v2d cs1 = lds2(tg);
         c1 = sg * cs1[0];
