@@ -262,6 +262,10 @@ def main_single(args):
         print("bench.py: no GPU visible; the HIP path has no CPU fallback", file=sys.stderr)
         sys.exit(3)
     scale_ref = scale_ref_leg(args) if args.scale_ref else None   # a fresh child process, before this one's first GPU call
+    if scale_ref is not None:
+        # the child has just released ~2 GB of HBM: the driver frees it in the background; twice in ~40 builder runs a
+        # bench pass that started in the first second after another process's exit ran 25 % (once 20x) slow
+        time.sleep(1.5)
     if not torch.cuda.is_available():
         print("bench.py: no GPU visible; the HIP path has no CPU fallback", file=sys.stderr)
         sys.exit(3)
