@@ -152,7 +152,7 @@ def test_dynamic_run_matches_single_rank(grid, periodic, overlap):
     from shpair import shapes, mrank
     from shpair.run import DeviceRun
     world = int(np.prod(grid))
-    lmax, nq, skin, dt, nsteps = 4, 8, 0.2, 2e-3, 120
+    lmax, nq, skin, dt, nsteps = 4, 8, 0.2, 2e-3, int(os.environ.get("SHPAIR_SOAK_STEPS", "120"))   # (a longer soak: the env variable)
     shp = [shapes.random_shape(lmax, 400 + s, amp=0.2) for s in range(2)]
     x, quat, sht, tag, lo, hi, rng = _bed(1500 if world < 8 else 4000, periodic)
     n = x.shape[0]
