@@ -168,7 +168,9 @@ int shpair_compute_device(shpair_ctx *ctx, int nlocal, int nghost, const double 
  * slots run beside the forward exchange, the ghost slots follow it, the other half runs beside the reverse exchange,
  * whose unpack uses the same FP64 atomics (atomic accumulation only: with "deterministic" 2 behaves as 1); 0: the
  * exchanges and the pair kernels follow each other on the caller's stream; same forces, another order of the per-atom
- * sums).
+ * sums), "waves_per_block" (tuning: waves per workgroup of the one-wave contact kernels, default 1), "queue_slack"
+ * (diagnostic, default 1: the node queue of the "jpoly" kernels takes what the wave's LDS layout leaves of its last
+ * 1 280-byte allocation granule, up to 192 entries; 0: 128 entries).
  * Memory: the contact path keeps per-slot scratch in HBM — a 320-byte record and, for the "jpoly" family, two rotated
  * coefficient vectors of (lmax+1)^2 doubles each (rounded up to 8 from lmax = 9 on): 1.1 KB per list slot at lmax = 6
  * (0.7 GB at 100k particles / 580k pairs, ~7 GB at 1 M), 3.0 KB at lmax = 12 (1.7 GB at 100k); +96 bytes per slot in

@@ -88,6 +88,7 @@ struct PairParams {
   const int* rec_i;
   int wave_lds_bytes;    // dynamic LDS per wave (wave_lds_layout)
   int ring_rows;         // quadrature rings whose tables are resident at a time (<= nq)
+  int qcap;              // per-azimuth kernels: entries of a wave's node queue (queue_capacity)
   int waves_per_block;
   // quadrature tables
   const double* glt;    // nq Gauss-Legendre nodes on [-1,1]
@@ -139,6 +140,9 @@ constexpr int kPairErrCoincident = 4;   // two centres coincide (rho = 0) or the
 #endif
 
 // docs/SPEC.md §2.6: residual below which the inverse-quadratic extrapolation is accepted
+#ifndef SHP_TRIGG
+#define SHP_TRIGG(L) 0
+#endif
 #ifndef SHP_TAU3
 #define SHP_TAU3 1e-4
 #endif
@@ -192,7 +196,9 @@ struct WaveLdsLayout {
   int park;                                      // JPT kernels with ring groups: 2 x 64 sums parked around the builds of the later groups (in the empty queue)
   int stash;                                     // JPT kernels: 64 prefetched Gauss nodes for the first pass of the first ring build
   int qstride;                                   // two waves per pair: doubles between the waves' private queue regions
+  int qcap;                                      // JPT kernels: entries of the node queue (kQueue ... kQueue + 64, see queue_capacity)
 };
+constexpr int kLdsGranule = 1280;                // bytes: a workgroup's LDS is allocated in 1/128 of the CU's 160 KB
 // Row of the per-azimuth table: G_l (L + 1 coefficients, descending powers), H_l (L), cos(psi_l), sin(psi_l) (the
 // higher orders follow by the angle-addition recurrence where r_i is evaluated), the Gauss-Legendre weight of the
 // RING with the row's index (n_q rows, n_q rings: the table doubles as the weight table), then padding to 16-byte
@@ -210,7 +216,7 @@ __host__ __device__ constexpr int jpoly_rows(const int L) { return 2 * L + 4; }
 // ... of which particle i needs the real orders only: PJ^i, (2L + 2) polynomials of L + 1 coefficients (an even count)
 __host__ __device__ constexpr int jpoly_pi_doubles(const int L) { return (2 * L + 2) * (L + 1); }
 __host__ __device__ inline WaveLdsLayout wave_lds_layout(const int L, const int rows, const bool weighted = false,
-                                                         const int nqj = 0)
+                                                         const int nqj = 0, const int qcap = kQueue)
 {
   WaveLdsLayout w;
   const int ns = (L + 1) * (L + 1);
@@ -239,12 +245,13 @@ __host__ __device__ inline WaveLdsLayout wave_lds_layout(const int L, const int 
   int ringsz = 4 * rows * (L + 1);
   if (nqj > 0 && rows > 0 && ringsz < jpoly_rows(L) * (L + 1) + 2) ringsz = jpoly_rows(L) * (L + 1) + 2;
   w.pj = w.ring;
+  w.qcap = qcap;   // (a multiple of 4: the 16-bit node indices end on an 8-byte boundary)
   w.qri = w.ring + ringsz;
-  w.qrj = w.qri + kQueue;
-  w.qp = w.qrj + kQueue;
-  w.qw = w.qp + kQueue / 4;
+  w.qrj = w.qri + qcap;
+  w.qp = w.qrj + qcap;
+  w.qw = w.qp + qcap / 4;
   w.park = w.qri;
-  w.coef = w.qw + (weighted ? kQueue : 0);
+  w.coef = w.qw + (weighted ? qcap : 0);
   w.stash = w.qri + 128;
   if (nqj > 0) {
     // PJ^i over the queue (one ring group: a single build, before any sum exists — nothing is parked) or behind the
@@ -287,7 +294,7 @@ __host__ __device__ inline WaveLdsLayout wave_lds_layout(const int L, const int 
   return w;
 }
 constexpr int kRedPerWave = (7 * kRedStride + 56 + 7 + 6 + 1) & ~1;   // epilogue scratch of one wave, even
-__host__ __device__ inline WaveLdsLayout pair_lds_layout2(const int L, const int rows, const int nq)
+__host__ __device__ inline WaveLdsLayout pair_lds_layout2(const int L, const int rows, const int nq, const int qcap)
 {
   WaveLdsLayout w;
   const int ns = (L + 1) * (L + 1);
@@ -310,15 +317,16 @@ __host__ __device__ inline WaveLdsLayout pair_lds_layout2(const int L, const int
   int shared_end = w.gh + ghsz;
   // the epilogue's scratch (one block per wave) lies over everything behind the frame, the queues included: wave 0's
   // from the frame on, wave 1's at the end of the pair's LDS
-  const int qs = 2 * kQueue + kQueue / 4;
+  const int qs = 2 * qcap + qcap / 4;
+  w.qcap = qcap;
   if (shared_end + 2 * qs < kFrameJ + 2 * kRedPerWave) shared_end = kFrameJ + 2 * kRedPerWave - 2 * qs;
   shared_end += shared_end & 1;
   w.qri = shared_end;
-  w.qrj = w.qri + kQueue;
-  w.qp = w.qrj + kQueue;
+  w.qrj = w.qri + qcap;
+  w.qp = w.qrj + qcap;
   w.park = w.qri;                          // 2 x 64 parked sums while the ring rows of a later group are built (the queue is empty then)
   w.stash = w.qri + 128;                   // (not used: two-wave kernels request their Gauss nodes where they use them)
-  w.qstride = 2 * kQueue + kQueue / 4;     // 288
+  w.qstride = qs;                          // 288 at 128 entries
   w.bytes = (8 * (shared_end + 2 * w.qstride) + 15) & ~15;
   return w;
 }
@@ -339,7 +347,19 @@ __device__ __forceinline__ v2d lds2(const double* p) { return *(const v2d*)__bui
 // CU, VALU 66 % busy, profiles/r03_e_L12_pmc.txt), 17.3 KB per two-wave pair (18 waves' worth; the registers allow 16).
 //   frame | PJ^i (particle i's first-stage polynomials; stay for the ring groups) | ring rows (first: first stage of j's table) | j's table |
 //   [epilogue scratch of both waves over everything behind the frame] | queue of wave 0 | queue of wave 1
-__host__ __device__ inline WaveLdsLayout pair_lds_layout2(const int L, const int rows, const int nq);
+__host__ __device__ inline WaveLdsLayout pair_lds_layout2(const int L, const int rows, const int nq, const int qcap = kQueue);
+// Entries of the node queue of the per-azimuth kernels.  A slab of node pairs brings up to 128 inside nodes to a queue
+// that holds fewer than 64: 128 entries overflow when a dense slab meets a leftover (the slab is then classified a second
+// time after a short batch: 0.74 slabs per pair at the headline, 5 % of the kernel's instructions), 191 never do.  The
+// LDS of a workgroup is allocated in granules of 1 280 bytes: the queue takes what the layout leaves of its last granule
+// (18 bytes per entry; `waves` = queues in the workgroup's LDS), at no cost in resident waves.
+__host__ __device__ inline int queue_capacity(const int bytes_at_128, const int waves)
+{
+  const int slack = (bytes_at_128 + kLdsGranule - 1) / kLdsGranule * kLdsGranule - bytes_at_128;
+  int extra = (slack / (18 * waves)) & ~3;
+  if (extra > 64) extra = 64;
+  return kQueue + extra;
+}
 
 // Integer products of the node loops through the 24-bit multiplier (v_mul_u32_u24 / v_mul_i32_i24: full rate;
 // v_mul_lo_u32 is a quarter-rate instruction).  Operands are node, ring and azimuth indices (< 2^15) and the
@@ -1258,6 +1278,42 @@ __device__ __forceinline__ void ring_grad_rec(const double* __restrict__ row, co
   }
 }
 
+// The same with (cos, sin)(m psi), m >= 2, read from the launch's table (row of the azimuth l mod n_q, global memory);
+// sg = -1 for the second half of the azimuths (psi + pi: the odd orders change sign), c1 = sg cos(psi_l), s1 likewise.
+template <int L>
+__device__ __forceinline__ void ring_grad_tab(const double* __restrict__ row, const v2d* __restrict__ tg, const double sg,
+                                              const double c1, const double s1, double& rmu, double& rpsi)
+{
+  double rme = row[2], rmo = 0.0, rpe = 0.0, rpo = 0.0;
+#pragma unroll
+  for (int m = 1; m <= L; ++m) {
+    const v2d ab = lds2(row + 4 * m), dab = lds2(row + 4 * m + 2);
+    const double A = ab[0], B = ab[1], dm = (double)m;
+    double cm = c1, sm = s1;
+    if (m > 1) {
+      const v2d cs = tg[m];
+      cm = cs[0];
+      sm = cs[1];
+    }
+    const double t = fma(B, cm, -(A * sm));
+    if (m == 1) {   // c1, s1 carry the sign already
+      rme = fma(dab[0], cm, rme);
+      rme = fma(dab[1], sm, rme);
+      rpe = t;
+    } else if (m & 1) {
+      rmo = fma(dab[0], cm, rmo);
+      rmo = fma(dab[1], sm, rmo);
+      rpo = (m == 3) ? dm * t : fma(dm, t, rpo);
+    } else {
+      rme = fma(dab[0], cm, rme);
+      rme = fma(dab[1], sm, rme);
+      rpe = fma(dm, t, rpe);
+    }
+  }
+  rmu = (L >= 3) ? fma(sg, rmo, rme) : rme;
+  rpsi = (L >= 3) ? fma(sg, rpo, rpe) : rpe;
+}
+
 // Two evaluations from one pass over the row (phase 1: the two nodes of a lane's pair share it)
 template <int L>
 __device__ __forceinline__ void jpoly_eval2(const double* __restrict__ row, const double mua, const double siga,
@@ -1318,7 +1374,8 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
   constexpr int LJ = JP ? L : 0;
   constexpr int FRAME = JP ? kFrameJ : kFrame;   // doubles of the frame in LDS; FRM(slot): where a record slot sits in it
 #define FRM(slot) (JP ? frj(slot) : (slot))
-  WaveLdsLayout W = (WPP == 2) ? pair_lds_layout2(LL, P.ring_rows, nq) : wave_lds_layout(LL, P.ring_rows, WEIGHTED, JP ? nq : 0);
+  WaveLdsLayout W = (WPP == 2) ? pair_lds_layout2(LL, P.ring_rows, nq, P.qcap)
+                               : wave_lds_layout(LL, P.ring_rows, WEIGHTED, JP ? nq : 0, JP ? P.qcap : kQueue);
   if constexpr (WPP == 2) {   // this wave's queue
     W.qri += half * W.qstride;
     W.qrj += half * W.qstride;
@@ -1641,8 +1698,8 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
     {                                                                                                                  \
       if (m_ != 0ULL) {                                                                                                \
         if (lane_of(m_)) {                                                                                             \
-          const int pos_ = (qhead + qcount + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m_ >> 32),                      \
-                                                    __builtin_amdgcn_mbcnt_lo((unsigned)m_, 0u))) & (kQueue - 1);     \
+          const int pos_ = qcount + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m_ >> 32),                               \
+                                                    __builtin_amdgcn_mbcnt_lo((unsigned)m_, 0u));                      \
           double* lq_ = SHP_LDS();                                                                                     \
           ((unsigned short*)(lq_ + W.qp))[pos_] = (unsigned short)(pn);                                                \
           lq_[W.qri + pos_] = (rin_);                                                                                  \
@@ -1669,6 +1726,25 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
       if constexpr (LJ >= 1) {
         const v2d cs1 = lds2(jpoly_trig_sep(LJ) ? fr + W.tr + 2 * l : gr + jpoly_trig(LJ));
         const double c1 = cs1[0], s1 = cs1[1];
+        if constexpr (SHP_TRIGG(LJ)) {
+        // (cos, sin)(m psi_l), m >= 2, from the launch's table in global memory (n_q rows, resident in the vector L1): no
+        // vector ALU instruction at all — the recurrence costs two v_fma_f64 per order
+        // (a scalar base and a 32-bit byte offset per lane: one vector instruction for the address)
+        const v2d* tg = (const v2d*)((const char*)P.trigj + (size_t)((unsigned)l * (unsigned)(16 * (LJ + 2))));
+#pragma unroll
+        for (int m = 1; m <= LJ; ++m) {
+          const v2d ab = lds2(row + 4 * m);
+          const double A = ab[0], B = ab[1];
+          double cm = c1, sm = s1;
+          if (m > 1) {
+            const v2d cs = tg[m];
+            cm = cs[0];
+            sm = cs[1];
+          }
+          if (m & 1) ro = fma(A, cm, fma(B, sm, ro));
+          else re = fma(A, cm, fma(B, sm, re));
+        }
+        } else {
         double cm = c1, sm = s1, cp = 1.0, sp = 0.0;   // three-term recurrence: one v_fma_f64 per cos / sin (ring_grad_rec)
         const double tc = c1 + c1;
 #pragma unroll
@@ -1684,6 +1760,7 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
             cm = c;
             sm = s;
           }
+        }
         }
       }
       const double ria = re + ro, rib = re - ro;
@@ -1720,7 +1797,12 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
       const unsigned long long ma = mca & (mza | wave_ballot(sa2 * inva < rja));
       const unsigned long long mb = mcb & (mzb | wave_ballot(sb2 * invb < rjb));
       const int pa = mul_sel<JP>(k, npsi) + l;
-      if (qcount + __builtin_popcountll(ma) + __builtin_popcountll(mb) > kQueue) break;   // wave-uniform; qcount > 0 here
+#ifdef SHP_STATS
+      if (qcount + __builtin_popcountll(ma) + __builtin_popcountll(mb) > W.qcap) {
+        if (lane == 0) atomicAdd(&P.dbg[9], 1ULL);
+      }
+#endif
+      if (qcount + __builtin_popcountll(ma) + __builtin_popcountll(mb) > W.qcap) break;   // wave-uniform; qcount > 0 here
 #ifdef SHP_STATS
       if (lane == 0) atomicAdd(&P.dbg[0], 2ULL);
       if (lane_of(mca)) atomicAdd(&P.dbg[1], 1ULL);
@@ -1801,9 +1883,11 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
     const int cnt = qcount < 64 ? qcount : 64;
     const bool active = lane < cnt;
     // (idle lanes repeat a queued node, with weight 0: the last one through a v_min in the per-azimuth kernels)
-    const int e = (qhead + (JP ? min(lane, cnt - 1) : (active ? lane : 0))) & (kQueue - 1);
-    qhead = (qhead + cnt) & (kQueue - 1);
+    // per-azimuth kernels: the batch is the LAST cnt entries (a stack: what is left stays at the front, appends and
+    // reads need no wrap, and the capacity need not be a power of two); the others keep a ring of kQueue entries
     qcount -= cnt;
+    const int e = JP ? qcount + min(lane, cnt - 1) : ((qhead + (active ? lane : 0)) & (kQueue - 1));
+    if constexpr (!JP) qhead = (qhead + cnt) & (kQueue - 1);
 #ifdef SHP_STATS
     if (lane == 0) atomicAdd(&P.dbg[4], 1ULL);
     if (active) atomicAdd(&P.dbg[7], 1ULL);
@@ -1937,6 +2021,9 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
           double res = ext, nxt = ext;
           unsigned long long mstop = wave_ballot(accept);
           if (mask_any<JP>(mact & (wave_ballot(tiny) | ~(wave_ballot(ext > lo) & wave_ballot(ext < hi))))) {
+#ifdef SHP_STATS
+            if (lane == 0) atomicAdd(&P.dbg[8], 1ULL);
+#endif
             // the general case, lane by lane with selects: the secant is the fallback of the interpolation, the
             // midpoint the fallback of both; an accepted point is clamped to the bracket
             double sec = ext, e2 = ext;
@@ -2041,7 +2128,11 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
         c1 = sg * cs1[0];
         s1 = sg * cs1[1];
       }
-      ring_grad_rec<LJ>(fr + W.ring + (k - k0) * rowlen, c1, s1, rmu, rpsi);
+      if constexpr (SHP_TRIGG(LJ))
+        ring_grad_tab<LJ>(fr + W.ring + (k - k0) * rowlen,
+                          (const v2d*)((const char*)P.trigj + (size_t)((unsigned)lrow * (unsigned)(16 * (LJ + 2)))), sg, c1, s1, rmu, rpsi);
+      else
+        ring_grad_rec<LJ>(fr + W.ring + (k - k0) * rowlen, c1, s1, rmu, rpsi);
       (void)r2;
     } else {
       ring_eval<L, true>(fr + W.ring + (k - k0) * rowlen, LL, c1, s1, P.trig + (trig_lmajor(L) ? (size_t)P.trig_stride * l : (size_t)(2 * l)), P.trig_stride, r2, rmu, rpsi);

@@ -784,7 +784,18 @@ int shp_compute_range(shpair_ctx* c, int nlocal, int nghost, const double* x, co
       if (rows < rows_min) rows = rows_min;
       if (rows > nq) rows = nq;
     }
-    const WaveLdsLayout wl = split ? pair_lds_layout2(c->lmax, rows, nq) : wave_lds_layout(c->lmax, rows, c->opt_rule != 0, nqj);
+    WaveLdsLayout wl = split ? pair_lds_layout2(c->lmax, rows, nq) : wave_lds_layout(c->lmax, rows, c->opt_rule != 0, nqj);
+    // per-azimuth kernels: the node queue grows into what is left of the last LDS granule (queue_capacity, pair_kernel.hpp)
+    int qcap = kQueue;
+    if (jpoly && !c->opt_rule && c->opt_wpb <= 1 && c->opt_queue_slack) {
+      qcap = queue_capacity(wl.bytes, split ? 2 : 1);
+      if (qcap > kQueue) {
+        const WaveLdsLayout wg = split ? pair_lds_layout2(c->lmax, rows, nq, qcap) : wave_lds_layout(c->lmax, rows, false, nqj, qcap);
+        if ((wg.bytes + kLdsGranule - 1) / kLdsGranule == (wl.bytes + kLdsGranule - 1) / kLdsGranule) wl = wg;
+        else qcap = kQueue;
+      }
+    }
+    P.qcap = qcap;
     if (wl.bytes > 160 * 1024)
       CTX_FAIL(c, SHPAIR_ELMAX, "lmax %d with nq %d needs %d bytes of LDS per pair, more than a CU has", c->lmax, nq,
                wl.bytes);
@@ -1113,6 +1124,7 @@ int shpair_set_option(shpair_ctx* c, const char* key, int value)
     c->rev_dirty = true;
   }
   else if (!strcmp(key, "waves_per_block")) c->opt_wpb = value;
+  else if (!strcmp(key, "queue_slack")) c->opt_queue_slack = value ? 1 : 0;
   else if (!strcmp(key, "halo_overlap")) c->opt_overlap = value <= 0 ? 0 : (value >= 2 ? 2 : 1);
   else CTX_FAIL(c, SHPAIR_EINVAL, "unknown option '%s'", key);
   return SHPAIR_OK;

@@ -96,6 +96,7 @@ struct shpair_ctx {
   unsigned long long* h_counters = nullptr;  // pinned 2
 
   int opt_force_volume = 0, opt_timing = 0, opt_count = 0, opt_variant = 0, opt_ring_rows = 0, opt_wpb = 0, opt_rule = 0;
+  int opt_queue_slack = 1;   // "queue_slack" (diagnostic): the node queue of the per-azimuth kernels takes the rest of its last LDS granule
   int opt_overlap = 2;   // "halo_overlap" (default 2: forward and reverse exchange beside owned-only slots; the one-GPU rehearsal of 8 ranks runs 26.2-26.6 ms per step at 0, 26.2-26.4 at 1, 25.9-26.0 at 2, profiles/r04_aa_local8.txt): device-built lists are partitioned interior / boundary and shhalo_run_device runs
                          // the interior slots while the forward exchange is in flight
   int n_interior = 0;    // slots [0, n_interior) of the installed list touch owned atoms only (device-built lists)

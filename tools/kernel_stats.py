@@ -27,7 +27,7 @@ rmax = [sp.rmax(0)]
 b = bed.make_bed(n, rmax, seed=bed.SEED0 + 2)
 il, of, jl = bed.half_neighbor_list(b["x"], b["shtype"], rmax)
 sp.set_neighbors_csr(il, of, jl)
-dbg = torch.zeros(8, dtype=torch.int64, device="cuda")
+dbg = torch.zeros(16, dtype=torch.int64, device="cuda")
 lib = capi.load_library()
 lib.shpair_debug_set_counters.argtypes = [C.c_void_p, C.c_void_p]
 lib.shpair_debug_set_counters(sp._h, dbg.data_ptr())
@@ -41,3 +41,5 @@ print(f"inside nodes: {d[3] / (npairs * Q):.3f} of all nodes; phase-2 batches pe
       f"lane fill of the batches: {d[7] / max(1, 64 * d[4]):.3f}")
 print(f"root finder: wave iterations per batch {d[5] / max(1, d[4]):.2f}; lane evals per inside node "
       f"{d[6] / max(1, d[3]):.2f}; lane fill in root loop {d[6] / max(1, 64 * d[5]):.3f}")
+print(f"root finder: general-case branch taken in {d[8] / max(1, d[5]):.3f} of the wave iterations; slabs classified twice "
+      f"(queue full): {d[9] / npairs:.3f} per pair")
