@@ -140,9 +140,6 @@ constexpr int kPairErrCoincident = 4;   // two centres coincide (rho = 0) or the
 #endif
 
 // docs/SPEC.md §2.6: residual below which the inverse-quadratic extrapolation is accepted
-#ifndef SHP_TRIGG
-#define SHP_TRIGG(L) 0
-#endif
 #ifndef SHP_TAU3
 #define SHP_TAU3 1e-4
 #endif
@@ -1278,42 +1275,6 @@ __device__ __forceinline__ void ring_grad_rec(const double* __restrict__ row, co
   }
 }
 
-// The same with (cos, sin)(m psi), m >= 2, read from the launch's table (row of the azimuth l mod n_q, global memory);
-// sg = -1 for the second half of the azimuths (psi + pi: the odd orders change sign), c1 = sg cos(psi_l), s1 likewise.
-template <int L>
-__device__ __forceinline__ void ring_grad_tab(const double* __restrict__ row, const v2d* __restrict__ tg, const double sg,
-                                              const double c1, const double s1, double& rmu, double& rpsi)
-{
-  double rme = row[2], rmo = 0.0, rpe = 0.0, rpo = 0.0;
-#pragma unroll
-  for (int m = 1; m <= L; ++m) {
-    const v2d ab = lds2(row + 4 * m), dab = lds2(row + 4 * m + 2);
-    const double A = ab[0], B = ab[1], dm = (double)m;
-    double cm = c1, sm = s1;
-    if (m > 1) {
-      const v2d cs = tg[m];
-      cm = cs[0];
-      sm = cs[1];
-    }
-    const double t = fma(B, cm, -(A * sm));
-    if (m == 1) {   // c1, s1 carry the sign already
-      rme = fma(dab[0], cm, rme);
-      rme = fma(dab[1], sm, rme);
-      rpe = t;
-    } else if (m & 1) {
-      rmo = fma(dab[0], cm, rmo);
-      rmo = fma(dab[1], sm, rmo);
-      rpo = (m == 3) ? dm * t : fma(dm, t, rpo);
-    } else {
-      rme = fma(dab[0], cm, rme);
-      rme = fma(dab[1], sm, rme);
-      rpe = fma(dm, t, rpe);
-    }
-  }
-  rmu = (L >= 3) ? fma(sg, rmo, rme) : rme;
-  rpsi = (L >= 3) ? fma(sg, rpo, rpe) : rpe;
-}
-
 // Two evaluations from one pass over the row (phase 1: the two nodes of a lane's pair share it)
 template <int L>
 __device__ __forceinline__ void jpoly_eval2(const double* __restrict__ row, const double mua, const double siga,
@@ -1690,10 +1651,13 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
     }
     } else if constexpr (JP) {
     // Queue append of the lanes flagged `in` (mask m_, prefix count).  A slab of node pairs may bring up to 128 inside
-    // nodes to a queue that holds 128: when the two halves do not both fit (qcount + n_a + n_b > 128 — more than 64
-    // inside nodes in one slab, i.e. a deeply overlapping pair; rare), the slab is NOT consumed: what is queued is
-    // drained as a (short) batch first and the slab is classified again with the queue empty.  (Until round 3 the
-    // second half waited in five registers that were live through phase 2, which the kernel does not have.)
+    // nodes to a queue that holds fewer than 64: with 128 ... 192 entries (queue_capacity) they do not always fit — a dense
+    // slab of a deeply overlapping pair on top of a leftover.  Then the slab is NOT consumed: what is queued is drained
+    // as a (short) batch first and the slab is classified again with the queue empty.  (Until round 3 the second half
+    // waited in five registers that were live through phase 2, which the kernel does not have.  Measured and dropped in
+    // round 4, profiles/r04_am_ab_queue2.txt: filling the queue with the first nodes of the slab so that the batch is a
+    // full one — the number of batches per pair does not change, the extra masks cost 1 %; and a batch straight from the
+    // lanes' registers, which costs every per-azimuth kernel 2-14 registers.)
 #define SHP_PUSH(m_, pn, rin_, rjn_)                                                                                  \
     {                                                                                                                  \
       if (m_ != 0ULL) {                                                                                                \
@@ -1726,25 +1690,6 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
       if constexpr (LJ >= 1) {
         const v2d cs1 = lds2(jpoly_trig_sep(LJ) ? fr + W.tr + 2 * l : gr + jpoly_trig(LJ));
         const double c1 = cs1[0], s1 = cs1[1];
-        if constexpr (SHP_TRIGG(LJ)) {
-        // (cos, sin)(m psi_l), m >= 2, from the launch's table in global memory (n_q rows, resident in the vector L1): no
-        // vector ALU instruction at all — the recurrence costs two v_fma_f64 per order
-        // (a scalar base and a 32-bit byte offset per lane: one vector instruction for the address)
-        const v2d* tg = (const v2d*)((const char*)P.trigj + (size_t)((unsigned)l * (unsigned)(16 * (LJ + 2))));
-#pragma unroll
-        for (int m = 1; m <= LJ; ++m) {
-          const v2d ab = lds2(row + 4 * m);
-          const double A = ab[0], B = ab[1];
-          double cm = c1, sm = s1;
-          if (m > 1) {
-            const v2d cs = tg[m];
-            cm = cs[0];
-            sm = cs[1];
-          }
-          if (m & 1) ro = fma(A, cm, fma(B, sm, ro));
-          else re = fma(A, cm, fma(B, sm, re));
-        }
-        } else {
         double cm = c1, sm = s1, cp = 1.0, sp = 0.0;   // three-term recurrence: one v_fma_f64 per cos / sin (ring_grad_rec)
         const double tc = c1 + c1;
 #pragma unroll
@@ -1760,7 +1705,6 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
             cm = c;
             sm = s;
           }
-        }
         }
       }
       const double ria = re + ro, rib = re - ro;
@@ -2128,11 +2072,7 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
         c1 = sg * cs1[0];
         s1 = sg * cs1[1];
       }
-      if constexpr (SHP_TRIGG(LJ))
-        ring_grad_tab<LJ>(fr + W.ring + (k - k0) * rowlen,
-                          (const v2d*)((const char*)P.trigj + (size_t)((unsigned)lrow * (unsigned)(16 * (LJ + 2)))), sg, c1, s1, rmu, rpsi);
-      else
-        ring_grad_rec<LJ>(fr + W.ring + (k - k0) * rowlen, c1, s1, rmu, rpsi);
+      ring_grad_rec<LJ>(fr + W.ring + (k - k0) * rowlen, c1, s1, rmu, rpsi);
       (void)r2;
     } else {
       ring_eval<L, true>(fr + W.ring + (k - k0) * rowlen, LL, c1, s1, P.trig + (trig_lmajor(L) ? (size_t)P.trig_stride * l : (size_t)(2 * l)), P.trig_stride, r2, rmu, rpsi);
