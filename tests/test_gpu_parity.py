@@ -632,6 +632,31 @@ def test_ring_groups_do_not_change_the_result(oracle, lmax, nq, rows):
     sp.close()
 
 
+@pytest.mark.parametrize("lmax,nq,spacing", [(6, 16, 1.6), (6, 24, 1.7), (8, 20, 1.7), (12, 32, 1.75), (5, 16, 1.6)])
+def test_dense_slabs_and_the_node_queue(oracle, lmax, nq, spacing):
+    """Deeply overlapping pairs: the central slabs of a cap are full of inside nodes and do not always fit the node
+    queue on top of a leftover (the slab is then classified a second time).  With the queue at its 128 entries and with
+    the entries the LDS granule leaves (option queue_slack) the result is the oracle's; the layout stays within the same
+    number of granules."""
+    case = make_case(90, lmax, 2, seed=70 + lmax, spacing=spacing, rmax_fn=oracle.shape_rmax)
+    K, E = coeff_tables(1, 1000.0, 1.25)
+    sp = make_ctx(case, nq, K, E)
+    b = case["bed"]
+    o = oracle_compute(oracle, case, nq, K, E, eflag=True)
+    res = {}
+    for slack in (1, 0):
+        sp.set_option("queue_slack", slack)
+        f, t, e, _ = sp.compute(case["n"], b["x"], b["quat"], b["type"], b["shtype"], eflag=True)
+        check(f, t, o)
+        assert abs(e - o["eng_virial"][0]) < TOL * abs(o["eng_virial"][0])
+        res[slack] = (f, e, sp.kernel_info())
+    fs = np.abs(res[0][0]).max()
+    assert np.abs(res[1][0] - res[0][0]).max() < 1e-12 * fs
+    k1, k0 = res[1][2], res[0][2]
+    assert k1["family"] == 1 and k1["lds_bytes_per_wave"] >= k0["lds_bytes_per_wave"] and k1["waves_per_cu_lds"] == k0["waves_per_cu_lds"]
+    sp.close()
+
+
 def test_non_finite_inputs_terminate(oracle):
     """inf coordinates and zero quaternions must not hang the kernel (every loop is bounded) and must not disturb pairs
     they are not part of; a NaN coordinate makes its pairs' separation not a number, which docs/SPEC.md 2 step 1 treats
