@@ -1132,6 +1132,8 @@ int shhalo_run_device(shhalo_ctx* h, shhalo_arrays* a, const shhalo_run_params* 
     if (rc) { h->err = sp->err; break; }
   }
   const hipError_t es = hipStreamSynchronize(st);
+  // a step that ended early may have left an exchange in flight on the second stream, reading the caller's arrays
+  if (rc != SHPAIR_OK && h->st2) (void)hipStreamSynchronize(h->st2);
   if (rc == SHPAIR_OK && es == hipSuccess && kernel_ms) {
     double sum = 0.0;
     for (int k = 0; k < ntimed; ++k) {
