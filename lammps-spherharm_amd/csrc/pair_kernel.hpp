@@ -140,6 +140,9 @@ constexpr int kPairErrCoincident = 4;   // two centres coincide (rho = 0) or the
 #endif
 
 // docs/SPEC.md §2.6: residual below which the inverse-quadratic extrapolation is accepted
+#ifndef SHP_PEEL
+#define SHP_PEEL(L) ((L) >= 6)
+#endif
 #ifndef SHP_TAU3
 #define SHP_TAU3 1e-4
 #endif
@@ -1993,6 +1996,28 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
       };
       double gl0 = 0.0;
       if constexpr (JP) {
+        if constexpr (SHP_PEEL(L)) {
+        // From L = 6 on the first trip stands alone: its first iterate is the secant step (two points), and written apart
+        // from the loop the oldest slot's initial value is dead — no copies of r_i and g(r_i) into it, no test of the trip
+        // count (A/B profiles/r04_ap_ab_peel.txt: L = 9 / 16 -1.2 %, L = 12 / 32 -0.7 %, L = 6 / 32 -1.1 %, headline -0.2 %;
+        // L <= 5 measured +1 % and keep the loop as it was)
+        do {
+          if (!mask_any(mact)) break;
+          iterate(xa, ga, xb, gb, lam, gl0, false);
+          if (!mask_any(mact)) break;
+          iterate(xb, gb, lam, gl0, xa, ga, true);
+          if (!mask_any(mact)) break;
+          iterate(lam, gl0, xa, ga, xb, gb, true);
+          for (int it = 3; it < 60; it = __builtin_amdgcn_readfirstlane(it + 3)) {   // (a scalar counter, said so)
+            if (!mask_any(mact)) break;
+            iterate(xa, ga, xb, gb, lam, gl0, true);
+            if (!mask_any(mact)) break;
+            iterate(xb, gb, lam, gl0, xa, ga, true);
+            if (!mask_any(mact)) break;
+            iterate(lam, gl0, xa, ga, xb, gb, true);
+          }
+        } while (false);
+        } else {
         for (int it = 0; it < 60; it = __builtin_amdgcn_readfirstlane(it + 3)) {   // (a scalar counter, said so)
           if (!mask_any(mact)) break;
           iterate(xa, ga, xb, gb, lam, gl0, it >= 1);
@@ -2000,6 +2025,7 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
           iterate(xb, gb, lam, gl0, xa, ga, true);
           if (!mask_any(mact)) break;
           iterate(lam, gl0, xa, ga, xb, gb, true);
+        }
         }
       } else {
         // body-frame kernels: one iterate per trip and the history shifted — their registers are spoken for: three
