@@ -657,6 +657,26 @@ def test_dense_slabs_and_the_node_queue(oracle, lmax, nq, spacing):
     sp.close()
 
 
+@pytest.mark.parametrize("lmax,nq,wpb,jpoly", [(6, 16, 2, -1), (6, 16, 4, -1), (4, 10, 4, -1), (5, 9, 3, 0), (9, 12, 2, -1), (14, 8, 2, -1)])
+def test_several_waves_per_workgroup(oracle, lmax, nq, wpb, jpoly):
+    """The tuning option waves_per_block: several one-wave pairs per workgroup, each with its own slice of the
+    workgroup's LDS (the default is one; A/B in DESIGN 4.4) — same results."""
+    case = make_case(100, lmax, 2, seed=80 + lmax, rmax_fn=oracle.shape_rmax)
+    K, E = coeff_tables(1, 1000.0, 1.25)
+    sp = make_ctx(case, nq, K, E)
+    b = case["bed"]
+    f0, t0, e0, _ = sp.compute(case["n"], b["x"], b["quat"], b["type"], b["shtype"], eflag=True)
+    sp.set_option("waves_per_block", wpb)
+    if jpoly >= 0:
+        sp.set_option("jpoly", jpoly)
+    f1, t1, e1, _ = sp.compute(case["n"], b["x"], b["quat"], b["type"], b["shtype"], eflag=True)
+    o = oracle_compute(oracle, case, nq, K, E, eflag=True)
+    check(f1, t1, o)
+    assert abs(e1 - o["eng_virial"][0]) < TOL * abs(o["eng_virial"][0])
+    assert np.abs(f1 - f0).max() < 1e-11 * np.abs(f0).max()
+    sp.close()
+
+
 def test_non_finite_inputs_terminate(oracle):
     """inf coordinates and zero quaternions must not hang the kernel (every loop is bounded) and must not disturb pairs
     they are not part of; a NaN coordinate makes its pairs' separation not a number, which docs/SPEC.md 2 step 1 treats
