@@ -677,6 +677,32 @@ def test_several_waves_per_workgroup(oracle, lmax, nq, wpb, jpoly):
     sp.close()
 
 
+@pytest.mark.parametrize("lmax,nq", [(6, 16), (3, 7), (12, 10)])
+def test_loop_kernel_forced_for_a_compiled_order_and_the_timing_option(oracle, lmax, nq):
+    """Option variant = 1: the run-time-order loop kernel also for the orders that have compiled kernels; option
+    timing = 1: the pair kernels' time of the last call in the statistics."""
+    case = make_case(100, lmax, 2, seed=90 + lmax, rmax_fn=oracle.shape_rmax)
+    K, E = coeff_tables(1, 1000.0, 1.25)
+    sp = make_ctx(case, nq, K, E)
+    b = case["bed"]
+    sp.set_option("variant", 1)
+    sp.set_option("timing", 1)
+    f1, t1, e1, _ = sp.compute(case["n"], b["x"], b["quat"], b["type"], b["shtype"], eflag=True)
+    o = oracle_compute(oracle, case, nq, K, E, eflag=True)
+    check(f1, t1, o)
+    assert abs(e1 - o["eng_virial"][0]) < TOL * abs(o["eng_virial"][0])
+    k = sp.kernel_info()
+    assert k["compiled_order"] == 0 and k["lmax"] == lmax
+    st = sp.stats()
+    assert 0.0 < st["kernel_ms"] <= st["total_ms"] < 1e4
+    sp.set_option("variant", 0)
+    sp.set_option("timing", 0)
+    f0, t0, e0, _ = sp.compute(case["n"], b["x"], b["quat"], b["type"], b["shtype"], eflag=True)
+    assert sp.kernel_info()["compiled_order"] == 1
+    assert np.abs(f1 - f0).max() < 1e-11 * np.abs(f0).max()
+    sp.close()
+
+
 def test_non_finite_inputs_terminate(oracle):
     """inf coordinates and zero quaternions must not hang the kernel (every loop is bounded) and must not disturb pairs
     they are not part of; a NaN coordinate makes its pairs' separation not a number, which docs/SPEC.md 2 step 1 treats
