@@ -154,8 +154,10 @@ constexpr int kPairErrCoincident = 4;   // two centres coincide (rho = 0) or the
 //   ring[rows][L+1][4]   A_km, B_km, dA/dmu, dB/dmu of `rows` consecutive rings; the two B slots
 //                        of m = 0 (identically zero) carry mu_k and sigma_k.  rows = nq when that
 //                        leaves the CU enough waves, else the cap is processed in ring groups.
-//   qri[kQueue], qrj[kQueue], qp[kQueue] (16-bit)   queue of inside nodes
-constexpr int kQueue = 128;  // entries; a slab adds <= 64 to a queue holding < 64
+//   qri[n], qrj[n], qp[n] (16-bit)   queue of inside nodes, n = kQueue (body-frame and weighted kernels: a ring buffer)
+//                        or queue_capacity() (per-azimuth kernels: a stack)
+constexpr int kQueue = 128;  // entries: a slab of 64 nodes adds <= 64 to a queue holding < 64 (the per-azimuth kernels' slabs
+                             // are 64 node PAIRS: see queue_capacity)
 constexpr int kFrame = 40;
 constexpr int kRedStride = 72;    // epilogue reduction: doubles between the 64-entry rows of the seven sums (64 + 8: rows
                                   // four apart share banks, not all seven)
