@@ -194,6 +194,8 @@ typedef struct shpair_kernel_info {
   int needv, weighted;        /* the instance's other two template arguments: overlap-volume root finder compiled in;
                                  covered-fraction rule.  (lmax, needv, weighted, family, waves_per_pair) name the
                                  pair_contact_kernel instance that ran — profiles/pmc_traffic.json is keyed to its code */
+  int queue_entries;          /* entries of a wave's node queue: 128, or for the "jpoly" family 128 + what the layout leaves
+                                 of its last LDS granule (at most 192; option "queue_slack") */
 } shpair_kernel_info;
 int shpair_get_kernel_info(shpair_ctx *ctx, shpair_kernel_info *out);
 

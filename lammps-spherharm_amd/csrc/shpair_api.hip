@@ -813,6 +813,7 @@ int shp_compute_range(shpair_ctx* c, int nlocal, int nghost, const double* x, co
     P.ring_rows = rows;
     c->last_lds_bytes = P.wave_lds_bytes;
     c->last_ring_rows = rows;
+    c->last_qcap = qcap;
   }
   P.pair_ft = nullptr;
   if (c->opt_deterministic) {
@@ -1029,6 +1030,7 @@ int shpair_get_kernel_info(shpair_ctx* c, shpair_kernel_info* out)
   out->lds_bytes_per_wave = c->last_lds_bytes / wpp;
   out->waves_per_pair = wpp;
   out->ring_rows = c->last_ring_rows;
+  out->queue_entries = c->last_qcap;
   // gfx950: 512 VGPRs per SIMD lane in blocks of 8, at most 8 waves per SIMD, 160 KiB LDS per CU of 4 SIMDs
   const int vg = ((a.numRegs + 7) / 8) * 8;
   int w = vg > 0 ? 512 / vg : 8;

@@ -112,7 +112,7 @@ struct shpair_ctx {
   int rev_nall = 0;
   int opt_split = -1;      // 1 / 0: two waves per pair (pair_kernel.hpp WPP = 2) or one; -1: by the rule use_split
   bool last_split = false;
-  int last_lds_bytes = 0, last_ring_rows = 0;  // of the last launch (shpair_get_kernel_info)
+  int last_lds_bytes = 0, last_ring_rows = 0, last_qcap = 0;  // of the last launch (shpair_get_kernel_info)
   bool last_needv = false;
   double* pair_out = nullptr;
   double *eatom_dev = nullptr, *vatom_dev = nullptr;    // shpair_set_peratom_output

@@ -653,6 +653,7 @@ def test_dense_slabs_and_the_node_queue(oracle, lmax, nq, spacing):
     fs = np.abs(res[0][0]).max()
     assert np.abs(res[1][0] - res[0][0]).max() < 1e-12 * fs
     k1, k0 = res[1][2], res[0][2]
+    assert k0["queue_entries"] == 128 <= k1["queue_entries"] <= 192
     assert k1["family"] == 1 and k1["lds_bytes_per_wave"] >= k0["lds_bytes_per_wave"] and k1["waves_per_cu_lds"] == k0["waves_per_cu_lds"]
     sp.close()
 
@@ -935,12 +936,14 @@ def test_kernel_info_reports_the_launched_footprint(oracle):
     assert k["lmax"] == 6 and k["compiled_order"] == 1 and 80 < k["vgprs"] <= 96 and k["scratch_bytes"] == 0
     assert k["family"] == 1 and 7680 < k["lds_bytes_per_wave"] <= 8960 and k["ring_rows"] == 16
     assert k["waves_per_simd_vgpr"] == 5 and k["waves_per_cu"] == 18 and k["waves_per_cu_lds"] == 18
+    assert 128 < k["queue_entries"] <= 192 and k["queue_entries"] % 4 == 0     # the rest of the 7th granule: 18 bytes per entry
     sp.set_option("jpoly", 0)       # the body-frame kernel of the same order
     sp.compute(60, b["x"], b["quat"], b["type"], b["shtype"])
     k = sp.kernel_info()
     assert k["lmax"] == 6 and k["compiled_order"] == 1 and 64 <= k["vgprs"] <= 80 and k["scratch_bytes"] == 0
     assert k["family"] == 0 and 4096 < k["lds_bytes_per_wave"] <= 8192 and k["ring_rows"] == 16
     assert k["waves_per_simd_vgpr"] == 6 and k["waves_per_cu"] == 21        # LDS (7.2 KB per wave = 6 granules of 1 280 B) is the limit
+    assert k["queue_entries"] == 128
     sp.set_option("rule", 1)
     sp.compute(60, b["x"], b["quat"], b["type"], b["shtype"])
     kw = sp.kernel_info()
