@@ -1280,6 +1280,31 @@ __device__ __forceinline__ void ring_grad_rec(const double* __restrict__ row, co
   }
 }
 
+template <bool B>
+struct BoolC { static constexpr bool value = B; };
+// r_i at a node of ring row `row` from (cos psi, sin psi), the same recurrence (a direct batch computes it a second time
+// behind the inner-radius search instead of carrying it through, see DIRECT in pair_contact_kernel)
+template <int L>
+__device__ __forceinline__ double ring_value(const double* __restrict__ row, const double c1, const double s1)
+{
+  double r = row[0];
+  double cm = c1, sm = s1, cp = 1.0, sp = 0.0;
+  const double tc = c1 + c1;
+#pragma unroll
+  for (int m = 1; m <= L; ++m) {
+    const v2d ab = lds2(row + 4 * m);
+    r = fma(ab[0], cm, fma(ab[1], sm, r));
+    if (m < L) {
+      const double c = fma(tc, cm, -cp), s = fma(tc, sm, -sp);
+      cp = cm;
+      sp = sm;
+      cm = c;
+      sm = s;
+    }
+  }
+  return r;
+}
+
 // Two evaluations from one pass over the row (phase 1: the two nodes of a lane's pair share it)
 template <int L>
 __device__ __forceinline__ void jpoly_eval2(const double* __restrict__ row, const double mua, const double siga,
@@ -1338,6 +1363,16 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
   // run-time-order kernel keeps the body-frame evaluation sh_eval_rt
   constexpr bool JP = JPT && (L >= 0) && !WEIGHTED;
   constexpr int LJ = JP ? L : 0;
+  // CARRY: the node (ring, azimuth, weight, mu, sigma) stays in registers across the inner-radius search where the kernel
+  // has them to spare (see phase 2); DIRECT: ... and a slab whose inside nodes do not fit the queue becomes a batch of its own
+#ifndef SHP_CARRY_NODE
+#define SHP_CARRY_NODE(L, WPP) ((L) >= 6 && !((L) == 9 && (WPP) == 1))
+#endif
+  constexpr bool CARRY = JP && SHP_CARRY_NODE(L, WPP);
+#ifndef SHP_DIRECT
+#define SHP_DIRECT(L) 1
+#endif
+  constexpr bool DIRECT = SHP_DIRECT(L) && JP && !WEIGHTED && (CARRY || !NEEDV);
   constexpr int FRAME = JP ? kFrameJ : kFrame;   // doubles of the frame in LDS; FRM(slot): where a record slot sits in it
 #define FRM(slot) (JP ? frj(slot) : (slot))
   WaveLdsLayout W = (WPP == 2) ? pair_lds_layout2(LL, P.ring_rows, nq, P.qcap)
@@ -1551,298 +1586,35 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
 #endif
   }
 
-  __builtin_amdgcn_s_setprio(0);
-  for (;;) {
-    // ---------------------------------------------------------------- phase 1
-    // classify slabs of 64 cap nodes until 64 inside nodes are queued
-    if constexpr (WEIGHTED) {
-    // iteration t: residuals of slab t (if any), then the weights of slab t - 1 from slabs t - 2, t - 1, t
-    while (qcount < 64 && slab < slab_end) {
-      fr = SHP_LDS();
-      const int t = slab;
-      ++slab;
-      double g0 = 0.0, ri0 = 0.0, rj00 = 0.0;
-      bool in0 = false;
-      if (t < nslabs) {  // wave-uniform
-        const int p = (t << 6) + lane;
-        const bool valid = p < Q;
-        const int k = valid ? (int)(umul_sel<JP>((unsigned)p, magic) >> 24) : 0;
-        const int l = valid ? p - mul_sel<JP>(k, npsi) : 0;
-        const double* row = fr + W.ring + (k - k0) * rowlen;
-        const double mu = row[1], sig = row[3];
-        const double c1 = P.cpsi[l], s1 = P.spsi[l];
-        double ri, t0, t1;
-        ring_eval<L, false>(row, LL, c1, s1, P.trig + (trig_lmajor(L) ? (size_t)P.trig_stride * l : (size_t)(2 * l)), P.trig_stride, ri, t0, t1);
-        const double a1 = sig * c1, a2 = sig * s1;
-        const double uj0 = fma(a1, fr[FR_BJ1], fma(a2, fr[FR_BJ2], mu * fr[FR_BJC]));
-        const double uj1 = fma(a1, fr[FR_BJ1 + 1], fma(a2, fr[FR_BJ2 + 1], mu * fr[FR_BJC + 1]));
-        const double uj2 = fma(a1, fr[FR_BJ1 + 2], fma(a2, fr[FR_BJ2 + 2], mu * fr[FR_BJC + 2]));
-        const double q0 = fma(ri, uj0, -fr[FR_DJ]), q1 = fma(ri, uj1, -fr[FR_DJ + 1]),
-                     q2 = fma(ri, uj2, -fr[FR_DJ + 2]);
-        const double s2 = q0 * q0 + q1 * q1 + q2 * q2;
-        const bool cand = valid && (s2 < fr[FR_RJ2]);
-        const bool szero = !(s2 > 0.0);
-        const double inv = rsqrt_nr1(fmax(s2, 1e-300));
-        const double sN = s2 * inv;
-        g0 = sN - fr[FR_RJ];  // outside B_j: the stand-in of SPEC §2.8 (>= 0)
-        double rj0 = fr[FR_RJ];
-        if (wave_any<false>(cand)) {  // wave-uniform
-          const double rj0e = sh_eval<L>(rc, cwj, lrt, q0 * inv, q1 * inv, q2 * inv);
-          if (!szero) rj0 = rj0e;
-          if (cand) g0 = szero ? -rj0 : sN - rj0;
-        }
-        in0 = cand;
-        ri0 = ri;
-        rj00 = rj0;
-      }
-      if (t >= 1) {
-        const int p1 = ((t - 1) << 6) + lane;
-        const bool valid1 = p1 < Q;
-        const int k1 = valid1 ? (int)(umul_sel<JP>((unsigned)p1, magic) >> 24) : 0;
-        const int l1 = valid1 ? p1 - mul_sel<JP>(k1, npsi) : 0;
-        double nb[3];
-        if (aligned) {
-          // rings do not straddle slabs (n_psi divides 64): the azimuth neighbours sit in slab t-1 itself and the
-          // ring neighbour one ring further in slab t-1 or at the start of slab t (n_psi = 64: the same lane of
-          // slab t, or of slab t-2 for the last ring) — 4 (2) cross-lane reads instead of 9
-          const int base = lane & ~(npsi - 1);
-          nb[0] = __shfl(wg1, base | ((lane + 1) & (npsi - 1)), 64);
-          nb[1] = __shfl(wg1, base | ((lane - 1) & (npsi - 1)), 64);
-          if (npsi == 64) {
-            nb[2] = (k1 < nq - 1) ? g0 : wg2;
-          } else {
-            const int idx = lane + ((k1 < nq - 1) ? npsi : -npsi);
-            const double v1 = __shfl(wg1, idx & 63, 64), v0 = __shfl(g0, idx & 63, 64);
-            nb[2] = (idx < 64) ? v1 : v0;
-          }
-        } else {
-          // neighbours as lane offsets within the three-slab window [t-2 | t-1 | t]
-          const int o_lp = (l1 == npsi - 1) ? -(npsi - 1) : 1;
-          const int o_lm = (l1 == 0) ? (npsi - 1) : -1;
-          const int o_k = (k1 < nq - 1) ? npsi : -npsi;
-#pragma unroll
-          for (int a = 0; a < 3; ++a) {
-            const int idx = lane + (a == 0 ? o_lp : (a == 1 ? o_lm : o_k));
-            const int src = idx & 63;
-            const double v2 = __shfl(wg2, src, 64), v1 = __shfl(wg1, src, 64), v0 = __shfl(g0, src, 64);
-            nb[a] = (idx < 0) ? v2 : ((idx < 64) ? v1 : v0);
-          }
-        }
-        const double Dl = 0.5 * fabs(nb[0] - nb[1]);
-        const double Dk = (nq > 1) ? fabs(nb[2] - wg1) : 0.0;
-        const double den = Dk + Dl;
-        double wt = (wg1 < 0.0) ? 1.0 : 0.0;
-        if (den > 0.0) wt = fmin(1.0, fmax(0.0, fma(-wg1, rcp_nr(den), 0.5)));
-        const bool take = valid1 && win1 && (wt > 0.0);
-        const unsigned long long m = wave_ballot(take);
-        if (m != 0ULL) {
-          if (take) {
-            const int pos = (qhead + qcount + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32),
-                                                     __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u))) & (kQueue - 1);
-            double* lq = (double*)fr;
-            ((unsigned short*)(lq + W.qp))[pos] = (unsigned short)p1;
-            lq[W.qri + pos] = wri1;
-            lq[W.qrj + pos] = wrj1;
-            lq[W.qw + pos] = (wg1 < 0.0) ? wt : -wt;  // the sign carries [g~ < 0] to phase 2 (no second opinion there)
-          }
-          qcount += __builtin_popcountll(m);
-        }
-      }
-      wg2 = wg1;
-      wg1 = g0;
-      wri1 = ri0;
-      wrj1 = rj00;
-      win1 = in0;
-    }
-    } else if constexpr (JP) {
-    // Queue append of the lanes flagged `in` (mask m_, prefix count).  A slab of node pairs may bring up to 128 inside
-    // nodes to a queue that holds fewer than 64: with 128 ... 192 entries (queue_capacity) they do not always fit — a dense
-    // slab of a deeply overlapping pair on top of a leftover.  Then the slab is NOT consumed: what is queued is drained
-    // as a (short) batch first and the slab is classified again with the queue empty.  (Until round 3 the second half
-    // waited in five registers that were live through phase 2, which the kernel does not have.  Measured and dropped in
-    // round 4, profiles/r04_am_ab_queue2.txt: filling the queue with the first nodes of the slab so that the batch is a
-    // full one — the number of batches per pair does not change, the extra masks cost 1 %; and a batch straight from the
-    // lanes' registers, which costs every per-azimuth kernel 2-14 registers.)
-#define SHP_PUSH(m_, pn, rin_, rjn_)                                                                                  \
-    {                                                                                                                  \
-      if (m_ != 0ULL) {                                                                                                \
-        if (lane_of(m_)) {                                                                                             \
-          const int pos_ = qcount + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m_ >> 32),                               \
-                                                    __builtin_amdgcn_mbcnt_lo((unsigned)m_, 0u));                      \
-          double* lq_ = SHP_LDS();                                                                                     \
-          ((unsigned short*)(lq_ + W.qp))[pos_] = (unsigned short)(pn);                                                \
-          lq_[W.qri + pos_] = (rin_);                                                                                  \
-          lq_[W.qrj + pos_] = (rjn_);                                                                                  \
-        }                                                                                                              \
-        qcount += __builtin_popcountll(m_);                                                                            \
-      }                                                                                                                \
-    }
-    while (qcount < 64 && slab < slab_end) {
-      fr = SHP_LDS();
-      const int pp = (slab << 6) + lane;   // node pair: ring k, azimuths l and l + n_q
-      // idle lanes (past the last node pair: in the last slab only, whose group holds the last ring) take the last node
-      // pair — a resident row, and one v_min instead of a compare, a masked region and two selects; mvalid drops them
-      const int ppc = min(pp, nq * per_ring - 1);
-      const int k = (int)(umul_sel<JP>((unsigned)ppc, magicr) >> 24);
-      const int l = ppc - mul_sel<JP>(k, per_ring) + half * per_ring;
-      const double* row = fr + W.ring + (k - k0) * rowlen;
-      const v2d r01 = lds2(row);   // (A_k0, mu_k)
-      const double mu = r01[1], sig = row[3];
-      // r_i at the two azimuths: psi + pi changes the sign of the odd orders
-      // cos/sin(m psi_l): the first order from the lane's row of particle j's table, the rest by angle addition
-      const double* gr = fr + W.gh + mul_sel<JP>(l, jpoly_row(LJ));
-      double re = r01[0], ro = 0.0;
-      if constexpr (LJ >= 1) {
-        const v2d cs1 = lds2(jpoly_trig_sep(LJ) ? fr + W.tr + 2 * l : gr + jpoly_trig(LJ));
-        const double c1 = cs1[0], s1 = cs1[1];
-        double cm = c1, sm = s1, cp = 1.0, sp = 0.0;   // three-term recurrence: one v_fma_f64 per cos / sin (ring_grad_rec)
-        const double tc = c1 + c1;
-#pragma unroll
-        for (int m = 1; m <= LJ; ++m) {
-          const v2d ab = lds2(row + 4 * m);
-          const double A = ab[0], B = ab[1];
-          if (m & 1) ro = fma(A, cm, fma(B, sm, ro));
-          else re = fma(A, cm, fma(B, sm, re));
-          if (m < LJ) {
-            const double c = fma(tc, cm, -cp), s = fma(tc, sm, -sp);
-            cp = cm;
-            sp = sm;
-            cm = c;
-            sm = s;
-          }
-        }
-      }
-      const double ria = re + ro, rib = re - ro;
-      const double rho = s_rho, rj2 = s_rj2;
-      const double qa0 = fma(ria, mu, -rho), qa1 = ria * sig;
-      const double qb0 = fma(rib, mu, -rho), qb1 = -rib * sig;
-      const double sa2 = fma(qa0, qa0, qa1 * qa1), sb2 = fma(qb0, qb0, qb1 * qb1);
-      // candidates, inside nodes: masks (scalar unit), not lane predicates
-      // the valid lanes are the first (count - 64 slab) of the wave: the mask from scalar arithmetic (as a ballot of
-      // `valid` it goes through a 0 / 1 value per lane)
-      const int nvalid = nq * per_ring - (slab << 6);
-      const unsigned long long mvalid = nvalid >= 64 ? ~0ULL : ((1ULL << nvalid) - 1ULL);
-      const unsigned long long mca = wave_ballot(sa2 < rj2) & mvalid, mcb = wave_ballot(sb2 < rj2) & mvalid;
-      if ((mca | mcb) == 0ULL) {   // wave-uniform: all 128 nodes miss B_j
-#ifdef SHP_STATS   // a slab of this family is 128 nodes: counted as two, so that the counters compare across families
-        if (lane == 0) atomicAdd(&P.dbg[0], 2ULL);
-#endif
-        ++slab;
-        continue;
-      }
-      const bool za = !(sa2 > 0.0), zb = !(sb2 > 0.0);
-      const unsigned long long mza = wave_ballot(za), mzb = wave_ballot(zb);   // once: the compares' own scalar pairs
-      // no clamp of sa2, sb2 (two v_max_f64 each under IEEE mode): a node on x_j leaves NaN in r_j, replaced below
-      const double inva = rsqrt_nr1(sa2), invb = rsqrt_nr1(sb2);
-      double rjae, rjbe;   // one pass over the lane's row of particle j's table serves both nodes
-      jpoly_eval2<LJ>(fr + W.gh + mul_sel<JP>(l, jpoly_row(LJ)), qa0 * inva, qa1 * inva, qb0 * invb, qb1 * invb, rjae, rjbe);
-      const double Rjl = s_rj;
-      double rja = rjae, rjb = rjbe;
-      if (mask_any(mza | mzb)) {   // a node on x_j: measure zero; the volatile statement keeps this a branch
-        asm volatile("; rare: a node on x_j");
-        rja = za ? Rjl : rjae;
-        rjb = zb ? Rjl : rjbe;
-      }
-      const unsigned long long ma = mca & (mza | wave_ballot(sa2 * inva < rja));
-      const unsigned long long mb = mcb & (mzb | wave_ballot(sb2 * invb < rjb));
-      const int pa = mul_sel<JP>(k, npsi) + l;
-#ifdef SHP_STATS
-      if (qcount + __builtin_popcountll(ma) + __builtin_popcountll(mb) > W.qcap) {
-        if (lane == 0) atomicAdd(&P.dbg[9], 1ULL);
-      }
-#endif
-      if (qcount + __builtin_popcountll(ma) + __builtin_popcountll(mb) > W.qcap) break;   // wave-uniform; qcount > 0 here
-#ifdef SHP_STATS
-      if (lane == 0) atomicAdd(&P.dbg[0], 2ULL);
-      if (lane_of(mca)) atomicAdd(&P.dbg[1], 1ULL);
-      if (lane_of(mcb)) atomicAdd(&P.dbg[1], 1ULL);
-      if (lane == 0) atomicAdd(&P.dbg[2], 2ULL);
-      if (lane_of(ma)) atomicAdd(&P.dbg[3], 1ULL);
-      if (lane_of(mb)) atomicAdd(&P.dbg[3], 1ULL);
-#endif
-      ++slab;
-      SHP_PUSH(ma, pa, ria, rja);
-      SHP_PUSH(mb, pa + nq, rib, rjb);
-    }
-#undef SHP_PUSH
-    } else {
-    while (qcount < 64 && slab < slab_end) {
-      fr = SHP_LDS();
-      const int p = (slab << 6) + lane;
-      ++slab;
-      const bool valid = p < Q;
-      const int k = valid ? (int)(umul_sel<JP>((unsigned)p, magic) >> 24) : 0;
-      const int l = valid ? p - mul_sel<JP>(k, npsi) : 0;
-      const double* row = fr + W.ring + (k - k0) * rowlen;
-      const double mu = row[1], sig = row[3];
-      const double c1 = P.cpsi[l], s1 = P.spsi[l];
-      double ri, t0, t1;
-      ring_eval<L, false>(row, LL, c1, s1, P.trig + (trig_lmajor(L) ? (size_t)P.trig_stride * l : (size_t)(2 * l)), P.trig_stride, ri, t0, t1);
-      // the surface point seen from x_j, in j's body frame
-      const double a1 = sig * c1, a2 = sig * s1;
-      const double uj0 = fma(a1, fr[FR_BJ1], fma(a2, fr[FR_BJ2], mu * fr[FR_BJC]));
-      const double uj1 = fma(a1, fr[FR_BJ1 + 1], fma(a2, fr[FR_BJ2 + 1], mu * fr[FR_BJC + 1]));
-      const double uj2 = fma(a1, fr[FR_BJ1 + 2], fma(a2, fr[FR_BJ2 + 2], mu * fr[FR_BJC + 2]));
-      const double q0 = fma(ri, uj0, -fr[FR_DJ]), q1 = fma(ri, uj1, -fr[FR_DJ + 1]),
-                   q2 = fma(ri, uj2, -fr[FR_DJ + 2]);
-      const double s2 = q0 * q0 + q1 * q1 + q2 * q2;
-      const bool cand = valid && (s2 < fr[FR_RJ2]);
-#ifdef SHP_STATS
-      if (lane == 0) atomicAdd(&P.dbg[0], 1ULL);
-      if (cand) atomicAdd(&P.dbg[1], 1ULL);
-      { const bool a_ = __any(cand); if (lane == 0 && a_) atomicAdd(&P.dbg[2], 1ULL); }
-#endif
-      if (!wave_any<false>(cand)) continue;  // wave-uniform: the whole 64-node slab misses B_j
-
-      // s == 0 (the node sits on x_j) is inside by definition; clamping s2 keeps that lane
-      // finite without a select per component (its direction is then the zero vector)
-      const bool szero = !(s2 > 0.0);
-      const double inv = rsqrt_nr1(fmax(s2, 1e-300));
-      const double rj0e = sh_eval<L>(rc, cwj, lrt, q0 * inv, q1 * inv, q2 * inv);
-      const double rj0 = szero ? fr[FR_RJ] : rj0e;
-      // SPEC: inside iff s < r_j (s == 0 is inside); s = s2 / sqrt(s2)
-      const bool inside = cand && (szero || s2 * inv < rj0);
-      const unsigned long long m = wave_ballot(inside);
-#ifdef SHP_STATS
-      if (inside) atomicAdd(&P.dbg[3], 1ULL);
-#endif
-      if (m == 0ULL) continue;
-      if (inside) {
-        const int pos = (qhead + qcount + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32),
-                                                 __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u))) & (kQueue - 1);
-        double* lq = (double*)fr;
-        ((unsigned short*)(lq + W.qp))[pos] = (unsigned short)p;
-        lq[W.qri + pos] = ri;
-        lq[W.qrj + pos] = rj0;
-      }
-      qcount += __builtin_popcountll(m);
-    }
-    }
-    if (qcount == 0) break;   // the group's slabs are classified and its queue is drained
-#if defined(SHP_ABL) && SHP_ABL == 3   // timing-only build: phase 1 only, the queue is discarded
-    qhead = (qhead + qcount) & (kQueue - 1);
-    qcount = 0;
-    continue;
-#endif
-
-    // ---------------------------------------------------------------- phase 2
-    // up to 64 queued inside nodes, one per lane: inner radius, then gradient
+  // Phase 2 as a lambda, instantiated twice by the kernels that take DIRECT batches: from the queue (DIR false), and on the
+  // lanes' own nodes (dp, dri, drj; lanes mdir) when a slab's inside nodes do not fit the queue.
+  auto phase2 = [&](auto dir_c, const int dp, const double dri, const double drj, const unsigned long long mdir)
+                    __attribute__((always_inline)) {
+    constexpr bool DIR = decltype(dir_c)::value;
+    (void)dp; (void)dri; (void)drj; (void)mdir;
     wave_lds_sync();
     fr = SHP_LDS();
-    const int cnt = qcount < 64 ? qcount : 64;
-    const bool active = lane < cnt;
+    const int cnt = DIR ? 64 : (qcount < 64 ? qcount : 64);
+    const bool active = DIR ? lane_of(mdir) : lane < cnt;
     // (idle lanes repeat a queued node, with weight 0: the last one through a v_min in the per-azimuth kernels)
     // per-azimuth kernels: the batch is the LAST cnt entries (a stack: what is left stays at the front, appends and
     // reads need no wrap, and the capacity need not be a power of two); the others keep a ring of kQueue entries
-    qcount -= cnt;
-    const int e = JP ? qcount + min(lane, cnt - 1) : ((qhead + (active ? lane : 0)) & (kQueue - 1));
+    if constexpr (!DIR) qcount -= cnt;
+    const int e = DIR ? 0 : (JP ? qcount + min(lane, cnt - 1) : ((qhead + (active ? lane : 0)) & (kQueue - 1)));
     if constexpr (!JP) qhead = (qhead + cnt) & (kQueue - 1);
 #ifdef SHP_STATS
     if (lane == 0) atomicAdd(&P.dbg[4], 1ULL);
     if (active) atomicAdd(&P.dbg[7], 1ULL);
 #endif
-    int p = ((const unsigned short*)(fr + W.qp))[e];   // Q = 2 nq^2 <= 2^15
-    double ri = fr[W.qri + e];
+    int p;
+    double ri;
+    if constexpr (DIR) {   // the lanes' own nodes; an idle lane holds a node of the slab that is not inside j: finite numbers, weight 0
+      p = dp;
+      ri = dri;
+    } else {
+      p = ((const unsigned short*)(fr + W.qp))[e];   // Q = 2 nq^2 <= 2^15
+      ri = fr[W.qri + e];
+    }
     int k = (int)(umul_sel<JP>((unsigned)p, magic) >> 24);
     int l = p - mul_sel<JP>(k, npsi);
     double omi = active ? fr[FRM(FR_WSC)] * (JP ? fr[W.glw + mul_sel<JP>(k, jpoly_row(LJ))] : P.glw[k]) : 0.0;   // the node's plain weight
@@ -1859,7 +1631,7 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
     double rin = 0.0;
     if (NEEDV) {
       // SPEC §2.6 inner radius, all lanes in lock step
-      const double rj0 = fr[W.qrj + e];
+      const double rj0 = DIR ? drj : fr[W.qrj + e];
       // the node's ray seen from x_j: compiled orders (axial, signed radial) = (lambda mu - rho, +-lambda sigma) in the
       // common frame; run-time-order kernel lambda u_j - d_j in j's body frame
       double uj0, uj1, uj2 = 0.0;
@@ -1902,7 +1674,7 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
       // the lanes still searching, as a scalar mask: the votes and the loop's exit are scalar compares, the loop counter
       // a scalar register (as a lane predicate the exit counts as divergent: counter and tests become vector code)
       unsigned long long mact;
-      if constexpr (JP) mact = centre_inside ? 0ULL : (cnt >= 64 ? ~0ULL : ((1ULL << cnt) - 1ULL));   // scalar arithmetic
+      if constexpr (JP) mact = centre_inside ? 0ULL : (DIR ? mdir : (cnt >= 64 ? ~0ULL : ((1ULL << cnt) - 1ULL)));   // scalar arithmetic
       else mact = wave_ballot(act);
       // One iterate of the search.  The three most recent points live in three (x, g) slots that trade roles from one
       // iterate to the next — (xa,ga) oldest, (xb,gb) middle, lam the point evaluated now, gc its residual — and the
@@ -2045,11 +1817,19 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
       // them to spare; elsewhere it is looked up a second time below
       // (from L = 6 on: six registers; up to L = 5 they would cost the sixth wave per SIMD, the one-wave kernel of L = 9
       // its fifth.  A/B profiles/r04_n_ab_carry.txt: L = 6, 7, 8 / n_q = 16 -1.6 %, -1.8 %, -1.5 %)
-#ifndef SHP_CARRY_NODE
-#define SHP_CARRY_NODE(L, WPP) ((L) >= 6 && !((L) == 9 && (WPP) == 1))
-#endif
-      constexpr bool CARRY = JP && SHP_CARRY_NODE(L, WPP);
-      if constexpr (JP) {
+      if constexpr (JP && DIR) {
+        // a direct batch has no slot: r_i a second time from the node's ring row (the node itself is carried)
+        const int lrow = l >= nq ? l - nq : l;
+        const double* tgd = jpoly_trig_sep(LJ) ? fr + W.tr + 2 * lrow : fr + W.gh + mul_sel<JP>(lrow, jpoly_row(LJ)) + jpoly_trig(LJ);
+        double cd = 1.0, sd = 0.0;
+        if constexpr (LJ >= 1) {
+          const v2d csd = lds2(tgd);
+          const double sgd = (l >= nq) ? -1.0 : 1.0;
+          cd = sgd * csd[0];
+          sd = sgd * csd[1];
+        }
+        ri = ring_value<LJ>(fr + W.ring + (k - k0) * rowlen, cd, sd);
+      } else if constexpr (JP) {
         // the batch's queue slots are untouched until the next phase 1: r_i and the node index are read again from
         // the slot instead of being carried through the root loop (three registers become one)
         const int e2 = (int)launder_u32((unsigned)e);
@@ -2121,6 +1901,307 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
     aT2 = fma(wr, u0 * A1 - u1 * A0, aT2);
     // the queue slots just read may be overwritten by the next phase 1
     wave_lds_sync();
+  };
+  __builtin_amdgcn_s_setprio(0);
+  for (;;) {
+    // ---------------------------------------------------------------- phase 1
+    // classify slabs of 64 cap nodes until 64 inside nodes are queued
+    if constexpr (WEIGHTED) {
+    // iteration t: residuals of slab t (if any), then the weights of slab t - 1 from slabs t - 2, t - 1, t
+    while (qcount < 64 && slab < slab_end) {
+      fr = SHP_LDS();
+      const int t = slab;
+      ++slab;
+      double g0 = 0.0, ri0 = 0.0, rj00 = 0.0;
+      bool in0 = false;
+      if (t < nslabs) {  // wave-uniform
+        const int p = (t << 6) + lane;
+        const bool valid = p < Q;
+        const int k = valid ? (int)(umul_sel<JP>((unsigned)p, magic) >> 24) : 0;
+        const int l = valid ? p - mul_sel<JP>(k, npsi) : 0;
+        const double* row = fr + W.ring + (k - k0) * rowlen;
+        const double mu = row[1], sig = row[3];
+        const double c1 = P.cpsi[l], s1 = P.spsi[l];
+        double ri, t0, t1;
+        ring_eval<L, false>(row, LL, c1, s1, P.trig + (trig_lmajor(L) ? (size_t)P.trig_stride * l : (size_t)(2 * l)), P.trig_stride, ri, t0, t1);
+        const double a1 = sig * c1, a2 = sig * s1;
+        const double uj0 = fma(a1, fr[FR_BJ1], fma(a2, fr[FR_BJ2], mu * fr[FR_BJC]));
+        const double uj1 = fma(a1, fr[FR_BJ1 + 1], fma(a2, fr[FR_BJ2 + 1], mu * fr[FR_BJC + 1]));
+        const double uj2 = fma(a1, fr[FR_BJ1 + 2], fma(a2, fr[FR_BJ2 + 2], mu * fr[FR_BJC + 2]));
+        const double q0 = fma(ri, uj0, -fr[FR_DJ]), q1 = fma(ri, uj1, -fr[FR_DJ + 1]),
+                     q2 = fma(ri, uj2, -fr[FR_DJ + 2]);
+        const double s2 = q0 * q0 + q1 * q1 + q2 * q2;
+        const bool cand = valid && (s2 < fr[FR_RJ2]);
+        const bool szero = !(s2 > 0.0);
+        const double inv = rsqrt_nr1(fmax(s2, 1e-300));
+        const double sN = s2 * inv;
+        g0 = sN - fr[FR_RJ];  // outside B_j: the stand-in of SPEC §2.8 (>= 0)
+        double rj0 = fr[FR_RJ];
+        if (wave_any<false>(cand)) {  // wave-uniform
+          const double rj0e = sh_eval<L>(rc, cwj, lrt, q0 * inv, q1 * inv, q2 * inv);
+          if (!szero) rj0 = rj0e;
+          if (cand) g0 = szero ? -rj0 : sN - rj0;
+        }
+        in0 = cand;
+        ri0 = ri;
+        rj00 = rj0;
+      }
+      if (t >= 1) {
+        const int p1 = ((t - 1) << 6) + lane;
+        const bool valid1 = p1 < Q;
+        const int k1 = valid1 ? (int)(umul_sel<JP>((unsigned)p1, magic) >> 24) : 0;
+        const int l1 = valid1 ? p1 - mul_sel<JP>(k1, npsi) : 0;
+        double nb[3];
+        if (aligned) {
+          // rings do not straddle slabs (n_psi divides 64): the azimuth neighbours sit in slab t-1 itself and the
+          // ring neighbour one ring further in slab t-1 or at the start of slab t (n_psi = 64: the same lane of
+          // slab t, or of slab t-2 for the last ring) — 4 (2) cross-lane reads instead of 9
+          const int base = lane & ~(npsi - 1);
+          nb[0] = __shfl(wg1, base | ((lane + 1) & (npsi - 1)), 64);
+          nb[1] = __shfl(wg1, base | ((lane - 1) & (npsi - 1)), 64);
+          if (npsi == 64) {
+            nb[2] = (k1 < nq - 1) ? g0 : wg2;
+          } else {
+            const int idx = lane + ((k1 < nq - 1) ? npsi : -npsi);
+            const double v1 = __shfl(wg1, idx & 63, 64), v0 = __shfl(g0, idx & 63, 64);
+            nb[2] = (idx < 64) ? v1 : v0;
+          }
+        } else {
+          // neighbours as lane offsets within the three-slab window [t-2 | t-1 | t]
+          const int o_lp = (l1 == npsi - 1) ? -(npsi - 1) : 1;
+          const int o_lm = (l1 == 0) ? (npsi - 1) : -1;
+          const int o_k = (k1 < nq - 1) ? npsi : -npsi;
+#pragma unroll
+          for (int a = 0; a < 3; ++a) {
+            const int idx = lane + (a == 0 ? o_lp : (a == 1 ? o_lm : o_k));
+            const int src = idx & 63;
+            const double v2 = __shfl(wg2, src, 64), v1 = __shfl(wg1, src, 64), v0 = __shfl(g0, src, 64);
+            nb[a] = (idx < 0) ? v2 : ((idx < 64) ? v1 : v0);
+          }
+        }
+        const double Dl = 0.5 * fabs(nb[0] - nb[1]);
+        const double Dk = (nq > 1) ? fabs(nb[2] - wg1) : 0.0;
+        const double den = Dk + Dl;
+        double wt = (wg1 < 0.0) ? 1.0 : 0.0;
+        if (den > 0.0) wt = fmin(1.0, fmax(0.0, fma(-wg1, rcp_nr(den), 0.5)));
+        const bool take = valid1 && win1 && (wt > 0.0);
+        const unsigned long long m = wave_ballot(take);
+        if (m != 0ULL) {
+          if (take) {
+            const int pos = (qhead + qcount + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32),
+                                                     __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u))) & (kQueue - 1);
+            double* lq = (double*)fr;
+            ((unsigned short*)(lq + W.qp))[pos] = (unsigned short)p1;
+            lq[W.qri + pos] = wri1;
+            lq[W.qrj + pos] = wrj1;
+            lq[W.qw + pos] = (wg1 < 0.0) ? wt : -wt;  // the sign carries [g~ < 0] to phase 2 (no second opinion there)
+          }
+          qcount += __builtin_popcountll(m);
+        }
+      }
+      wg2 = wg1;
+      wg1 = g0;
+      wri1 = ri0;
+      wrj1 = rj00;
+      win1 = in0;
+    }
+    } else if constexpr (JP) {
+    // Queue append of the lanes flagged `in` (mask m_, prefix count).  A slab of node pairs may bring up to 128 inside
+    // nodes to a queue that holds fewer than 64: with 128 ... 192 entries (queue_capacity) they do not always fit — a dense
+    // slab of a deeply overlapping pair on top of a leftover.  The kernels that carry the node through the search (DIRECT)
+    // then run phase 2 on the lanes' own nodes at once, a second instance of the phase-2 lambda: every lane with an inside
+    // node keeps one of its two, the other — where both are inside — is queued (at most 64 entries: they always fit), and
+    // the slab is consumed.  The others do NOT consume the slab: what is queued is drained as a (short) batch first and
+    // the slab is classified again with the queue empty.  (Until round 3 the second half waited in five registers that
+    // were live through phase 2, which the kernel does not have.  Round 4, profiles/r04_ar_ab_direct.txt: headline -2.3 %,
+    // L = 7 / 16 -3.6 %, L = 8 / 20 -6.4 %, L = 6 / 32 -2.3 %; written as ONE phase 2 with a second entry the same idea
+    // cost every kernel 2-14 registers and was dropped; so was filling the queue with the first nodes of the slab and
+    // classifying it again for the rest — the number of batches per pair does not change, r04_am_ab_queue2.txt.)
+#define SHP_PUSH(m_, pn, rin_, rjn_)                                                                                  \
+    {                                                                                                                  \
+      if (m_ != 0ULL) {                                                                                                \
+        if (lane_of(m_)) {                                                                                             \
+          const int pos_ = qcount + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m_ >> 32),                               \
+                                                    __builtin_amdgcn_mbcnt_lo((unsigned)m_, 0u));                      \
+          double* lq_ = SHP_LDS();                                                                                     \
+          ((unsigned short*)(lq_ + W.qp))[pos_] = (unsigned short)(pn);                                                \
+          lq_[W.qri + pos_] = (rin_);                                                                                  \
+          lq_[W.qrj + pos_] = (rjn_);                                                                                  \
+        }                                                                                                              \
+        qcount += __builtin_popcountll(m_);                                                                            \
+      }                                                                                                                \
+    }
+    while (qcount < 64 && slab < slab_end) {
+      fr = SHP_LDS();
+      const int pp = (slab << 6) + lane;   // node pair: ring k, azimuths l and l + n_q
+      // idle lanes (past the last node pair: in the last slab only, whose group holds the last ring) take the last node
+      // pair — a resident row, and one v_min instead of a compare, a masked region and two selects; mvalid drops them
+      const int ppc = min(pp, nq * per_ring - 1);
+      const int k = (int)(umul_sel<JP>((unsigned)ppc, magicr) >> 24);
+      const int l = ppc - mul_sel<JP>(k, per_ring) + half * per_ring;
+      const double* row = fr + W.ring + (k - k0) * rowlen;
+      const v2d r01 = lds2(row);   // (A_k0, mu_k)
+      const double mu = r01[1], sig = row[3];
+      // r_i at the two azimuths: psi + pi changes the sign of the odd orders
+      // cos/sin(m psi_l): the first order from the lane's row of particle j's table, the rest by angle addition
+      const double* gr = fr + W.gh + mul_sel<JP>(l, jpoly_row(LJ));
+      double re = r01[0], ro = 0.0;
+      if constexpr (LJ >= 1) {
+        const v2d cs1 = lds2(jpoly_trig_sep(LJ) ? fr + W.tr + 2 * l : gr + jpoly_trig(LJ));
+        const double c1 = cs1[0], s1 = cs1[1];
+        double cm = c1, sm = s1, cp = 1.0, sp = 0.0;   // three-term recurrence: one v_fma_f64 per cos / sin (ring_grad_rec)
+        const double tc = c1 + c1;
+#pragma unroll
+        for (int m = 1; m <= LJ; ++m) {
+          const v2d ab = lds2(row + 4 * m);
+          const double A = ab[0], B = ab[1];
+          if (m & 1) ro = fma(A, cm, fma(B, sm, ro));
+          else re = fma(A, cm, fma(B, sm, re));
+          if (m < LJ) {
+            const double c = fma(tc, cm, -cp), s = fma(tc, sm, -sp);
+            cp = cm;
+            sp = sm;
+            cm = c;
+            sm = s;
+          }
+        }
+      }
+      const double ria = re + ro, rib = re - ro;
+      const double rho = s_rho, rj2 = s_rj2;
+      const double qa0 = fma(ria, mu, -rho), qa1 = ria * sig;
+      const double qb0 = fma(rib, mu, -rho), qb1 = -rib * sig;
+      const double sa2 = fma(qa0, qa0, qa1 * qa1), sb2 = fma(qb0, qb0, qb1 * qb1);
+      // candidates, inside nodes: masks (scalar unit), not lane predicates
+      // the valid lanes are the first (count - 64 slab) of the wave: the mask from scalar arithmetic (as a ballot of
+      // `valid` it goes through a 0 / 1 value per lane)
+      const int nvalid = nq * per_ring - (slab << 6);
+      const unsigned long long mvalid = nvalid >= 64 ? ~0ULL : ((1ULL << nvalid) - 1ULL);
+      const unsigned long long mca = wave_ballot(sa2 < rj2) & mvalid, mcb = wave_ballot(sb2 < rj2) & mvalid;
+      if ((mca | mcb) == 0ULL) {   // wave-uniform: all 128 nodes miss B_j
+#ifdef SHP_STATS   // a slab of this family is 128 nodes: counted as two, so that the counters compare across families
+        if (lane == 0) atomicAdd(&P.dbg[0], 2ULL);
+#endif
+        ++slab;
+        continue;
+      }
+      const bool za = !(sa2 > 0.0), zb = !(sb2 > 0.0);
+      const unsigned long long mza = wave_ballot(za), mzb = wave_ballot(zb);   // once: the compares' own scalar pairs
+      // no clamp of sa2, sb2 (two v_max_f64 each under IEEE mode): a node on x_j leaves NaN in r_j, replaced below
+      const double inva = rsqrt_nr1(sa2), invb = rsqrt_nr1(sb2);
+      double rjae, rjbe;   // one pass over the lane's row of particle j's table serves both nodes
+      jpoly_eval2<LJ>(fr + W.gh + mul_sel<JP>(l, jpoly_row(LJ)), qa0 * inva, qa1 * inva, qb0 * invb, qb1 * invb, rjae, rjbe);
+      const double Rjl = s_rj;
+      double rja = rjae, rjb = rjbe;
+      if (mask_any(mza | mzb)) {   // a node on x_j: measure zero; the volatile statement keeps this a branch
+        asm volatile("; rare: a node on x_j");
+        rja = za ? Rjl : rjae;
+        rjb = zb ? Rjl : rjbe;
+      }
+      const unsigned long long ma = mca & (mza | wave_ballot(sa2 * inva < rja));
+      const unsigned long long mb = mcb & (mzb | wave_ballot(sb2 * invb < rjb));
+      const int pa = mul_sel<JP>(k, npsi) + l;
+#ifdef SHP_STATS
+      if (qcount + __builtin_popcountll(ma) + __builtin_popcountll(mb) > W.qcap) {
+        if (lane == 0) atomicAdd(&P.dbg[9], 1ULL);
+      }
+#endif
+      if (qcount + __builtin_popcountll(ma) + __builtin_popcountll(mb) > W.qcap) {   // wave-uniform; qcount > 0 here
+        if constexpr (DIRECT) {
+          // every lane with an inside node keeps one of its two — the second where both are inside, the first of those is
+          // queued: at most 64 go to a queue that holds fewer than 64 — and phase 2 runs on the lanes' own nodes at once
+          const unsigned long long mboth = ma & mb;
+          SHP_PUSH(mboth, pa, ria, rja);
+          const bool second = lane_of(mb);
+          ++slab;
+#ifdef SHP_STATS
+          if (lane == 0) atomicAdd(&P.dbg[0], 2ULL);
+          if (lane_of(mca)) atomicAdd(&P.dbg[1], 1ULL);
+          if (lane_of(mcb)) atomicAdd(&P.dbg[1], 1ULL);
+          if (lane == 0) atomicAdd(&P.dbg[2], 2ULL);
+          if (lane_of(ma)) atomicAdd(&P.dbg[3], 1ULL);
+          if (lane_of(mb)) atomicAdd(&P.dbg[3], 1ULL);
+          if (lane == 0) atomicAdd(&P.dbg[10], 1ULL);
+#endif
+          phase2(BoolC<true>{}, second ? pa + nq : pa, second ? rib : ria, second ? rjb : rja, ma | mb);
+          continue;
+        }
+        break;
+      }
+#ifdef SHP_STATS
+      if (lane == 0) atomicAdd(&P.dbg[0], 2ULL);
+      if (lane_of(mca)) atomicAdd(&P.dbg[1], 1ULL);
+      if (lane_of(mcb)) atomicAdd(&P.dbg[1], 1ULL);
+      if (lane == 0) atomicAdd(&P.dbg[2], 2ULL);
+      if (lane_of(ma)) atomicAdd(&P.dbg[3], 1ULL);
+      if (lane_of(mb)) atomicAdd(&P.dbg[3], 1ULL);
+#endif
+      ++slab;
+      SHP_PUSH(ma, pa, ria, rja);
+      SHP_PUSH(mb, pa + nq, rib, rjb);
+    }
+#undef SHP_PUSH
+    } else {
+    while (qcount < 64 && slab < slab_end) {
+      fr = SHP_LDS();
+      const int p = (slab << 6) + lane;
+      ++slab;
+      const bool valid = p < Q;
+      const int k = valid ? (int)(umul_sel<JP>((unsigned)p, magic) >> 24) : 0;
+      const int l = valid ? p - mul_sel<JP>(k, npsi) : 0;
+      const double* row = fr + W.ring + (k - k0) * rowlen;
+      const double mu = row[1], sig = row[3];
+      const double c1 = P.cpsi[l], s1 = P.spsi[l];
+      double ri, t0, t1;
+      ring_eval<L, false>(row, LL, c1, s1, P.trig + (trig_lmajor(L) ? (size_t)P.trig_stride * l : (size_t)(2 * l)), P.trig_stride, ri, t0, t1);
+      // the surface point seen from x_j, in j's body frame
+      const double a1 = sig * c1, a2 = sig * s1;
+      const double uj0 = fma(a1, fr[FR_BJ1], fma(a2, fr[FR_BJ2], mu * fr[FR_BJC]));
+      const double uj1 = fma(a1, fr[FR_BJ1 + 1], fma(a2, fr[FR_BJ2 + 1], mu * fr[FR_BJC + 1]));
+      const double uj2 = fma(a1, fr[FR_BJ1 + 2], fma(a2, fr[FR_BJ2 + 2], mu * fr[FR_BJC + 2]));
+      const double q0 = fma(ri, uj0, -fr[FR_DJ]), q1 = fma(ri, uj1, -fr[FR_DJ + 1]),
+                   q2 = fma(ri, uj2, -fr[FR_DJ + 2]);
+      const double s2 = q0 * q0 + q1 * q1 + q2 * q2;
+      const bool cand = valid && (s2 < fr[FR_RJ2]);
+#ifdef SHP_STATS
+      if (lane == 0) atomicAdd(&P.dbg[0], 1ULL);
+      if (cand) atomicAdd(&P.dbg[1], 1ULL);
+      { const bool a_ = __any(cand); if (lane == 0 && a_) atomicAdd(&P.dbg[2], 1ULL); }
+#endif
+      if (!wave_any<false>(cand)) continue;  // wave-uniform: the whole 64-node slab misses B_j
+
+      // s == 0 (the node sits on x_j) is inside by definition; clamping s2 keeps that lane
+      // finite without a select per component (its direction is then the zero vector)
+      const bool szero = !(s2 > 0.0);
+      const double inv = rsqrt_nr1(fmax(s2, 1e-300));
+      const double rj0e = sh_eval<L>(rc, cwj, lrt, q0 * inv, q1 * inv, q2 * inv);
+      const double rj0 = szero ? fr[FR_RJ] : rj0e;
+      // SPEC: inside iff s < r_j (s == 0 is inside); s = s2 / sqrt(s2)
+      const bool inside = cand && (szero || s2 * inv < rj0);
+      const unsigned long long m = wave_ballot(inside);
+#ifdef SHP_STATS
+      if (inside) atomicAdd(&P.dbg[3], 1ULL);
+#endif
+      if (m == 0ULL) continue;
+      if (inside) {
+        const int pos = (qhead + qcount + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32),
+                                                 __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u))) & (kQueue - 1);
+        double* lq = (double*)fr;
+        ((unsigned short*)(lq + W.qp))[pos] = (unsigned short)p;
+        lq[W.qri + pos] = ri;
+        lq[W.qrj + pos] = rj0;
+      }
+      qcount += __builtin_popcountll(m);
+    }
+    }
+    if (qcount == 0) break;   // the group's slabs are classified and its queue is drained
+#if defined(SHP_ABL) && SHP_ABL == 3   // timing-only build: phase 1 only, the queue is discarded
+    qhead = (qhead + qcount) & (kQueue - 1);
+    qcount = 0;
+    continue;
+#endif
+
+    // ---------------------------------------------------------------- phase 2 (the lambda in front of the loop)
+    phase2(BoolC<false>{}, 0, 0.0, 0.0, 0ULL);
   }
   }  // ring groups
 

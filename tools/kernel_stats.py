@@ -41,5 +41,5 @@ print(f"inside nodes: {d[3] / (npairs * Q):.3f} of all nodes; phase-2 batches pe
       f"lane fill of the batches: {d[7] / max(1, 64 * d[4]):.3f}")
 print(f"root finder: wave iterations per batch {d[5] / max(1, d[4]):.2f}; lane evals per inside node "
       f"{d[6] / max(1, d[3]):.2f}; lane fill in root loop {d[6] / max(1, 64 * d[5]):.3f}")
-print(f"root finder: general-case branch taken in {d[8] / max(1, d[5]):.3f} of the wave iterations; slabs classified twice "
-      f"(queue full): {d[9] / npairs:.3f} per pair")
+print(f"root finder: general-case branch taken in {d[8] / max(1, d[5]):.3f} of the wave iterations; slabs that did not fit the queue: "
+      f"{d[9] / npairs:.3f} per pair, of which run as direct batches {d[10] / npairs:.3f} (the others are classified twice)")
