@@ -1364,7 +1364,8 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
   constexpr bool JP = JPT && (L >= 0) && !WEIGHTED;
   constexpr int LJ = JP ? L : 0;
   // CARRY: the node (ring, azimuth, weight, mu, sigma) stays in registers across the inner-radius search where the kernel
-  // has them to spare (see phase 2); DIRECT: ... and a slab whose inside nodes do not fit the queue becomes a batch of its own
+  // has them to spare (see phase 2); DIRECT (every per-azimuth kernel): a slab whose inside nodes do not fit the queue
+  // becomes a batch of its own
 #ifndef SHP_CARRY_NODE
 #define SHP_CARRY_NODE(L, WPP) ((L) >= 6 && !((L) == 9 && (WPP) == 1))
 #endif
@@ -1372,7 +1373,7 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
 #ifndef SHP_DIRECT
 #define SHP_DIRECT(L) 1
 #endif
-  constexpr bool DIRECT = SHP_DIRECT(L) && JP && !WEIGHTED && (CARRY || !NEEDV);
+  constexpr bool DIRECT = SHP_DIRECT(L) && JP && !WEIGHTED;
   constexpr int FRAME = JP ? kFrameJ : kFrame;   // doubles of the frame in LDS; FRM(slot): where a record slot sits in it
 #define FRM(slot) (JP ? frj(slot) : (slot))
   WaveLdsLayout W = (WPP == 2) ? pair_lds_layout2(LL, P.ring_rows, nq, P.qcap)
@@ -1817,8 +1818,9 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
       // them to spare; elsewhere it is looked up a second time below
       // (from L = 6 on: six registers; up to L = 5 they would cost the sixth wave per SIMD, the one-wave kernel of L = 9
       // its fifth.  A/B profiles/r04_n_ab_carry.txt: L = 6, 7, 8 / n_q = 16 -1.6 %, -1.8 %, -1.5 %)
-      if constexpr (JP && DIR) {
-        // a direct batch has no slot: r_i a second time from the node's ring row (the node itself is carried)
+      // the node's r_i behind the search: a queued node reads it again from its slot, a direct batch has no slot and computes
+      // it a second time from the node's ring row
+      auto ri_again = [&]() __attribute__((always_inline)) {
         const int lrow = l >= nq ? l - nq : l;
         const double* tgd = jpoly_trig_sep(LJ) ? fr + W.tr + 2 * lrow : fr + W.gh + mul_sel<JP>(lrow, jpoly_row(LJ)) + jpoly_trig(LJ);
         double cd = 1.0, sd = 0.0;
@@ -1828,18 +1830,18 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
           cd = sgd * csd[0];
           sd = sgd * csd[1];
         }
-        ri = ring_value<LJ>(fr + W.ring + (k - k0) * rowlen, cd, sd);
-      } else if constexpr (JP) {
-        // the batch's queue slots are untouched until the next phase 1: r_i and the node index are read again from
-        // the slot instead of being carried through the root loop (three registers become one)
-        const int e2 = (int)launder_u32((unsigned)e);
-        ri = fr[W.qri + e2];
-        if constexpr (!CARRY) p = ((const unsigned short*)(fr + W.qp))[e2];
-      }
-      const double dv3 = (WEIGHTED && outside) ? 0.0 : ri * ri * ri - rin * rin * rin;
+        return ring_value<LJ>(fr + W.ring + (k - k0) * rowlen, cd, sd);
+      };
       if constexpr (JP && !CARRY) {
         // The node is looked up a second time here (the root loop holds a row of particle j's table in 4L + 2
-        // registers and has none to carry weight, psi, mu, sigma across), from LDS only.
+        // registers and has none to carry weight, psi, mu, sigma across), from LDS only: the batch's queue slots are
+        // untouched until the next phase 1, r_i and the node index are read again from the slot instead of being
+        // carried through the root loop (three registers become one; a direct batch carries the index)
+        if constexpr (!DIR) {
+          const int e2 = (int)launder_u32((unsigned)e);
+          ri = fr[W.qri + e2];
+          p = ((const unsigned short*)(fr + W.qp))[e2];
+        }
         p = (int)launder_u32((unsigned)p);
         k = (int)(umul_sel<JP>((unsigned)p, magic) >> 24);
         l = p - mul_sel<JP>(k, npsi);
@@ -1847,7 +1849,17 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
         const double* row = fr + W.ring + (k - k0) * rowlen;
         mu = row[1];
         sig = row[3];
-      } else if constexpr (WEIGHTED) {
+        if constexpr (DIR) ri = ri_again();
+      } else if constexpr (JP) {
+        if constexpr (DIR) {
+          ri = ri_again();
+        } else {
+          const int e2 = (int)launder_u32((unsigned)e);
+          ri = fr[W.qri + e2];
+        }
+      }
+      const double dv3 = (WEIGHTED && outside) ? 0.0 : ri * ri * ri - rin * rin * rin;
+      if constexpr (!JP && WEIGHTED) {
         // The weighted kernels have three slabs of residuals in registers on top of the root finder's state: the
         // node (weight, psi, mu, sigma: nine registers) is looked up a second time here, through a copy of p the
         // compiler cannot see through, instead of being carried across the loop — that is what keeps them free of
@@ -2008,15 +2020,16 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
     } else if constexpr (JP) {
     // Queue append of the lanes flagged `in` (mask m_, prefix count).  A slab of node pairs may bring up to 128 inside
     // nodes to a queue that holds fewer than 64: with 128 ... 192 entries (queue_capacity) they do not always fit — a dense
-    // slab of a deeply overlapping pair on top of a leftover.  The kernels that carry the node through the search (DIRECT)
-    // then run phase 2 on the lanes' own nodes at once, a second instance of the phase-2 lambda: every lane with an inside
-    // node keeps one of its two, the other — where both are inside — is queued (at most 64 entries: they always fit), and
-    // the slab is consumed.  The others do NOT consume the slab: what is queued is drained as a (short) batch first and
-    // the slab is classified again with the queue empty.  (Until round 3 the second half waited in five registers that
-    // were live through phase 2, which the kernel does not have.  Round 4, profiles/r04_ar_ab_direct.txt: headline -2.3 %,
-    // L = 7 / 16 -3.6 %, L = 8 / 20 -6.4 %, L = 6 / 32 -2.3 %; written as ONE phase 2 with a second entry the same idea
-    // cost every kernel 2-14 registers and was dropped; so was filling the queue with the first nodes of the slab and
-    // classifying it again for the rest — the number of batches per pair does not change, r04_am_ab_queue2.txt.)
+    // slab of a deeply overlapping pair on top of a leftover.  Phase 2 then runs on the lanes' own nodes at once (DIRECT), a
+    // second instance of the phase-2 lambda: every lane with an inside node keeps one of its two, the other — where both
+    // are inside — is queued (at most 64 entries: they always fit), and the slab is consumed.  (SHP_DIRECT(L) = 0 is the
+    // kernel before: the slab is NOT consumed, what is queued is drained as a (short) batch first and the slab is
+    // classified again with the queue empty.  Until round 3 the second half waited in five registers that were live
+    // through phase 2, which the kernel does not have.  Round 4, profiles/r04_ar_ab_direct.txt, r04_as_ab_direct2.txt:
+    // headline -2.3 %, L = 7 / 16 -3.6 %, L = 8 / 20 -6.4 %, L = 6 / 32 -2.3 %, L = 2 / 16 -3.9 %, L = 5 / 24 -2.6 %; written
+    // as ONE phase 2 with a second entry the same idea cost every kernel 2-14 registers and was dropped; so was filling
+    // the queue with the first nodes of the slab and classifying it again for the rest — the number of batches per pair
+    // does not change, r04_am_ab_queue2.txt.)
 #define SHP_PUSH(m_, pn, rin_, rjn_)                                                                                  \
     {                                                                                                                  \
       if (m_ != 0ULL) {                                                                                                \
