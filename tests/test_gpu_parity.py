@@ -632,7 +632,8 @@ def test_ring_groups_do_not_change_the_result(oracle, lmax, nq, rows):
     sp.close()
 
 
-@pytest.mark.parametrize("lmax,nq,spacing", [(6, 16, 1.6), (6, 24, 1.7), (8, 20, 1.7), (12, 32, 1.75), (5, 16, 1.6)])
+@pytest.mark.parametrize("lmax,nq,spacing", [(6, 16, 1.6), (6, 24, 1.7), (8, 20, 1.7), (12, 32, 1.75), (5, 16, 1.6), (2, 16, 1.6), (4, 20, 1.6),
+                                                (9, 12, 1.6), (0, 16, 1.5)])
 def test_dense_slabs_and_the_node_queue(oracle, lmax, nq, spacing):
     """Deeply overlapping pairs: the central slabs of a cap are full of inside nodes and do not always fit the node
     queue on top of a leftover (the slab is then classified a second time).  With the queue at its 128 entries and with
