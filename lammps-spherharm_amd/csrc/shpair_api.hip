@@ -419,7 +419,11 @@ static bool use_split(const shpair_ctx* c, const bool jpoly)
   // kernels with their ring groups re-sized, r03_fin_split_matrix.txt; the boxes' noise is +-3 %): two waves win at
   // n_q = 32 from L = 8 on (0...-7 %), at n_q = 24 from L = 11 on (-3 %; L = 10: +2.5 %) and at L = 12 from n_q = 16
   // on (-11 %); they lose below (at n_q = 8 half of each wave's lanes have no node pair: +40 %)
-  return (c->lmax >= 8 && c->nq >= 32) || (c->lmax >= 11 && c->nq >= 24) || (c->lmax >= 12 && c->nq >= 16);
+  // Round 4, end-of-round kernels (Horner ring tables, larger node queue, direct batches; profiles/r04_q5_sweep2.txt):
+  // with all 16 rings resident one wave beats two at L = 12 / n_q = 16 (-4.9 %), and one wave with 8-ring groups at
+  // L = 11 / n_q = 24 (-4.9 %); two waves keep n_q >= 32 from L = 8 (L = 9 / 32 -4.8 %) and L = 12 from n_q = 18
+  // (L = 12 / 20 -5.7 % against the best one-wave form)
+  return (c->lmax >= 8 && c->nq >= 32) || (c->lmax >= 12 && c->nq >= 18);
 }
 
 }  // extern "C"
@@ -718,10 +722,15 @@ int shp_compute_range(shpair_ctx* c, int nlocal, int nghost, const double* x, co
       // before sized the groups without j's table and left L = 9, n_q = 16 with groups of 14 + 2 rings: +6 %).  Known
       // exception: L = 8, n_q = 20, where 17 + 3 rings measured 4 % faster than the 10 + 10 this rule picks.
       const auto total = [&](const int r) { return wave_lds_layout(c->lmax, r, false, nqj).bytes; };
-      if (total(nq) > 11776) {
-        int step = 64, a = per_ring;
-        while (a) { const int t = step % a; step = a; a = t; }   // gcd(64, per_ring)
-        step = 64 / step;   // rings per whole number of slabs
+      int step = 64, a = per_ring;
+      while (a) { const int t = step % a; step = a; a = t; }   // gcd(64, per_ring)
+      step = 64 / step;   // rings per whole number of slabs
+      // Round 4 (profiles/r04_q5_sweep2.txt, r04_q5_ring_rows.txt; the table builds got cheaper, the node loops did not):
+      // one group up to 13 KB where the cap is four slabs (n_q <= 16: L = 11 / 16 -6.8 %, L = 12 / 16 -4.9 % with the one
+      // wave that goes with it), and up to 14.5 KB from L = 9 on where groups cannot end on slab boundaries (n_q = 20:
+      // L = 9 -3.6 %, L = 10 -3.2 %, L = 11 -2.7 %); n_q = 24 and 32 keep their aligned groups at those sizes
+      const int one_group_max = (2 * step <= nq) ? (nq <= 16 ? 13312 : 11776) : (c->lmax >= 9 ? 14848 : 11776);
+      if (total(nq) > one_group_max) {
         if (2 * step <= nq) {
           // groups that end on a slab boundary (no slab straddles a hand-over: at n_q = 24 every order measured,
           // L = 7...11, wants 8 rings = 3 slabs, not the 12 a budget alone gives): the largest such group within 10 KB
