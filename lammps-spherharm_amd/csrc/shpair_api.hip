@@ -395,15 +395,18 @@ int shpair_set_neighbors_device(shpair_ctx* c, int inum, const int* ilist, const
 // (JPT kernels + rotation kernel) or the body-frame Horner evaluation.  The first trades ~170 instructions and a
 // table build per pair for 60 fewer per radius evaluation: it wins unless a pair has very few cap nodes.  Option
 // "jpoly": 1 / 0 force, -1 (default) the measured rule (interleaved A/B over L = 0..12 x n_q = 4..32,
-// profiles/r02_y_jpoly_matrix.txt: the body-frame family is faster only at n_q = 4 from L = 6 and at n_q <= 8 from L = 9).
+// profiles/r02_y_jpoly_matrix.txt: the body-frame family was faster only at n_q = 4 from L = 6 and at n_q <= 8 from L = 9;
+// re-measured in round 4, below).
 static bool use_jpoly_at(const shpair_ctx* c, const int L)
 {
   if (L > kMaxUnrolledL || c->opt_variant == 1 || c->opt_rule) return false;
   if (c->opt_jpoly >= 0) return c->opt_jpoly == 1;
-  const int nq = c->nq;
-  if (L <= 5) return true;
-  if (L <= 8) return nq >= 6;
-  return nq >= 12;
+  // Round 4 (end-of-round kernels, profiles/r04_q6_jpoly_small_nq.txt, r04_q6_jpoly_tiny_nq.txt): the per-azimuth family
+  // has caught up everywhere but at L >= 11 with n_q <= 5 (L = 12 / 4 +3 %, L = 11 / 5 +3 %, L = 12 / 1 +16 %) — round 2's
+  // rule kept the body-frame kernels at n_q < 6 from L = 6 and at n_q < 12 from L = 9, where they now lose by 5...28 %
+  // (L = 9 / 10 3.10 -> 2.24 ms, L = 12 / 10 4.41 -> 3.29, L = 8 / 4 1.90 -> 1.55, L = 6 / 4 1.25 -> 1.09)
+  if (L >= 11) return c->nq >= 6;
+  return true;
 }
 static bool use_jpoly(const shpair_ctx* c) { return use_jpoly_at(c, c->lmax); }
 
