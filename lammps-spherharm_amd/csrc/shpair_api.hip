@@ -402,10 +402,10 @@ static bool use_jpoly_at(const shpair_ctx* c, const int L)
   if (L > kMaxUnrolledL || c->opt_variant == 1 || c->opt_rule) return false;
   if (c->opt_jpoly >= 0) return c->opt_jpoly == 1;
   // Round 4 (end-of-round kernels, profiles/r04_q6_jpoly_small_nq.txt, r04_q6_jpoly_tiny_nq.txt): the per-azimuth family
-  // has caught up everywhere but at L >= 11 with n_q <= 5 (L = 12 / 4 +3 %, L = 11 / 5 +3 %, L = 12 / 1 +16 %) — round 2's
+  // has caught up everywhere but at L >= 10 with n_q <= 5 (L = 12 / 4 +3 %, L = 11 / 5 +3 %, L = 12 / 1 +16 %) — round 2's
   // rule kept the body-frame kernels at n_q < 6 from L = 6 and at n_q < 12 from L = 9, where they now lose by 5...28 %
   // (L = 9 / 10 3.10 -> 2.24 ms, L = 12 / 10 4.41 -> 3.29, L = 8 / 4 1.90 -> 1.55, L = 6 / 4 1.25 -> 1.09)
-  if (L >= 11) return c->nq >= 6;
+  if (L >= 10) return c->nq >= 6;   // (L = 10 / 3, 4, 5: the body-frame kernels 3.5...4.5 % faster, r04_q7_sweep4.txt)
   return true;
 }
 static bool use_jpoly(const shpair_ctx* c) { return use_jpoly_at(c, c->lmax); }
@@ -426,7 +426,13 @@ static bool use_split(const shpair_ctx* c, const bool jpoly)
   // with all 16 rings resident one wave beats two at L = 12 / n_q = 16 (-4.9 %), and one wave with 8-ring groups at
   // L = 11 / n_q = 24 (-4.9 %); two waves keep n_q >= 32 from L = 8 (L = 9 / 32 -4.8 %) and L = 12 from n_q = 18
   // (L = 12 / 20 -5.7 % against the best one-wave form)
-  return (c->lmax >= 8 && c->nq >= 32) || (c->lmax >= 12 && c->nq >= 18);
+  // ... and, from L = 9, n_q >= 22 where one wave's ring groups cannot end on slab boundaries (n_q = 22, 26, 28, 30; not
+  // 24): L = 11 / 22 -13 %, L = 9 / 26 -7.7 %, L = 9 / 28 -6.1 %, L = 11 / 26 -5.0 %, L = 10 / 22 -4.2 %
+  // (profiles/r04_q7_sweep4.txt)
+  int g = 64, a = c->nq;
+  while (a) { const int t = g % a; g = a; a = t; }   // gcd(64, n_q): a one-wave slab spans 64 / g rings
+  const bool aligned1 = 2 * (64 / g) <= c->nq;
+  return (c->lmax >= 8 && c->nq >= 32) || (c->lmax >= 12 && c->nq >= 18) || (c->lmax >= 9 && c->nq >= 22 && !aligned1);
 }
 
 }  // extern "C"
