@@ -705,6 +705,26 @@ def test_loop_kernel_forced_for_a_compiled_order_and_the_timing_option(oracle, l
     sp.close()
 
 
+@pytest.mark.parametrize("lmax,nq,family,waves", [(11, 16, 1, 1), (12, 16, 1, 1), (9, 20, 1, 1), (11, 20, 1, 1), (12, 20, 1, 2), (11, 22, 1, 2),
+                                                   (9, 26, 1, 2), (11, 24, 1, 1), (12, 24, 1, 2), (9, 10, 1, 1), (12, 10, 1, 1), (8, 4, 1, 1),
+                                                   (10, 5, 0, 1), (12, 4, 0, 1), (10, 6, 1, 1), (8, 32, 1, 2), (7, 32, 1, 1)])
+def test_the_library_s_own_choice_of_kernel_at_the_boundaries_of_its_rules(oracle, lmax, nq, family, waves):
+    """With every option left alone: the kernel family, one or two waves per pair and the ring groups the measured rules
+    pick (shpair_api.hip: use_jpoly_at, use_split, the ring-row rule) on either side of their boundaries — against the
+    oracle, and the choice itself as the rules of round 4 make it."""
+    case = make_case(80, lmax, 2, seed=110 + lmax + nq, rmax_fn=oracle.shape_rmax)
+    K, E = coeff_tables(1, 1000.0, 1.25)
+    sp = make_ctx(case, nq, K, E)
+    b = case["bed"]
+    f, tq, eng, _ = sp.compute(case["n"], b["x"], b["quat"], b["type"], b["shtype"], eflag=True)
+    o = oracle_compute(oracle, case, nq, K, E, eflag=True)
+    check(f, tq, o)
+    assert abs(eng - o["eng_virial"][0]) < TOL * abs(o["eng_virial"][0])
+    k = sp.kernel_info()
+    assert (k["family"], k["waves_per_pair"]) == (family, waves) and k["scratch_bytes"] == 0
+    sp.close()
+
+
 def test_non_finite_inputs_terminate(oracle):
     """inf coordinates and zero quaternions must not hang the kernel (every loop is bounded) and must not disturb pairs
     they are not part of; a NaN coordinate makes its pairs' separation not a number, which docs/SPEC.md 2 step 1 treats
