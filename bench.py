@@ -33,9 +33,13 @@ Prints ONE JSON line on rank 0 (fields: DESIGN.md §7).
 import argparse
 import json
 import os
+import re
+import signal
 import sys
 import threading
 import time
+
+T_START = time.monotonic()    # the whole-run bound (--total-s) counts from here
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "lammps-spherharm_amd"))
@@ -99,8 +103,20 @@ def parse():
     ap.add_argument("--launch", action="store_true", help="with --gpus 1 --multi: go through the self-launcher (this process starts "
                     "the rank as a fresh child, as `--gpus N` without a launcher does for N > 1)")
     ap.add_argument("--scale-ref", type=int, default=1, help="N = 1 default line: add the `scale_ref` object (0 = skip)")
-    ap.add_argument("--wait-s", type=float, default=240.0, help="bound of every wait on another rank (rendezvous, "
-                    "ncclCommInitRank, barriers); the whole multi-rank run is bounded by 6 x this")
+    ap.add_argument("--wait-s", type=float, default=75.0, help="bound of every wait on another rank (rendezvous, "
+                    "ncclCommInitRank, first build, verification, barriers; warm-up and timed steps get 2 x this)")
+    ap.add_argument("--total-s", type=float, default=540.0, help="bound of the WHOLE run, counted from the start of this process "
+                    "(the driver ends a bench step after 600 s without a word: before that, the process that owns the JSON line "
+                    "prints one with an `error` field naming the phase and the rank, and exits 4); 0 = none")
+    ap.add_argument("--verify-overlap", dest="verify_overlap", action="store_true", default=None,
+                    help="N > 1: run 4 timesteps from one saved state with halo_overlap 0 and with the run's value, compare owned "
+                         "positions / forces / torques by tag (1e-9), time both, and fall back to 0 when they differ (default on)")
+    ap.add_argument("--no-verify-overlap", dest="verify_overlap", action="store_false")
+    ap.add_argument("--ab-steps", type=int, default=12, help="N > 1: timesteps of each leg of the in-run halo_overlap A/B")
+    ap.add_argument("--configs", type=int, default=1, help="N = 1 default line: add the `configs` object (BASELINE configs[2], "
+                    "configs[4] and configs[0]'s shape at scale: 3 warm-up + 5 timed steps each, after the headline; 0 = skip)")
+    ap.add_argument("--host-path", type=int, default=1, help="N = 1 default line: add the `host_path` object (what an unmodified "
+                    "LAMMPS pays: shpair_compute on pinned host arrays, shpair_set_neighbors from firstneigh rows; 0 = skip)")
     ap.add_argument("--ramp", type=int, default=8, help="extra untimed passes before the W warm-up steps: the first "
                     "~8 launches of a fresh process run up to 25 %% slower while the GPU clock ramps (rocprof per-launch "
                     "durations in profiles/); they are never part of the K timed steps")
@@ -114,7 +130,7 @@ def parse():
     ap.add_argument("--halo-overlap", type=int, default=-1, choices=[-1, 0, 1, 2],
                     help="N > 1: option \"halo_overlap\" (1: the forward exchange runs on a stream of its own beside the pair "
                          "kernels of the slots that touch owned atoms only; 2: the reverse exchange hidden too, beside the second half of "
-                         "those slots); -1 = the library's default")
+                         "those slots); -1 = auto: 2 if the in-run check against 0 passes AND the in-run A/B says it is not slower, else 0")
     ap.add_argument("--one-device", action="store_true", help="N > 1 with --transport rccl: every rank uses GPU 0 (only to probe "
                     "what RCCL does with several ranks on one device; RCCL normally refuses)")
     a = ap.parse_args()
@@ -123,31 +139,94 @@ def parse():
         a.particles = 125000 if multi else 100000
     if a.verify is None:
         a.verify = multi and a.transport == "rccl"
+    if a.verify_overlap is None:
+        a.verify_overlap = multi
     return a
+
+
+def error_line(args, what):
+    """The JSON line of a run that did not produce a measurement: same envelope, `value` null, `error` says which
+    phase on which rank gave up.  Printed by whoever owns stdout's line (rank 0, or the self-launcher's parent)."""
+    return json.dumps({"metric": "contact_pairs_per_sec", "value": None, "unit": "contact-pairs/s", "n_gpus": args.gpus,
+                       "steps": args.steps, "warmup": args.warmup, "ms_per_step": None, "higher_is_better": True,
+                       "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic", "error": what,
+                       "elapsed_s": round(time.monotonic() - T_START, 1)})
+
+
+def _kfd_gpu_nodes():
+    """Number of GPU nodes the kernel driver exposes, read from sysfs — no HIP / HSA call, so a parent that only wants
+    to know whether starting GPU children makes sense stays free of any GPU context (torch.cuda.device_count() falls
+    back to hipGetDeviceCount when amdsmi is not usable).  0 when the KFD topology is absent (ROCr itself enumerates
+    from it: no topology, no device); None when it is there but unreadable (unknown: let the child find out)."""
+    top = "/sys/class/kfd/kfd/topology/nodes"
+    if not os.path.isdir(top):
+        return 0
+    n = 0
+    try:
+        for node in os.listdir(top):
+            with open(os.path.join(top, node, "properties")) as fh:
+                for ln in fh:
+                    if ln.startswith("simd_count"):
+                        n += 1 if int(ln.split()[1]) > 0 else 0
+                        break
+    except (OSError, ValueError):
+        return None
+    return n
 
 
 class Watchdog:
     """Bounded waits: a daemon thread that ends the process (message on stderr, exit code 4) when the phase that was
-    declared with `phase(what, seconds)` has not been left in time.  The calls it guards sit in C (ncclCommInitRank,
-    gloo collectives, hipStreamSynchronize behind an ncclRecv whose sender died) and cannot be interrupted from
-    Python; RCCL itself has no timeout.  os._exit, not an exec: the GPU is initialised."""
+    declared with `phase(what, seconds)` has not been left in time, or when the whole run has lasted --total-s.  The
+    calls it guards sit in C (ncclCommInitRank, gloo collectives, hipStreamSynchronize behind an ncclRecv whose sender
+    died) and cannot be interrupted from Python; RCCL itself has no timeout.  os._exit, not an exec: the GPU is
+    initialised.  `emit`: this process owns the JSON line on stdout (rank 0) and prints one with an `error` field
+    before it leaves.  watch_sigterm(): a launcher that ends this rank because ANOTHER rank failed (torch.distributed.run
+    sends SIGTERM) gets the same courtesy — the C-level signal handler writes to a wake-up pipe that a thread of its
+    own reads, so it works while the main thread sits in a C call that never returns."""
 
-    def __init__(self):
+    def __init__(self, args=None, emit=False):
+        self.args, self.emit = args, emit
         self._lock = threading.Lock()
-        self._deadline, self._what = None, ""
+        self._deadline, self._what = None, "start-up"
+        self._total = (T_START + args.total_s) if (args is not None and getattr(args, "total_s", 0) > 0) else None
         t = threading.Thread(target=self._loop, daemon=True)
         t.start()
 
+    def _leave(self, why, code):
+        rank = os.environ.get("RANK", "0")
+        with self._lock:
+            w = self._what
+        msg = f"rank {rank}: '{w}' {why}"
+        print(f"bench.py: {msg}; giving up with exit code {code}", file=sys.stderr, flush=True)
+        if self.emit and self.args is not None:
+            print(error_line(self.args, msg), flush=True)
+        os._exit(code)
+
     def _loop(self):
         while True:
-            time.sleep(0.5)
+            time.sleep(0.25)
             with self._lock:
-                d, w = self._deadline, self._what
-            if d is not None and time.monotonic() > d:
-                rank = os.environ.get("RANK", "0")
-                print(f"bench.py: rank {rank}: '{w}' did not finish in time (another rank lost, or RCCL / gloo cannot "
-                      "reach its peers); giving up with exit code 4", file=sys.stderr, flush=True)
-                os._exit(4)
+                d = self._deadline
+            now = time.monotonic()
+            if d is not None and now > d:
+                self._leave("did not finish in time (another rank lost, or RCCL / gloo cannot reach its peers)", 4)
+            if self._total is not None and now > self._total:
+                self._leave(f"was still running when the whole-run bound of {self.args.total_s:.0f} s passed", 4)
+
+    def watch_sigterm(self):
+        """Main thread only."""
+        r, w = os.pipe()
+        os.set_blocking(w, False)
+        signal.signal(signal.SIGTERM, lambda *_: None)    # a Python-level handler, so that the C handler feeds the pipe
+        signal.set_wakeup_fd(w, warn_on_full_buffer=False)
+
+        def _wait():
+            while True:
+                b = os.read(r, 1)
+                if b and b[0] == signal.SIGTERM:
+                    self._leave("was interrupted by SIGTERM (the launcher ends every rank when one of them fails: see that "
+                                "rank's message on stderr)", 143)
+        threading.Thread(target=_wait, daemon=True).start()
 
     def phase(self, what, seconds):
         wd = self
@@ -204,7 +283,7 @@ def roofline_objects(args, sp, n_contact, kernel_ms, world):
     # is the static PMC table's entry a measurement of the code that just ran?  (hash of the kernel's machine code + the
     # launch shape; tools/pmc_table.py stores both with every entry)
     stale = None
-    if ent:
+    if ent and khash is not None and ent.get("kernel_hash") is not None:   # no hash on either side: nothing was compared -> unknown
         stale = not (ent.get("kernel_hash") == khash and ent.get("ring_rows") == ki["ring_rows"]
                      and ent.get("waves_per_pair") == ki["waves_per_pair"])
     roof = {
@@ -236,7 +315,7 @@ def roofline_objects(args, sp, n_contact, kernel_ms, world):
     util = {"source": src, "stale": stale,
             "stale_note": "false: the table entry was measured on this very contact-kernel code (SHA-256 of its machine code, "
                           "occupancy.kernel_hash) with the same ring groups / waves per pair; true: on another build — re-run "
-                          "tools/pmc_run.sh; null: no entry"}
+                          "tools/pmc_run.sh; null: no entry, or no hash on one side (nothing was compared)"}
     if ent:
         util["measured_on"] = {k: ent.get(k) for k in ("kernel_hash", "commit", "ring_rows", "waves_per_pair")}
         for k in ("valu_busy", "lds_busy", "lds_bank_conflict_share", "fp64_instr_share", "int32_instr_share", "valu_instr_per_pair",
@@ -254,13 +333,91 @@ def roofline_objects(args, sp, n_contact, kernel_ms, world):
     return roof, valu, occ, util
 
 
+class StaticBed:
+    """One static-bed workload of BASELINE.json (configs[1], [2], [4], and configs[0]'s shape at scale) resident in HBM:
+    shapes, context, bed, half list, the atom arrays, and the step that is timed — initial_integrate -> clear f /
+    torque -> shpair_compute_device() -> final_integrate."""
+
+    def __init__(self, args, passes):
+        import torch
+        from shpair import shapes, bed
+        self.torch, self.args = torch, args
+        dev = torch.device("cuda", 0)
+        lmax, nshapes = args.lmax, args.nshapes
+        self.shp = [shapes.random_shape(lmax, bed.SEED0 + 2 + s) for s in range(nshapes)]
+        self.sp = sp = make_ctx(args, self.shp, 0)
+        self.rmax = [sp.rmax(s) for s in range(nshapes)]
+        self.gbed = gbed = bed.make_bed(args.particles, self.rmax, nshapes, seed=bed.SEED0 + 2)
+        self.nlocal = nall = args.particles
+        self.il, self.of, self.jl = bed.half_neighbor_list(gbed["x"], gbed["shtype"], self.rmax)
+        sp.set_neighbors_csr(self.il, self.of, self.jl)
+        self.x = torch.from_numpy(gbed["x"]).to(dev)
+        self.q = torch.from_numpy(gbed["quat"]).to(dev)
+        self.ty = torch.from_numpy(gbed["type"]).to(dev)
+        self.sh = torch.from_numpy(gbed["shtype"]).to(dev)
+        self.f = torch.zeros(nall, 3, dtype=torch.float64, device=dev)
+        self.tq = torch.zeros_like(self.f)
+        self.stream = torch.cuda.current_stream()
+        # the integrator either side of the hot path (include/shstep.h).  The bed starts at rest and dt is sized so that
+        # nothing moves further than 1e-2 of the neighbour skin during the whole run: the half list (and the
+        # contact-pair count) stay valid without a rebuild.
+        self.v = torch.zeros(self.nlocal, 3, dtype=torch.float64, device=dev)
+        self.angmom = torch.zeros_like(self.v)
+        self.mask = torch.ones(self.nlocal, dtype=torch.int32, device=dev)
+        self.dt = min(1.0e-4, 4.0e-3 / (passes + 1))
+
+    def integrate(self, phase):
+        self.sp.nve_device(phase, self.nlocal, self.dt, self.x.data_ptr(), self.v.data_ptr(), self.q.data_ptr(), self.angmom.data_ptr(),
+                           self.f.data_ptr(), self.tq.data_ptr(), self.sh.data_ptr(), self.mask.data_ptr(), stream=self.stream.cuda_stream)
+
+    def step(self, events=None):
+        self.integrate(0)
+        self.f.zero_()
+        self.tq.zero_()
+        if events:
+            events[0].record(self.stream)   # HIP events on the stream the pair kernel is launched on
+        self.sp.compute_device(self.nlocal, 0, self.x.data_ptr(), self.q.data_ptr(), self.ty.data_ptr(), self.sh.data_ptr(),
+                               self.f.data_ptr(), self.tq.data_ptr(), stream=self.stream.cuda_stream)
+        if events:
+            events[1].record(self.stream)
+        self.integrate(1)
+
+    def count(self):
+        """untimed: the contact pairs of this bed (static positions)"""
+        self.sp.set_option("count", 1)
+        self.step()
+        self.torch.cuda.synchronize()
+        st = self.sp.stats()
+        self.sp.set_option("count", 0)
+        return st["n_contact"], st["n_touching"]
+
+    def timed(self, untimed, steps):
+        """`untimed` passes, then exactly `steps` steps between two synchronize: (seconds, mean kernel ms per step)."""
+        torch = self.torch
+        for _ in range(untimed):
+            self.step()
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(steps):
+            self.step(ev[k])
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        fh = self.f[:self.nlocal].cpu().numpy()
+        assert np.all(np.isfinite(fh)) and np.abs(fh).max() > 0
+        return elapsed, float(np.mean([a.elapsed_time(b) for a, b in ev]))
+
+    def close(self):
+        self.sp.close()
+
+
 # ======================================================================================================== N = 1
 def main_single(args):
     import torch
-    from shpair import shapes, bed
-    if torch.cuda.device_count() < 1:    # counting devices does not initialise the GPU
+    if _kfd_gpu_nodes() == 0:    # sysfs only: the parent makes no HIP / HSA call before the scale_ref child has come and gone
         print("bench.py: no GPU visible; the HIP path has no CPU fallback", file=sys.stderr)
         sys.exit(3)
+    wd = Watchdog(args, emit=True)   # only the whole-run bound: one GPU, no peer to wait for
     scale_ref = scale_ref_leg(args) if args.scale_ref else None   # a fresh child process, before this one's first GPU call
     if scale_ref is not None:
         # the child has just released ~2 GB of HBM: the driver frees it in the background; twice in ~40 builder runs a
@@ -270,69 +427,12 @@ def main_single(args):
         print("bench.py: no GPU visible; the HIP path has no CPU fallback", file=sys.stderr)
         sys.exit(3)
     torch.cuda.set_device(0)
-    dev = torch.device("cuda", 0)
     lmax, nq, nshapes = args.lmax, args.nq, args.nshapes
-    shp = [shapes.random_shape(lmax, bed.SEED0 + 2 + s) for s in range(nshapes)]
-    sp = make_ctx(args, shp, 0)
-    rmax = [sp.rmax(s) for s in range(nshapes)]
-    gbed = bed.make_bed(args.particles, rmax, nshapes, seed=bed.SEED0 + 2)
-    nlocal = nall = args.particles
-    il, of, jl = bed.half_neighbor_list(gbed["x"], gbed["shtype"], rmax)
-    sp.set_neighbors_csr(il, of, jl)
-
-    x = torch.from_numpy(gbed["x"]).to(dev)
-    q = torch.from_numpy(gbed["quat"]).to(dev)
-    ty = torch.from_numpy(gbed["type"]).to(dev)
-    sh = torch.from_numpy(gbed["shtype"]).to(dev)
-    f = torch.zeros(nall, 3, dtype=torch.float64, device=dev)
-    tq = torch.zeros_like(f)
-    stream = torch.cuda.current_stream()
-    # the integrator either side of the hot path (include/shstep.h).  The bed starts at rest and dt is sized so that
-    # nothing moves further than 1e-2 of the neighbour skin during the whole run: the half list (and the
-    # contact-pair count) stay valid without a rebuild.
-    v = torch.zeros(nlocal, 3, dtype=torch.float64, device=dev)
-    angmom = torch.zeros_like(v)
-    mask = torch.ones(nlocal, dtype=torch.int32, device=dev)
-    dt = min(1.0e-4, 4.0e-3 / (args.steps + args.warmup + args.ramp + 1))
-
-    def integrate(phase):
-        sp.nve_device(phase, nlocal, dt, x.data_ptr(), v.data_ptr(), q.data_ptr(), angmom.data_ptr(), f.data_ptr(),
-                      tq.data_ptr(), sh.data_ptr(), mask.data_ptr(), stream=stream.cuda_stream)
-
-    def step(events=None):
-        integrate(0)
-        f.zero_()
-        tq.zero_()
-        if events:
-            events[0].record(stream)   # HIP events on the stream the pair kernel is launched on
-        sp.compute_device(nlocal, 0, x.data_ptr(), q.data_ptr(), ty.data_ptr(), sh.data_ptr(), f.data_ptr(), tq.data_ptr(),
-                          stream=stream.cuda_stream)
-        if events:
-            events[1].record(stream)
-        integrate(1)
-
-    # ---- untimed: count the contact pairs of this bed (static positions)
-    sp.set_option("count", 1)
-    step()
-    torch.cuda.synchronize()
-    st = sp.stats()
-    n_contact, n_touching = st["n_contact"], st["n_touching"]
-    sp.set_option("count", 0)
-    for _ in range(args.ramp + args.warmup):
-        step()
-
-    # ---- timed region: exactly K steps between synchronize
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        step(ev[k])
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
-
-    fh = f[:nlocal].cpu().numpy()
-    assert np.all(np.isfinite(fh)) and np.abs(fh).max() > 0
+    sb = StaticBed(args, args.steps + args.warmup + args.ramp)
+    sp = sb.sp
+    n_contact, n_touching = sb.count()
+    # ---- timed region: exactly K steps between synchronize (StaticBed.timed)
+    elapsed, kernel_ms = sb.timed(args.ramp + args.warmup, args.steps)
 
     roof, valu, occ, util = roofline_objects(args, sp, n_contact, kernel_ms, 1)
     out = {
@@ -347,23 +447,155 @@ def main_single(args):
                         "inputs resident in HBM",
             "particles_per_gpu": args.particles, "lmax": lmax, "nq": nq, "nshapes": nshapes,
             "exponent": args.exponent, "rule": args.rule, "proc_grid": [1, 1, 1], "backend": "none",
-            "half_list_pairs_rank0": int(jl.size), "contact_pairs_rank0": int(n_contact),
+            "half_list_pairs_rank0": int(sb.jl.size), "contact_pairs_rank0": int(n_contact),
             "touching_pairs_rank0": int(n_touching), "contact_pairs_all_ranks": int(n_contact), "ghost_atoms_rank0": 0,
         },
         "timesteps_per_sec": args.steps / elapsed,
         "timestep_note": "one step = initial_integrate + clear + pair compute + final_integrate, "
-                         f"dt = {dt:g} from rest, no list rebuild inside the timed steps (see the `timestep` object for whole "
+                         f"dt = {sb.dt:g} from rest, no list rebuild inside the timed steps (see the `timestep` object for whole "
                          "steps with rebuilds)",
         "roofline": roof, "occupancy": occ, "valu_f64": valu, "utilisation": util, "library": _library_name(),
     }
+    # everything below comes AFTER the headline's timed region and cannot disturb it
+    if args.host_path:
+        try:
+            out["host_path"] = host_path_leg(args, sb, kernel_ms)
+        except Exception as e:  # noqa: BLE001 — an extra leg never takes the headline with it
+            out["host_path"] = {"error": repr(e)}
+    if args.configs:
+        out["configs"] = configs_leg(args)
     if args.ts_steps > 0:
-        out["timestep"] = timestep_leg(args, shp)
+        out["timestep"] = timestep_leg(args, sb.shp)
     if scale_ref is not None:
         out["scale_ref"] = scale_ref
     if args.cpu_seconds > 0:
-        out["cpu_baseline"] = cpu_baseline(args, shp, rmax, gbed, il, of, jl)
+        out["cpu_baseline"] = cpu_baseline(args, sb.shp, sb.rmax, sb.gbed, sb.il, sb.of, sb.jl)
+    out["elapsed_s"] = round(time.monotonic() - T_START, 1)
     print(json.dumps(out), flush=True)
     sp.close()
+    del wd
+
+
+CONFIG_LEGS = (
+    ("configs[2]", "100k particles, 4 mixed SH shape types L_max=6, n_q=16", dict(nshapes=4, lmax=6, nq=16)),
+    ("configs[4]", "100k particles, L_max=12 high-order shape, n_q=32", dict(nshapes=1, lmax=12, nq=32)),
+    ("configs[0]-shape", "configs[0]'s L_max=4 / n_q=10 at 100k particles (configs[0] itself is the 1000-particle CPU case: "
+                         "tests/golden/cfg1_L4_ellipsoid.npz)", dict(nshapes=1, lmax=4, nq=10)),
+)
+
+
+def configs_leg(args, warm=3, steps=5):
+    """The other single-GPU workloads of BASELINE.json, each through the very code of the headline (StaticBed): 3 warm-up
+    + 5 timed steps, a few seconds in all, run after the headline's timed region.  Numbers of a 5-step sample: they
+    put every BASELINE config into the driver's own record; the headline stays the K-step figure."""
+    out = {"steps": steps, "warmup": warm,
+           "note": "same step as the headline (initial_integrate + clear + pair compute + final_integrate), same bed generator and "
+                   "force law (kn=1000, exponent as --exponent), fresh context per workload; valu_f64_frac / roofline_frac as in the "
+                   "headline's objects; utilisation from the static PMC table with its own `stale` flag"}
+    for key, what, over in CONFIG_LEGS:
+        a2 = argparse.Namespace(**{**vars(args), **over, "particles": 100000, "jpoly": -1, "rule": "sharp", "peak_ms": 0.0})
+        try:
+            sb = StaticBed(a2, warm + steps + 1)
+            nc, nt = sb.count()
+            el, kms = sb.timed(warm, steps)
+            roof, valu, occ, util = roofline_objects(a2, sb.sp, nc, kms, 1)
+            out[key] = {
+                "workload": what, "lmax": a2.lmax, "nq": a2.nq, "nshapes": a2.nshapes, "exponent": a2.exponent,
+                "value": nc * steps / el, "unit": "contact-pairs/s", "ms_per_step": 1e3 * el / steps, "kernel_ms": kms,
+                "contact_pairs": int(nc), "touching_pairs": int(nt),
+                "valu_f64_frac": valu["frac"], "roofline_frac": roof["frac"], "traffic": roof["traffic"], "stale": roof["stale"],
+                "waves_per_pair": occ["waves_per_pair"], "waves_per_cu": occ["waves_per_cu"], "vgprs": occ.get("vgprs"),
+                "ring_rows": occ["ring_rows"], "family": occ["family"], "kernel_hash": occ["kernel_hash"],
+                "utilisation": {k: util.get(k) for k in ("valu_busy", "lds_busy", "fp64_instr_share", "valu_instr_per_pair",
+                                                         "fp64_executed_frac_of_peak", "stale", "source")},
+            }
+            sb.close()
+            del sb
+        except Exception as e:  # noqa: BLE001 — an extra leg never takes the headline with it
+            out[key] = {"workload": what, "error": repr(e)}
+    return out
+
+
+def host_path_leg(args, sb, kernel_ms_device, calls=7):
+    """What an UNMODIFIED LAMMPS pays on top of the kernels (north_star's boundary: PairSH::compute on host arrays): per
+    call, shpair_compute() with LAMMPS-layout host arrays page-locked by shpair_pin_host (x, quat, type, shtype up;
+    f, torque up, added to on the device, down) — wall time minus the kernels' time = the staging overhead; and, per
+    reneighbouring, shpair_set_neighbors(inum, ilist, numneigh, firstneigh) from real per-row pointers (flatten into the
+    pinned stage + one upload + expansion on the device).  Never part of `value`."""
+    import ctypes as C
+    from shpair import capi
+    g = sb.gbed
+    n = sb.nlocal
+    sp = make_ctx(args, sb.shp, 0)
+    lib = capi.load_library()
+    il = np.ascontiguousarray(sb.il, dtype=np.int32)
+    of = np.ascontiguousarray(sb.of, dtype=np.int32)
+    jl = np.ascontiguousarray(sb.jl, dtype=np.int32)
+    # LAMMPS' NeighList: numneigh and firstneigh are indexed by ATOM, firstneigh[i] points at row i's neighbours
+    numneigh = np.zeros(n, dtype=np.int32)
+    numneigh[il] = np.diff(of)
+    rows = np.zeros(n, dtype=np.uint64)
+    rows[il] = jl.ctypes.data + 4 * of[:-1].astype(np.uint64)
+    ip = C.POINTER(C.c_int)
+    first = rows.ctypes.data_as(C.POINTER(ip))
+
+    def t_list(fn):
+        ts = []
+        for _ in range(5):
+            t = time.perf_counter()
+            rc = fn()
+            ts.append(1e3 * (time.perf_counter() - t))
+            assert rc == 0, rc
+        return min(ts), float(np.median(ts))
+    rows_min, rows_med = t_list(lambda: lib.shpair_set_neighbors(sp._h, il.size, il.ctypes.data_as(ip), numneigh.ctypes.data_as(ip), first))
+    csr_min, csr_med = t_list(lambda: lib.shpair_set_neighbors_csr(sp._h, il.size, il.ctypes.data_as(ip), of.ctypes.data_as(ip),
+                                                                      jl.ctypes.data_as(ip)))
+    rc = lib.shpair_set_neighbors(sp._h, il.size, il.ctypes.data_as(ip), numneigh.ctypes.data_as(ip), first)
+    assert rc == 0
+    sp.set_option("timing", 1)
+    x, q, ty, sh = (np.ascontiguousarray(g[k]) for k in ("x", "quat", "type", "shtype"))
+    fb, tb = np.zeros((n, 3)), np.zeros((n, 3))
+
+    def calls_ms(k):
+        w, km = [], []
+        for _ in range(k):
+            fb[:] = 0.0
+            tb[:] = 0.0
+            t = time.perf_counter()
+            sp.compute(n, x, q, ty, sh, f=fb, torque=tb)
+            w.append(1e3 * (time.perf_counter() - t))
+            km.append(sp.stats()["kernel_ms"])
+        return w, km
+    calls_ms(2)
+    w_page, k_page = calls_ms(3)
+    arrs = [x, q, ty, sh, fb, tb]
+    for a_ in arrs:
+        sp.pin_host(a_)
+    calls_ms(1)
+    w_pin, k_pin = calls_ms(calls)
+    for a_ in arrs:
+        sp.unpin_host(a_)
+    assert np.all(np.isfinite(fb)) and np.abs(fb).max() > 0
+    up = x.nbytes + q.nbytes + ty.nbytes + sh.nbytes + fb.nbytes + tb.nbytes
+    down = fb.nbytes + tb.nbytes
+    i_pin = int(np.argmin(w_pin))
+    i_page = int(np.argmin(w_page))
+    out = {
+        "workload": "the headline's bed and list (BASELINE configs[1]) through the HOST-pointer entry points of include/shpair.h, "
+                    "as lammps/pair_sh.cpp calls them",
+        "compute_call_ms_pinned": w_pin[i_pin], "compute_call_ms_pinned_median": float(np.median(w_pin)),
+        "compute_kernel_ms": k_pin[i_pin], "compute_overhead_ms_pinned": w_pin[i_pin] - k_pin[i_pin],
+        "compute_call_ms_pageable": w_page[i_page], "compute_overhead_ms_pageable": w_page[i_page] - k_page[i_page],
+        "contact_pairs_per_sec_pinned": None, "bytes_up_per_call": int(up), "bytes_down_per_call": int(down), "calls": calls,
+        "set_neighbors_ms": rows_min, "set_neighbors_ms_median": rows_med, "set_neighbors_csr_ms": csr_min,
+        "set_neighbors_bytes_uploaded": int(4 * (2 * il.size + 1 + jl.size)), "half_list_pairs": int(jl.size),
+        "device_resident_kernel_ms": kernel_ms_device,
+        "note": "PCIe-inclusive: a reported cost of the drop-in boundary, never `value`.  compute_overhead = wall time of one "
+                "shpair_compute() (upload, kernels, download, host-side synchronisation) minus the hipEvent time of its kernels; "
+                "set_neighbors = one call per reneighbouring, from firstneigh row pointers indexed by atom (min of 5 / median)",
+    }
+    sp.close()
+    return out
 
 
 def timestep_leg(args, shp):
@@ -425,17 +657,21 @@ def scale_ref_leg(args):
     argv = ["--gpus", "1", "--multi", "--particles", "125000", "--steps", str(args.steps), "--warmup", str(args.warmup),
             "--ramp", str(args.ramp), "--lmax", str(args.lmax), "--nq", str(args.nq), "--nshapes", str(args.nshapes),
             "--exponent", repr(float(args.exponent)), "--jpoly", str(args.jpoly), "--rule", args.rule, "--vthermal", repr(float(args.vthermal)),
-            "--no-verify", "--peak-ms", "0", "--wait-s", str(args.wait_s)]
+            "--no-verify", "--peak-ms", "0", "--wait-s", str(args.wait_s), "--halo-overlap", str(args.halo_overlap),
+            "--total-s", f"{max(20.0, min(3.0 * args.wait_s, 0.4 * args.total_s if args.total_s > 0 else 1e9)):.0f}"]
     try:
-        rc, out = run_rank_children(argv, 1, 3.0 * args.wait_s)
+        rc, out = run_rank_children(argv, 1, max(25.0, min(3.0 * args.wait_s, 0.4 * args.total_s if args.total_s > 0 else 1e9) + 5.0))
         lines = [ln for ln in out.splitlines() if ln.startswith("{")]
-        if rc != 0 or not lines:
+        ln = json.loads(lines[-1]) if lines else None
+        if ln is not None and ln.get("error"):
+            return {"error": ln["error"], "exit_code": rc}
+        if ln is None or (rc != 0 and ln.get("verify_overlap_ok") is not False):   # exit code 1 with a line: the overlap check failed, the line says so
             return {"error": f"child `bench.py {' '.join(argv)}` ended with exit code {rc} and {len(lines)} JSON line(s)"}
-        ln = json.loads(lines[-1])
         return {"value": ln["value"], "unit": ln["unit"], "ms_per_step": ln["ms_per_step"], "timesteps_per_sec": ln["timesteps_per_sec"],
                 "steps": ln["steps"], "particles": ln["config"]["particles_all_ranks"],
                 "contact_pairs": ln["config"]["contact_pairs_all_ranks"], "ghost_atoms": ln["config"]["ghost_atoms_rank0"],
-                "pair_kernel_ms": ln["roofline"]["kernel_ms"],
+                "pair_kernel_ms": ln["roofline"]["kernel_ms"], "overlap_used": ln.get("overlap_used"),
+                "verify_overlap_ok": ln.get("verify_overlap_ok"), "overlap_ab_ms": ln.get("overlap_ab_ms"),
                 "transport": ln["halo"]["transport"], "ranks_reported_by_transport": ln["halo"]["ranks_reported_by_transport"],
                 "rebuilds_in_timed_steps": ln["halo"]["rebuilds_in_timed_steps"][0], "workload": ln["config"]["workload"],
                 "library": ln.get("library"), "cmd": "python bench.py " + " ".join(argv),
@@ -508,53 +744,82 @@ class _Collective:
         return out
 
 
+def _cmp_owned(a, b, box):
+    """Largest deviation between two (tag, x, v, quat, f, torque) snapshots of one rank's owned atoms sorted by tag:
+    (|dx| / box edge, |df| and |dtorque| absolute, max |f| of the first) — inf when the two hold different atoms."""
+    if a[0].shape != b[0].shape or not np.array_equal(a[0], b[0]):
+        return float("inf"), float("inf"), 0.0
+    if a[0].size == 0:
+        return 0.0, 0.0, 0.0
+    ex = float(np.abs(a[1] - b[1]).max() / box)
+    ef = float(max(np.abs(a[4] - b[4]).max(), np.abs(a[5] - b[5]).max()))
+    return ex, ef, float(np.abs(a[4]).max())
+
+
 def multi_rank_body(args, rank, world, device, coll, hub, uid, result, wd=None):
     import torch
     from shpair import shapes, bed, mrank
-    wd = wd or Watchdog()
+    wd = wd or Watchdog(args)
+    setup = {}
+    t_lap = [time.perf_counter()]
+
+    def lap(name):
+        now = time.perf_counter()
+        setup[name] = round(now - t_lap[0], 3)
+        t_lap[0] = now
     torch.cuda.set_device(device)
     shp = [shapes.random_shape(args.lmax, bed.SEED0 + 2 + s) for s in range(args.nshapes)]
     sp = make_ctx(args, shp, device)
-    if args.halo_overlap >= 0:
-        sp.set_option("halo_overlap", args.halo_overlap)
+    # "halo_overlap": the run starts at 0 (the exchanges and the pair kernels follow each other on one stream); the
+    # candidate — 2 unless --halo-overlap names another — is used only after it has been checked against 0 IN THIS RUN
+    candidate = 2 if args.halo_overlap < 0 else args.halo_overlap
+    check_overlap = bool(args.verify_overlap) and candidate > 0
+    sp.set_option("halo_overlap", 0 if check_overlap else candidate)
     skin = 0.1
     grid = mrank.proc_grid(world)
     cfg = config4_bed(args, world, grid)
+    lap("bed_on_host")
     cut = 2.0 * max(sp.rmax(s) for s in range(args.nshapes)) + skin
     geo = mrank.plan_geometry(grid, cfg["lo"], cfg["hi"], cfg["periodic"], cut, rank)
     xw, owner = mrank.plan_owner(geo, cfg["x"])
     mine = owner == rank
+    lap("owner_plan")
     with wd.phase("ncclCommInitRank (shhalo_create_rccl)" if uid is not None else "shhalo_create_local", args.wait_s):
         halo = mrank.Halo(sp, rank, world, grid, cfg["lo"], cfg["hi"], cfg["periodic"], skin, hub=hub, unique_id_bytes=uid)
+    lap("comm_init")
     dt = 1.0e-3
     with wd.phase("first migration + ghost plan + list build + forces (RankRun)", args.wait_s):
         run = mrank.RankRun(sp, halo, xw[mine], cfg["quat"][mine], cfg["shtype"][mine], cfg["tag"][mine], v=cfg["v"][mine],
                             mask=cfg["mask"][mine], dt=dt, gravity=(0.0, 0.0, -1.0), device=f"cuda:{device}",
                             capacity=int(1.5 * mine.sum()) + 4096)
+    lap("first_build")
     verify_err = None
     if args.verify:
         with wd.phase("gather of the initial forces (verify)", args.wait_s):
             t, _, _, _, f0, tq0 = run.owned()
             parts = coll.gather(rank, (t, f0, tq0))
         if rank == 0:
-            from shpair.run import DeviceRun
-            ref_sp = make_ctx(args, shp, device)
-            ref = DeviceRun(ref_sp, cfg["x"], cfg["quat"], cfg["shtype"], cfg["lo"], cfg["hi"], cfg["periodic"], skin, mask=cfg["mask"],
-                            dt=dt, gravity=(0.0, 0.0, -1.0), device=f"cuda:{device}")
-            ref.v[:] = torch.from_numpy(cfg["v"]).to(ref.v.device)
-            ref.force()
-            torch.cuda.synchronize()
-            n = cfg["n"]
-            fr, tr = ref.f[:n].cpu().numpy(), ref.tq[:n].cpu().numpy()
-            fg, tg = np.zeros_like(fr), np.zeros_like(tr)
-            for t_, f_, q_ in parts:
-                fg[t_] = f_
-                tg[t_] = q_
-            verify_err = float(max(np.abs(fg - fr).max(), np.abs(tg - tr).max()) / np.abs(fr).max())
-            if not verify_err < 1e-9:   # reported in the line (verify_ok) and by the exit code; the run goes on so that every rank ends together
-                print(f"bench.py: decomposed forces differ from single-domain forces: rel err {verify_err}", file=sys.stderr, flush=True)
-            ref_sp.close()
-            del ref
+            with wd.phase("single-domain reference forces on rank 0 (verify)", args.wait_s):
+                from shpair.run import DeviceRun
+                ref_sp = make_ctx(args, shp, device)
+                ref = DeviceRun(ref_sp, cfg["x"], cfg["quat"], cfg["shtype"], cfg["lo"], cfg["hi"], cfg["periodic"], skin, mask=cfg["mask"],
+                                dt=dt, gravity=(0.0, 0.0, -1.0), device=f"cuda:{device}")
+                ref.v[:] = torch.from_numpy(cfg["v"]).to(ref.v.device)
+                ref.force()
+                torch.cuda.synchronize()
+                n = cfg["n"]
+                fr, tr = ref.f[:n].cpu().numpy(), ref.tq[:n].cpu().numpy()
+                fg, tg = np.zeros_like(fr), np.zeros_like(tr)
+                for t_, f_, q_ in parts:
+                    fg[t_] = f_
+                    tg[t_] = q_
+                verify_err = float(max(np.abs(fg - fr).max(), np.abs(tg - tr).max()) / np.abs(fr).max())
+                if not verify_err < 1e-9:   # reported in the line (verify_ok) and by the exit code; the run goes on so that every rank ends together
+                    print(f"bench.py: decomposed forces differ from single-domain forces: rel err {verify_err}", file=sys.stderr, flush=True)
+                ref_sp.close()
+                del ref
+        del parts
+        lap("verify")
 
     def count_contacts():
         sp.set_option("count", 1)
@@ -563,13 +828,66 @@ def multi_rank_body(args, rank, world, device, coll, hub, uid, result, wd=None):
         sp.set_option("count", 0)
         return st["n_contact"], st["n_touching"]
 
+    # ---- the path the timed steps take, checked in the run itself: from ONE saved state, k timesteps of shhalo_run_device
+    # with "halo_overlap" 0 and again with the candidate; owned x / f / torque compared by tag on every rank (4 steps: no
+    # chaos yet); then both are timed.  A candidate that differs is not used (and the exit code says so).
+    ov = {"requested": args.halo_overlap, "candidate": candidate, "used": candidate, "checked": False}
+    if check_overlap:
+        box = float(np.max(cfg["hi"] - cfg["lo"]))
+        with wd.phase("halo_overlap check: 4 timesteps at 0 and at the candidate from one saved state", 2 * args.wait_s):
+            run.run(4)                      # code objects loaded, clocks up
+            state = run.save_state()
+
+            def leg(opt, nsteps):
+                sp.set_option("halo_overlap", opt)
+                run.restore_state(state)    # collective: migration, ghost plan, list (partitioned when opt > 0), forces
+                run.sync()
+                coll.barrier()
+                t0 = time.perf_counter()
+                run.run(nsteps)
+                run.sync()
+                coll.barrier()
+                return time.perf_counter() - t0
+            leg(0, 4)
+            ref_owned = run.owned()
+            leg(candidate, 4)
+            got = run.owned()
+            if os.environ.get("SHPAIR_BENCH_FAULT") == "overlap" and rank == 0 and got[4].size:
+                got[4][0, 0] += 1e-5 * max(1.0, float(np.abs(got[4]).max()))   # diagnostic hook (tests): a wrong candidate
+            errs = coll.gather(rank, _cmp_owned(ref_owned, got, box))
+            fscale = max(e[2] for e in errs) or 1.0
+            ov_err = max(max(e[0] for e in errs), max(e[1] for e in errs) / fscale)
+            ov_ok = bool(ov_err < 1e-9)
+            del ref_owned, got
+        ov.update(checked=True, rel_err=ov_err, ok=ov_ok, steps=4)
+        with wd.phase("halo_overlap A/B timing", 2 * args.wait_s):
+            ab = {0: [], candidate: []}
+            for opt in (0, candidate, 0, candidate):
+                el = leg(opt, args.ab_steps)
+                ab[opt].append(max(coll.gather(rank, el)))     # max over ranks, as the timed region
+            ms = {str(k): 1e3 * min(v) / args.ab_steps for k, v in ab.items()}
+            ov["ab_ms_per_step"] = ms
+            ov["ab_steps"] = args.ab_steps
+            if not ov_ok:
+                ov["used"] = 0
+                if rank == 0:
+                    print(f"bench.py: halo_overlap {candidate} differs from 0 after 4 timesteps (rel err {ov_err}): timing with 0",
+                          file=sys.stderr, flush=True)
+            elif args.halo_overlap < 0 and ms[str(candidate)] > ms["0"]:
+                ov["used"] = 0     # auto: correct, but not faster here
+            sp.set_option("halo_overlap", ov["used"])
+            run.restore_state(state)
+            del state
+        lap("overlap_check")
+
     with wd.phase("warm-up timesteps", 2 * args.wait_s):
         for _ in range(max(1, (args.ramp + args.warmup) // 4)):   # clock ramp and warm-up, in chunks so that rebuilds happen too
             run.run(4)
         c0, t0_ = count_contacts()
+    lap("warm_up")
     b0, k0 = run.builds, run.kernel_ms
     s0 = halo.stats()
-    with wd.phase("timed timesteps", 3 * args.wait_s):
+    with wd.phase("timed timesteps", 2 * args.wait_s):
         run.sync()
         coll.barrier()
         torch.cuda.synchronize()
@@ -584,13 +902,15 @@ def multi_rank_body(args, rank, world, device, coll, hub, uid, result, wd=None):
         n_end = run.n
         mine_out = dict(elapsed=elapsed, contact=0.5 * (c0 + c1), touching=0.5 * (t0_ + t1_), kernel_ms=(run.kernel_ms - k0) / args.steps,
                         rebuilds=run.builds - b0, migrated=s1["migrated_out"] - s0["migrated_out"], nlocal=n_end, nghost=run.nghost,
-                        npairs=run.npairs, stats=s1)
+                        npairs=run.npairs, stats=s1, setup=setup)
         allr = coll.gather(rank, mine_out)
     if rank == 0:
         el = max(r["elapsed"] for r in allr)
         contact_all = sum(r["contact"] for r in allr)
         assert sum(r["nlocal"] for r in allr) == cfg["n"], "atoms lost"
         roof, valu, occ, util = roofline_objects(args, sp, allr[0]["contact"], allr[0]["kernel_ms"], world)
+        roof["kernel_ms_note"] = ("sum of the hipEvent pairs around each slot range of a step (with halo_overlap up to three): the pair "
+                                  "kernels only, the waits for the exchange between the ranges are not in it")
         st = allr[0]["stats"]
         result["line"] = {
             "metric": "contact_pairs_per_sec", "value": contact_all * args.steps / el, "unit": "contact-pairs/s",
@@ -612,17 +932,30 @@ def multi_rank_body(args, rank, world, device, coll, hub, uid, result, wd=None):
             "halo": {
                 "transport": "rccl" if st["transport"] == 1 else "local",
                 "ranks_reported_by_transport": st["nranks_transport"], "rccl_version": st["rccl_version"],
-                "overlap_option": args.halo_overlap, "peers_rank0": st["npeers"], "send_rows_rank0": st["nsend_rows"], "ghost_rows_rank0": st["nghost_rows"],
+                "overlap_option": ov["used"], "peers_rank0": st["npeers"], "send_rows_rank0": st["nsend_rows"], "ghost_rows_rank0": st["nghost_rows"],
                 "forward_bytes_per_step_rank0": st["forward_bytes_per_step"], "reverse_bytes_per_step_rank0": st["reverse_bytes_per_step"],
                 "rebuilds_in_timed_steps": [r["rebuilds"] for r in allr], "atoms_migrated_in_timed_steps": int(sum(r["migrated"] for r in allr)),
                 "owned_atoms": [r["nlocal"] for r in allr], "ghost_atoms": [r["nghost"] for r in allr],
                 "what": "per step and direction of travel one pack kernel, one ncclGroupStart..ncclSend/ncclRecv per peer.."
-                        "ncclGroupEnd on the compute stream, one unpack kernel; no host wait except at the rebuild test",
+                        "ncclGroupEnd, one unpack kernel; no host wait except at the rebuild test.  overlap_option 0: all of it on "
+                        "the compute stream; 1 / 2: the forward (and the reverse) exchange on a second stream beside the pair "
+                        "kernels of the owned-only slots",
             },
+            "overlap_requested": ov["requested"], "overlap_candidate": ov["candidate"], "overlap_used": ov["used"],
+            "verify_overlap_rel_err": ov.get("rel_err"), "verify_overlap_ok": ov.get("ok"),
+            "overlap_ab_ms": ov.get("ab_ms_per_step"), "overlap_ab_steps": ov.get("ab_steps"),
+            "verify_overlap_note": "the path the timed steps take, checked in this run: from one saved state (x, v, quat, angmom of "
+                                   "every rank) 4 timesteps of shhalo_run_device with halo_overlap 0 and again with overlap_candidate; "
+                                   "owned positions (per box edge), forces and torques (per max |F|) compared by tag on every rank, bar "
+                                   "1e-9; overlap_ab_ms: ms per timestep of both over overlap_ab_steps steps from that state (min of 2 "
+                                   "legs each, max over ranks).  overlap_used = 0 when the check fails (exit code 1) or, with "
+                                   "--halo-overlap -1, when the candidate is not faster",
             "value_note": "contact pairs of all ranks (mean of the counts before and after the timed steps) x K / max-over-ranks time",
             "verify_rel_err": verify_err, "verify_ok": (None if verify_err is None else bool(verify_err < 1e-9)),
             "verify_note": "decomposed forces and torques of the initial configuration against a single-domain compute of the "
                            "whole bed on rank 0 (max abs difference / max |F|), untimed; bar 1e-9",
+            "setup_s": {"rank0": allr[0]["setup"], "max_over_ranks": {k: max(r["setup"].get(k, 0.0) for r in allr) for k in allr[0]["setup"]}},
+            "elapsed_s": round(time.monotonic() - T_START, 1),
             "roofline": roof, "occupancy": occ, "valu_f64": valu, "utilisation": util, "library": _library_name(),
             "scale_ref_cmd": f"python bench.py --gpus 1 --multi --steps {args.steps} --warmup {args.warmup}",
             "scale_ref_note": "parallel efficiency of this line = value / (n_gpus x value of scale_ref_cmd's line): the same workload "
@@ -635,7 +968,16 @@ def multi_rank_body(args, rank, world, device, coll, hub, uid, result, wd=None):
     sp.close()
 
 
+def _line_rc(line):
+    return 1 if (line.get("verify_ok") is False or line.get("verify_overlap_ok") is False) else 0
+
+
 def main_multi(args):
+    wd = Watchdog(args, emit=(os.environ.get("RANK", "0") == "0"))
+    wd.watch_sigterm()
+    if os.environ.get("SHPAIR_BENCH_FAULT") == "stall":    # diagnostic hook (tests, no GPU needed): a rank that never comes back
+        with wd.phase("diagnostic stall (SHPAIR_BENCH_FAULT=stall)", args.wait_s):
+            time.sleep(1.0e6)
     import torch
     if not torch.cuda.is_available():
         print("bench.py: no GPU visible; the HIP path has no CPU fallback", file=sys.stderr)
@@ -650,7 +992,7 @@ def main_multi(args):
 
         def work(r):
             try:
-                multi_rank_body(args, r, world, 0, coll, hub, None, result)
+                multi_rank_body(args, r, world, 0, coll, hub, None, result)   # a watchdog per rank thread
             except BaseException as e:  # noqa: BLE001
                 import traceback
                 errs.append(traceback.format_exc())
@@ -668,7 +1010,7 @@ def main_multi(args):
             sys.exit(1)
         print(json.dumps(result["line"]), flush=True)
         hub.close()
-        return
+        sys.exit(_line_rc(result["line"]))
     wsz = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -680,7 +1022,6 @@ def main_multi(args):
     import datetime
     import torch.distributed as dist
     from shpair import mrank
-    wd = Watchdog()
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     if world == 1 and "MASTER_PORT" not in os.environ:   # `--gpus 1 --multi` without a launcher
         import socket
@@ -694,7 +1035,7 @@ def main_multi(args):
         print(f"bench.py: rank {rank}: LOCAL_RANK {local_rank} but only {ndev} GPU(s) visible", file=sys.stderr, flush=True)
         sys.exit(3)
     torch.cuda.set_device(local_rank)
-    with wd.phase("gloo rendezvous (torch.distributed.init_process_group)", args.wait_s):
+    with wd.phase("gloo rendezvous (torch.distributed.init_process_group) + ncclGetUniqueId broadcast", args.wait_s):
         # control plane only: id broadcast, barriers, timings
         dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=args.wait_s))
         box = [mrank.unique_id() if rank == 0 else None]
@@ -705,12 +1046,14 @@ def main_multi(args):
         multi_rank_body(args, rank, world, local_rank, coll, None, box[0], result, wd)
     except BaseException:  # noqa: BLE001 — a rank that failed must not leave the others in a collective for ever: say why, then end
         import traceback
-        print(f"bench.py: rank {rank} failed:\n{traceback.format_exc()}", file=sys.stderr, flush=True)
+        tb = traceback.format_exc()
+        print(f"bench.py: rank {rank} failed:\n{tb}", file=sys.stderr, flush=True)
+        if rank == 0:
+            print(error_line(args, f"rank 0 failed: {tb.strip().splitlines()[-1]}"), flush=True)
         os._exit(1)
     if rank == 0:
         print(json.dumps(result["line"]), flush=True)
-        if result["line"].get("verify_ok") is False:
-            rc = 1
+        rc = _line_rc(result["line"])
     with wd.phase("shutdown barrier", args.wait_s):
         dist.barrier()
         dist.destroy_process_group()
@@ -798,26 +1141,43 @@ def _rank_env(rank, world, port):
     return env
 
 
-def run_rank_children(argv, world, bound_s, stdout_of_rank0=True, script=None):
+_WD_MSG = re.compile(r"^bench\.py: (rank \d+: '.*?' .*?); giving up with exit code \d+")
+
+
+def run_rank_children(argv, world, bound_s, stdout_of_rank0=True, script=None, notes=None):
     """Starts `world` FRESH processes of this script — one rank per GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set —
     waits for all of them within `bound_s`, ends the others (their exact PIDs) when one dies or the bound passes, and
     returns (worst exit code, rank 0's stdout).  The caller has not touched the GPU: children are ordinary
-    fork + exec of the interpreter, never a re-exec of a process that holds a HIP context."""
+    fork + exec of the interpreter, never a re-exec of a process that holds a HIP context.  The ranks' stderr is relayed
+    line by line; what their watchdogs said before giving up is also appended to `notes` (a list)."""
     import subprocess
     port = _free_port()
     cmd = [sys.executable, script or os.path.abspath(__file__)] + list(argv)
     procs = []
     for r in range(world):
         procs.append(subprocess.Popen(cmd, env=_rank_env(r, world, port), cwd=ROOT, text=True,
-                                      stdout=(subprocess.PIPE if r == 0 else subprocess.DEVNULL), stderr=None))
+                                      stdout=(subprocess.PIPE if r == 0 else subprocess.DEVNULL), stderr=subprocess.PIPE))
     out0 = []
-    reader = None
+    readers = []
+
+    def _relay(p):
+        for ln in p.stderr:
+            sys.stderr.write(ln)
+            sys.stderr.flush()
+            m = _WD_MSG.match(ln)
+            if m and notes is not None:
+                notes.append(m.group(1))
+    for p in procs:
+        t = threading.Thread(target=_relay, args=(p,), daemon=True)
+        t.start()
+        readers.append(t)
     if stdout_of_rank0:
         def _read():
             for ln in procs[0].stdout:
                 out0.append(ln)
-        reader = threading.Thread(target=_read, daemon=True)
-        reader.start()
+        t = threading.Thread(target=_read, daemon=True)
+        t.start()
+        readers.append(t)
     deadline = time.monotonic() + bound_s
     codes = [None] * world
     worst = 0
@@ -852,11 +1212,15 @@ def run_rank_children(argv, world, bound_s, stdout_of_rank0=True, script=None):
                       f"rank(s) {failed} failed"), file=sys.stderr, flush=True)
             if late and not failed:
                 print(f"bench.py: the {world} rank processes did not finish within {bound_s:.0f} s", file=sys.stderr, flush=True)
+                if notes is not None:
+                    notes.append(f"the {world} rank processes did not finish within the launcher's bound of {bound_s:.0f} s")
                 worst = 4
+            elif notes is not None and failed:
+                notes.append(f"rank(s) {failed} ended with exit code(s) {[codes[r] for r in failed]}")
             break
         time.sleep(0.2)
-    if reader is not None:
-        reader.join(timeout=10.0)
+    for t in readers:
+        t.join(timeout=10.0)
     for c in codes:
         if c is not None and c != 0:
             worst = max(worst, c if c > 0 else 128 - c)   # a signal's negative code as the shell would print it
@@ -868,9 +1232,16 @@ def self_launch(args):
     launcher.  It has made no GPU call (importing torch is all that happened) and makes none: it starts N fresh rank
     processes, relays rank 0's single JSON line and returns the worst exit code.  The line carries `scale_ref_cmd` —
     the command whose `value` is the like-for-like one-GPU point of the scaling curve (same workload per GPU, same C++
-    loop, same transport code)."""
+    loop, same transport code).  Bounded by --total-s from THIS process's start (the ranks get what is left, less a
+    margin, as their own --total-s): when no measurement comes back in time the line printed here has `value` null and
+    an `error` field naming the phase and the rank that gave up."""
     argv = [a for a in sys.argv[1:] if a != "--launch"]
-    rc, out = run_rank_children(argv, args.gpus, 6.0 * args.wait_s + 120.0)
+    bound = 6.0 * args.wait_s + 120.0
+    if args.total_s > 0:
+        bound = max(20.0, args.total_s - (time.monotonic() - T_START) - 5.0)
+        argv += ["--total-s", f"{max(10.0, bound - 15.0):.0f}"]
+    notes = []
+    rc, out = run_rank_children(argv, args.gpus, bound, notes=notes)
     lines = [ln for ln in out.splitlines() if ln.startswith("{")]
     for ln in out.splitlines():
         if not ln.startswith("{"):
@@ -879,11 +1250,18 @@ def self_launch(args):
         try:
             d = json.loads(lines[-1])
             d["launcher"] = "bench.py self-launch: N fresh rank processes (RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* set by the parent)"
+            if d.get("error") and notes:
+                d["error_notes"] = notes
             print(json.dumps(d), flush=True)
         except ValueError:
             print(lines[-1], flush=True)
-    elif rc == 0:
-        rc = 1
+    else:
+        if rc == 0:
+            rc = 1
+        # no measurement: one line all the same, `value` null and the reason (what the ranks' watchdogs said, or their exit codes)
+        d = json.loads(error_line(args, "; ".join(notes) if notes else f"the rank processes ended with exit code {rc} and no line"))
+        d["launcher"] = "bench.py self-launch"
+        print(json.dumps(d), flush=True)
     sys.exit(rc)
 
 

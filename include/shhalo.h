@@ -176,8 +176,9 @@ int shhalo_get_stats(const shhalo_ctx *h, shhalo_stats *out);
  * final_integrate, all on `stream`; the host only waits at the rebuild tests.  On entry the plan, ghosts and list of
  * the current positions must exist (shhalo_exchange_device + shhalo_borders_device +
  * shstep_neighbor_build_device with tags) and f, torque must hold their forces (as after Verlet::setup).
- * a->nlocal and *nghost are updated.  kernel_ms (nullable): sum of the pair-kernel times of the steps (hipEvents
- * recorded on `stream`).  Blocks until the last step is done. */
+ * a->nlocal and *nghost are updated.  kernel_ms (nullable): sum of the pair-kernel times of the steps (hipEvent pairs
+ * recorded on `stream` around each slot range of a step — with "halo_overlap" there are up to three — so the waits
+ * for the exchange between the ranges are not in it).  Blocks until the last step is done. */
 typedef struct shhalo_run_params {
   double dt;
   int groupbit;

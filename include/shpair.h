@@ -164,9 +164,9 @@ int shpair_compute_device(shpair_ctx *ctx, int nlocal, int nghost, const double 
  * tallies are bitwise reproducible in both modes — per-slot rows added in slot order — the per-atom tallies keep their
  * atomics), "halo_overlap" (1: device-built lists are partitioned — slots whose two atoms are owned first, slots with a
  * ghost behind them, each in list order — and shhalo_run_device runs the forward exchange of a step on a stream of its
- * own beside the pair kernels of the owned-only slots; 2, the default: the reverse exchange is hidden as well — half of the owned-only
+ * own beside the pair kernels of the owned-only slots; 2: the reverse exchange is hidden as well — half of the owned-only
  * slots run beside the forward exchange, the ghost slots follow it, the other half runs beside the reverse exchange,
- * whose unpack uses the same FP64 atomics (atomic accumulation only: with "deterministic" 2 behaves as 1); 0: the
+ * whose unpack uses the same FP64 atomics (atomic accumulation only: with "deterministic" 2 behaves as 1); 0, the default: the
  * exchanges and the pair kernels follow each other on the caller's stream; same forces, another order of the per-atom
  * sums), "waves_per_block" (tuning: waves per workgroup of the one-wave contact kernels, default 1), "queue_slack"
  * (diagnostic, default 1: the node queue of the "jpoly" kernels takes what the wave's LDS layout leaves of its last

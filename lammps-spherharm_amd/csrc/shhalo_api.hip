@@ -1015,10 +1015,20 @@ int shhalo_run_device(shhalo_ctx* h, shhalo_arrays* a, const shhalo_run_params* 
   }
   const bool body = p->gravity[0] != 0.0 || p->gravity[1] != 0.0 || p->gravity[2] != 0.0 || p->gamma_t != 0.0 || p->gamma_r != 0.0;
   int nghost = *nghost_io, nreb = 0;
-  // pair-kernel time: one event pair per step (bounded pool; beyond it the steps are not timed)
-  const int ntimed = kernel_ms ? (nsteps < 4096 ? nsteps : 4096) : 0;
-  std::vector<hipEvent_t> ev((size_t)2 * ntimed, nullptr);
+  // pair-kernel time: one event pair around EACH slot range of a step — up to three with "halo_overlap" — so that the
+  // waits for the exchange's events between the ranges are not counted as kernel time (bounded pool; beyond it the
+  // steps are not timed)
+  constexpr int kEvPerStep = 6;
+  const int ntimed = kernel_ms ? (nsteps < 2048 ? nsteps : 2048) : 0;
+  std::vector<hipEvent_t> ev((size_t)kEvPerStep * ntimed, nullptr);
+  std::vector<unsigned char> ev_used((size_t)(kEvPerStep / 2) * ntimed, 0);
   for (auto& e : ev) H_HIP(h, hipEventCreate(&e));
+  // range k (0, 1, 2) of `step`: record before / after on the caller's stream
+  const auto tick = [&](const int step, const int k, const int end) {
+    if (step >= ntimed) return;
+    (void)hipEventRecord(ev[(size_t)kEvPerStep * step + 2 * k + end], st);
+    if (end) ev_used[(size_t)(kEvPerStep / 2) * step + k] = 1;
+  };
   int rc = SHPAIR_OK;
   for (int step = 0; step < nsteps && rc == SHPAIR_OK; ++step) {
     rc = shstep_nve_device(sp, 0, a->nlocal, p->dt, a->x, a->v, a->quat, a->angmom, a->f, a->torque, a->shtype, a->mask,
@@ -1068,7 +1078,6 @@ int shhalo_run_device(shhalo_ctx* h, shhalo_arrays* a, const shhalo_run_params* 
       break;
     }
     const int ef = (p->eflag_last && step == nsteps - 1) ? 1 : 0;
-    if (step < ntimed) (void)hipEventRecord(ev[2 * step], st);
     // "halo_overlap" 2 (atomic accumulation only): the REVERSE exchange is hidden too — the owned-only slots are cut in
     // two, [0, a) runs beside the forward exchange, the ghost slots follow it, and [a, split) runs beside the reverse
     // exchange, whose unpack adds into the owners' rows with the same FP64 atomics the pair kernels use.  (The
@@ -1076,18 +1085,23 @@ int shhalo_run_device(shhalo_ctx* h, shhalo_arrays* a, const shhalo_run_params* 
     const bool overlap_rev = overlap && sp->opt_overlap >= 2 && !sp->opt_deterministic;
     bool reverse_done = false;
     if (overlap) {
-      const int split = sp->n_interior & ~31;
+      const int split = (sp->n_interior < sp->npairs ? sp->n_interior : sp->npairs) & ~31;   // never beyond the installed list
       const int cut = overlap_rev ? ((split / 2) & ~31) : split;   // [0, cut) beside the forward exchange
+      tick(step, 0, 0);
       rc = shp_compute_range(sp, a->nlocal, nghost, a->x, a->quat, a->type, a->shtype, 1, ef, ef, a->f, a->torque,
                              ef ? p->ev_dev : nullptr, st, 0, cut, kPartPre);
+      tick(step, 0, 1);
       if (!rc && hipStreamWaitEvent(st, h->ev_ghosts, 0) != hipSuccess) {
         h->err = "hipStreamWaitEvent failed (halo_overlap)";
         rc = SHPAIR_EHIP;
         break;
       }
-      if (!rc)
+      if (!rc) {
+        tick(step, 1, 0);
         rc = shp_compute_range(sp, a->nlocal, nghost, a->x, a->quat, a->type, a->shtype, 1, ef, ef, a->f, a->torque,
                                ef ? p->ev_dev : nullptr, st, split, sp->npairs, overlap_rev ? 0 : kPartPost);
+        tick(step, 1, 1);
+      }
       if (!rc && overlap_rev) {
         // every contribution to a ghost row is in: the reverse exchange starts on the second stream ...
         if (hipEventRecord(h->ev_bdone, st) != hipSuccess || hipStreamWaitEvent(h->st2, h->ev_bdone, 0) != hipSuccess) {
@@ -1103,8 +1117,10 @@ int shhalo_run_device(shhalo_ctx* h, shhalo_arrays* a, const shhalo_run_params* 
           break;
         }
         // ... beside the second half of the owned-only slots
+        tick(step, 2, 0);
         rc = shp_compute_range(sp, a->nlocal, nghost, a->x, a->quat, a->type, a->shtype, 1, ef, ef, a->f, a->torque,
                                ef ? p->ev_dev : nullptr, st, cut, split, kPartPost);
+        tick(step, 2, 1);
         if (!rc && hipStreamWaitEvent(st, h->ev_rev, 0) != hipSuccess) {
           h->err = "hipStreamWaitEvent failed (halo_overlap 2)";
           rc = SHPAIR_EHIP;
@@ -1113,10 +1129,11 @@ int shhalo_run_device(shhalo_ctx* h, shhalo_arrays* a, const shhalo_run_params* 
         reverse_done = true;
       }
     } else {
+      tick(step, 0, 0);
       rc = shpair_compute_device(sp, a->nlocal, nghost, a->x, a->quat, a->type, a->shtype, 1, ef, ef, a->f, a->torque,
                                  ef ? p->ev_dev : nullptr, st);
+      tick(step, 0, 1);
     }
-    if (step < ntimed) (void)hipEventRecord(ev[2 * step + 1], st);
     if (rc) { h->err = sp->err; break; }
     if (!reverse_done) {
       rc = shhalo_reverse_device(h, a->f, a->torque, st);
@@ -1136,10 +1153,13 @@ int shhalo_run_device(shhalo_ctx* h, shhalo_arrays* a, const shhalo_run_params* 
   if (rc != SHPAIR_OK && h->st2) (void)hipStreamSynchronize(h->st2);
   if (rc == SHPAIR_OK && es == hipSuccess && kernel_ms) {
     double sum = 0.0;
-    for (int k = 0; k < ntimed; ++k) {
-      float ms = 0.f;
-      if (hipEventElapsedTime(&ms, ev[2 * k], ev[2 * k + 1]) == hipSuccess) sum += ms;
-    }
+    for (int k = 0; k < ntimed; ++k)
+      for (int r = 0; r < kEvPerStep / 2; ++r) {
+        float ms = 0.f;
+        if (ev_used[(size_t)(kEvPerStep / 2) * k + r] &&
+            hipEventElapsedTime(&ms, ev[(size_t)kEvPerStep * k + 2 * r], ev[(size_t)kEvPerStep * k + 2 * r + 1]) == hipSuccess)
+          sum += ms;
+      }
     *kernel_ms = sum;
   }
   for (auto& e : ev)

@@ -884,7 +884,7 @@ int shp_compute_range(shpair_ctx* c, int nlocal, int nghost, const double* x, co
     P.flags = c->d_flags.p;
   }
   const bool needv = c->opt_force_volume || eflag || c->any_nonunit_exponent || c->eatom_dev != nullptr;
-  c->last_needv = needv;
+  c->last_needv = needv || c->opt_rule != 0;   // the template argument launched: the weighted rule has one instance, with the volume path
   // per-pair records (pair_setup.hpp); the buffers are sized when a list is installed, so nothing is allocated here
   // unless a caller swapped the list behind the context's back
   HIPCHK(c, c->d_rec.ensure((size_t)c->npairs * kRecStride));

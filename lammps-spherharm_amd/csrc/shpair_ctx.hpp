@@ -97,8 +97,10 @@ struct shpair_ctx {
 
   int opt_force_volume = 0, opt_timing = 0, opt_count = 0, opt_variant = 0, opt_ring_rows = 0, opt_wpb = 0, opt_rule = 0;
   int opt_queue_slack = 1;   // "queue_slack" (diagnostic): the node queue of the per-azimuth kernels takes the rest of its last LDS granule
-  int opt_overlap = 2;   // "halo_overlap" (default 2: forward and reverse exchange beside owned-only slots; the one-GPU rehearsal of 8 ranks runs 26.2-26.6 ms per step at 0, 26.2-26.4 at 1, 25.9-26.0 at 2, profiles/r04_aa_local8.txt): device-built lists are partitioned interior / boundary and shhalo_run_device runs
-                         // the interior slots while the forward exchange is in flight
+  int opt_overlap = 0;   // "halo_overlap" (default 0 since round 5: the exchanges and the pair kernels follow each other on the caller's
+                         // stream; 1 / 2 are opt-in until a run between GPUs has measured them — bench.py --gpus N tries 2, checks it
+                         // against 0 in the run itself and reports both): device-built lists are partitioned interior / boundary and
+                         // shhalo_run_device runs the interior slots while the forward (2: and the reverse) exchange is in flight
   int n_interior = 0;    // slots [0, n_interior) of the installed list touch owned atoms only (device-built lists)
   int opt_jpoly = -1;      // 1 / 0: compiled orders evaluate particle j from per-azimuth polynomials or not; -1: by the
                            // measured rule (shpair_api.hip use_jpoly)

@@ -410,7 +410,11 @@ int shstep_neighbor_build_device(shpair_ctx* c, int nlocal, int nghost, const do
   c->have_neighbors = false;
   s->l_nlocal = -1;
   if (nlocal == 0) {
+    // a rank that lost all its atoms by migration: an empty list, and nothing of the previous list's partition survives
+    // (shhalo_run_device cuts its slot ranges at n_interior)
     c->npairs = 0;
+    c->n_interior = 0;
+    s->partitioned = false;
     c->max_atom_index = nall - 1;
     HIPCHK(c, c->d_pair_i.ensure(1));
     HIPCHK(c, c->d_pair_j.ensure(1));

@@ -264,6 +264,28 @@ class RankRun:
         self.kernel_ms += ms
         return nreb
 
+    def save_state(self):
+        """Everything a rank needs to come back to this instant: the owned rows of every per-atom array (clones on the
+        device) and their count.  Ghosts, plan and list are NOT saved: restore_state() rebuilds them."""
+        self.sync()
+        n = self.a.nlocal
+        keep = {k: getattr(self, k)[:n].clone() for k in ("x", "q", "v", "L", "tag", "sh", "ty", "mask")}
+        self.torch.cuda.synchronize()
+        return dict(n=n, arrays=keep)
+
+    def restore_state(self, state):
+        """Back to save_state()'s instant: owned rows, then (collectively, every rank calls it) migration + ghost plan +
+        list + forces, as after the constructor.  The list is built under the context's CURRENT options (a changed
+        "halo_overlap" takes effect here)."""
+        self.sync()
+        n = state["n"]
+        for k, t in state["arrays"].items():
+            getattr(self, k)[:n] = t
+        self.a.nlocal = n
+        self.torch.cuda.synchronize()
+        self.rebuild()
+        self.force()
+
     def owned(self):
         """(tag, x, v, quat, f, torque) of the owned atoms on the host, sorted by tag."""
         self.sync()

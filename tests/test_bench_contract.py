@@ -52,6 +52,25 @@ def test_single_gpu_line_has_the_contract_fields():
     assert d["roofline"]["stale"] in (None, True, False) and d["utilisation"]["stale"] == d["roofline"]["stale"]
     assert sr["value"] > 1e7 and sr["steps"] == 20 and "configs[3]" in sr["workload"] and sr["ghost_atoms"] > 0
     assert abs(sr["value"] * sr["ms_per_step"] * 1e-3 - sr["contact_pairs"]) < 1e-6 * sr["contact_pairs"]
+    assert sr["verify_overlap_ok"] is True and sr["overlap_used"] in (0, 2) and set(sr["overlap_ab_ms"]) == {"0", "2"}
+    # every other single-GPU workload of BASELINE.json, in the same line (3 warm-up + 5 timed steps each, after the headline)
+    cf = d["configs"]
+    assert cf["steps"] == 5 and cf["warmup"] == 3
+    for key, lmax, nq, nshapes in (("configs[2]", 6, 16, 4), ("configs[4]", 12, 32, 1), ("configs[0]-shape", 4, 10, 1)):
+        c = cf[key]
+        assert "error" not in c, c
+        for k in ("value", "ms_per_step", "kernel_ms", "valu_f64_frac", "roofline_frac", "stale", "utilisation", "contact_pairs", "kernel_hash"):
+            assert k in c, (key, k)
+        assert (c["lmax"], c["nq"], c["nshapes"]) == (lmax, nq, nshapes) and c["value"] > 1e6 and 0 < c["kernel_ms"] <= c["ms_per_step"]
+        assert c["stale"] in (None, True, False) and c["utilisation"]["stale"] == c["stale"] and c["contact_pairs"] > 500000
+    assert cf["configs[4]"]["waves_per_pair"] == 2 and cf["configs[4]"]["ms_per_step"] > 3 * cf["configs[2]"]["ms_per_step"]
+    # the boundary north_star names: host arrays in, host arrays out (what an unmodified LAMMPS pays); never `value`
+    hp = d["host_path"]
+    assert "error" not in hp, hp
+    assert hp["compute_call_ms_pinned"] > hp["compute_kernel_ms"] > 0 and 0 < hp["compute_overhead_ms_pinned"] < 5.0
+    assert hp["compute_overhead_ms_pageable"] > 0 and hp["set_neighbors_ms"] > 0 and hp["set_neighbors_csr_ms"] > 0
+    assert hp["half_list_pairs"] == d["config"]["half_list_pairs_rank0"] and hp["bytes_up_per_call"] > hp["bytes_down_per_call"] > 0
+    assert d["elapsed_s"] > 0
 
 
 def _free_port():
@@ -109,13 +128,19 @@ def test_self_launcher_gives_the_line_of_torch_distributed_run():
     # atomics order the sums differently from run to run and the bed is chaotic: the contact counts agree closely, not exactly
     assert abs(ca["contact_pairs_all_ranks"] - cb["contact_pairs_all_ranks"]) < 0.01 * cb["contact_pairs_all_ranks"]
     assert a["verify_ok"] is True and b["verify_ok"] is True and a["halo"]["transport"] == "rccl"
+    # the path the timed steps take was checked inside both runs: halo_overlap 2 against 0 from one saved state
+    for d in (a, b):
+        assert d["verify_overlap_ok"] is True and d["verify_overlap_rel_err"] < 1e-9 and d["overlap_candidate"] == 2
+        assert d["overlap_used"] in (0, 2) and d["halo"]["overlap_option"] == d["overlap_used"] and set(d["overlap_ab_ms"]) == {"0", "2"}
+        assert "first_build" in d["setup_s"]["rank0"] and "overlap_check" in d["setup_s"]["max_over_ranks"]
     assert a["scale_ref_cmd"] == b["scale_ref_cmd"] and a["library"] == b["library"] == "libshpair.so"
     assert 0.5 < a["value"] / b["value"] < 2.0
 
 
 def test_self_launcher_with_more_ranks_than_gpus_ends_cleanly():
     """`bench.py --gpus 2` on a box with ONE GPU: rank 1 finds no device of its own and leaves with exit code 3 while rank 0
-    sits in the rendezvous; the parent gives rank 0 ten seconds, ends it, and returns rank 1's code — no line, no hang."""
+    sits in the rendezvous; the parent gives rank 0 ten seconds, ends it, and returns rank 1's code — no hang, and the one line
+    that comes has `value` null and says why."""
     import time
     import torch
     if torch.cuda.device_count() != 1:
@@ -126,7 +151,8 @@ def test_self_launcher_with_more_ranks_than_gpus_ends_cleanly():
                        capture_output=True, text=True, timeout=400, cwd=ROOT, env=env)
     assert r.returncode == 3, (r.returncode, r.stderr[-2000:])
     assert "only 1 GPU(s) visible" in r.stderr and "ended rank process(es) [0]" in r.stderr, r.stderr[-2000:]
-    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    d = _last_json(r.stdout)     # one line, and it is not a measurement: value null, the reason in `error`
+    assert d["value"] is None and d["n_gpus"] == 2 and d["error"] and any("[1] ended with exit code(s) [3]" in n for n in d.get("error_notes", [d["error"]]))
     assert time.monotonic() - t0 < 200
 
 
@@ -144,16 +170,39 @@ def test_multi_rank_line_rehearsed_as_rank_threads():
     """bench.py --gpus N, N > 1, with the ranks as threads of one process on the one GPU (--transport local): the same
     C++ loop, plan and pack / unpack kernels as the RCCL path; --verify compares the decomposed initial forces with a
     single-domain compute.  (The product transport itself: tests/test_gpu_mrank.py::test_rccl_self_communicator...)"""
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--transport", "local", "--verify",
-                        "--particles", "6000", "--steps", "12", "--warmup", "1", "--ramp", "3", "--peak-ms", "0"],
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--transport", "local", "--verify",
+                        "--particles", "5000", "--steps", "12", "--warmup", "1", "--ramp", "3", "--peak-ms", "0"],
                        capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-3000:]
     d = _last_json(r.stdout)
-    assert d["n_gpus"] == 4 and d["scaling"] == "weak" and d["config"]["proc_grid"] == [2, 2, 1]
+    assert d["n_gpus"] == 8 and d["scaling"] == "weak" and d["config"]["proc_grid"] == [2, 2, 2]
     assert d["verify_rel_err"] is not None and d["verify_rel_err"] < 1e-12
+    # halo_overlap 2 (exchanges on a second stream beside the owned-only slots) against 0, 4 timesteps from one saved state
+    assert d["verify_overlap_ok"] is True and d["verify_overlap_rel_err"] < 1e-9 and d["overlap_used"] in (0, 2)
+    assert set(d["overlap_ab_ms"]) == {"0", "2"} and min(d["overlap_ab_ms"].values()) > 0
     h = d["halo"]
-    assert h["transport"] == "local" and h["ranks_reported_by_transport"] == 4 and h["peers_rank0"] == 3
+    assert h["transport"] == "local" and h["ranks_reported_by_transport"] == 8 and h["peers_rank0"] == 7
     assert min(h["ghost_atoms"]) > 0 and sum(h["owned_atoms"]) == d["config"]["particles_all_ranks"]
     assert max(h["rebuilds_in_timed_steps"]) >= 1 and len(set(h["rebuilds_in_timed_steps"])) == 1
     assert d["value"] > 1e6 and d["roofline"]["kernel_ms"] > 0 and d["roofline"]["traffic"] is None
     assert d["config"]["contact_pairs_all_ranks"] > d["config"]["contact_pairs_rank0"]
+
+
+def test_a_wrong_overlap_result_is_not_used_and_fails_the_run():
+    """The fall-back of the in-run halo_overlap check, forced with the diagnostic hook (SHPAIR_BENCH_FAULT=overlap perturbs one
+    force component of the candidate's result on rank 0 by 1e-5 of max |F|): the line still comes — timed with
+    halo_overlap 0 — says so (`overlap_used` 0, `verify_overlap_ok` false) and the exit code is 1."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--transport", "local", "--particles", "5000",
+                        "--steps", "8", "--warmup", "1", "--ramp", "3", "--peak-ms", "0", "--halo-overlap", "2"],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT, env=dict(os.environ, SHPAIR_BENCH_FAULT="overlap"))
+    assert r.returncode == 1, (r.returncode, r.stderr[-3000:])
+    d = _last_json(r.stdout)
+    assert d["verify_overlap_ok"] is False and d["verify_overlap_rel_err"] > 1e-7 and d["overlap_used"] == 0 and d["overlap_candidate"] == 2
+    assert d["halo"]["overlap_option"] == 0 and d["value"] > 1e6 and "differs from 0" in r.stderr
+    # asked for explicitly and correct: used whatever the A/B says
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--transport", "local", "--particles", "5000",
+                        "--steps", "8", "--warmup", "1", "--ramp", "3", "--peak-ms", "0", "--halo-overlap", "2"],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = _last_json(r.stdout)
+    assert d["verify_overlap_ok"] is True and d["overlap_used"] == 2 and d["halo"]["overlap_option"] == 2

@@ -210,6 +210,71 @@ def test_dynamic_run_matches_single_rank(grid, periodic, overlap):
         hub.close()
 
 
+@pytest.mark.parametrize("overlap", [0, 1, 2])
+def test_a_rank_that_loses_all_its_atoms_keeps_stepping(overlap):
+    """Every atom of rank 0 migrates to rank 1 in the middle of a run (a cluster flying across the brick face).  From then
+    on rank 0 holds an EMPTY list: nothing of its previous list's interior / boundary partition may survive the rebuild
+    (shstep_neighbor_build_device's nlocal == 0 branch; the slot ranges of shhalo_run_device are cut at n_interior) —
+    with "halo_overlap" 1 and 2 a stale n_interior made rank 0 fail in mid-loop and left rank 1 waiting for it."""
+    import torch
+    from shpair import shapes, mrank
+    from shpair.run import DeviceRun
+    grid, periodic, world = (2, 1, 1), (0, 0, 0), 2
+    lmax, nq, skin, dt, nsteps = 4, 8, 0.2, 2e-3, 320
+    shp = [shapes.random_shape(lmax, 400 + s, amp=0.2) for s in range(2)]
+    lo, hi = np.zeros(3), np.array([40.0, 9.5, 9.5])
+    rng = np.random.default_rng(31)
+    gy, gz = np.meshgrid(1.0 + 1.85 * np.arange(4), 1.0 + 1.85 * np.arange(4), indexing="ij")
+
+    def block(x0):
+        return np.concatenate([np.stack([np.full(16, x0 + 1.85 * k), gy.ravel(), gz.ravel()], axis=1) for k in range(2)])
+    x = np.concatenate([block(16.0), block(30.0)]) + rng.uniform(-0.03, 0.03, (64, 3))
+    n = x.shape[0]
+    from shpair import bed
+    quat = bed.random_quaternions(n, rng)
+    sht = rng.integers(0, 2, n).astype(np.int32)
+    tag = np.arange(n, dtype=np.int32)
+    v0 = np.zeros((n, 3))
+    v0[:32, 0] = 6.0      # the left cluster crosses x = 20 after ~0.35 time units, whole
+    sp0 = _ctx(lmax, shp, nq)
+    cut = 2.0 * max(sp0.rmax(s) for s in range(2)) + skin
+    xw, owner = _distribute(grid, lo, hi, periodic, cut, x)
+    assert (owner == 0).sum() == 32 and (owner == 1).sum() == 32
+    hub = mrank.Hub(world)
+
+    def body(rank):
+        sp = _ctx(lmax, shp, nq)
+        sp.set_option("halo_overlap", overlap)
+        halo = mrank.Halo(sp, rank, world, grid, lo, hi, periodic, skin, hub=hub)
+        mine = owner == rank
+        run = mrank.RankRun(sp, halo, xw[mine], quat[mine], sht[mine], tag[mine], v=v0[mine], dt=dt, capacity=256)
+        counts = []
+        for _ in range(nsteps // 40):
+            run.run(40)
+            counts.append(run.n)
+        t, X, V, _, _, _ = run.owned()
+        res = dict(tag=t, x=X, v=V, counts=counts, builds=run.builds)
+        halo.close()
+        sp.close()
+        return res
+    parts = _run_ranks(world, body)
+    assert parts[0]["counts"][0] == 32 and parts[0]["counts"][-1] == 0 and parts[1]["counts"][-1] == 64
+    assert parts[0]["counts"].count(0) >= 2          # rank 0 went on stepping with nothing: more than one call of the loop
+    tg = np.concatenate([p["tag"] for p in parts])
+    o = np.argsort(tg)
+    assert np.array_equal(tg[o], np.arange(n))
+    X = np.concatenate([p["x"] for p in parts])[o]
+    V = np.concatenate([p["v"] for p in parts])[o]
+    ref = DeviceRun(sp0, x, quat, sht, lo, hi, periodic, skin, dt=dt)
+    ref.v[:] = torch.from_numpy(v0).to(ref.v.device)
+    ref.force()
+    ref.run(nsteps)
+    torch.cuda.synchronize()
+    assert np.abs(X - ref.x[:n].cpu().numpy()).max() < 1e-8 and np.abs(V - ref.v.cpu().numpy()).max() < 1e-7
+    sp0.close()
+    hub.close()
+
+
 def test_config4_one_million_particles_eight_ranks():
     """BASELINE configs[3] as a rehearsal: 1 M particles, L_max = 6, 2x2x2 bricks, periodic in x and y, gravity;
     eight rank threads on the one GPU.  A few steps of the C++ loop, then: no atom lost, the forces of a sample of
