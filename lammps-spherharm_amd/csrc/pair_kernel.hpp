@@ -2134,6 +2134,7 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
           if (lane_of(ma)) atomicAdd(&P.dbg[3], 1ULL);
           if (lane_of(mb)) atomicAdd(&P.dbg[3], 1ULL);
           if (lane == 0) atomicAdd(&P.dbg[10], 1ULL);
+          if (lane == 0 && P.dbg[15]) atomicAdd(&P.dbg[64 + w], (unsigned long long)(__builtin_popcountll(ma) + __builtin_popcountll(mb)));   // per-slot inside-node counts (tools/halfwave_sim.py)
 #endif
           phase2(BoolC<true>{}, second ? pa + nq : pa, second ? rib : ria, second ? rjb : rja, ma | mb);
           continue;
@@ -2147,6 +2148,7 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
       if (lane == 0) atomicAdd(&P.dbg[2], 2ULL);
       if (lane_of(ma)) atomicAdd(&P.dbg[3], 1ULL);
       if (lane_of(mb)) atomicAdd(&P.dbg[3], 1ULL);
+      if (lane == 0 && P.dbg[15]) atomicAdd(&P.dbg[64 + w], (unsigned long long)(__builtin_popcountll(ma) + __builtin_popcountll(mb)));
 #endif
       ++slab;
       SHP_PUSH(ma, pa, ria, rja);

@@ -9,6 +9,8 @@
 
 #include "fix_nve_sh.h"
 
+#include "sh_lammps_compat.h"
+
 #include "atom.h"
 #include "error.h"
 #include "force.h"
@@ -80,11 +82,9 @@ void FixNVESH::step(int phase)
   int nlocal = atom->nlocal;
   if (igroup == atom->firstgroup) nlocal = atom->nfirst;
   if (nlocal == 0) return;
-  int flag = 0, cols = 0, idx;
-  double **quat = (double **) atom->extract("quat");
-  if (!quat && (idx = atom->find_custom("quat", flag, cols)) >= 0 && flag == 1 && cols == 4) quat = atom->darray[idx];
-  int *shtype = (int *) atom->extract("shtype");
-  if (!shtype && (idx = atom->find_custom("shtype", flag, cols)) >= 0 && flag == 0 && cols == 0) shtype = atom->ivector[idx];
+  int custom = 0;
+  double **quat = sh_lammps::find_quat(atom, custom);
+  int *shtype = sh_lammps::find_shtype(atom);
   if (!quat || !shtype) error->one(FLERR, "fix nve/sh: per-atom quaternions / shape index not found");
   check(shstep_nve(ctx, phase, nlocal, dtv, atom->x[0], atom->v[0], quat[0], atom->angmom[0], atom->f[0], atom->torque[0],
                    shtype, atom->mask, groupbit),

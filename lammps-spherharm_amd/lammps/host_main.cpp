@@ -11,6 +11,7 @@
 // With LAMMPS_HOST_GHOST_OWNERS=<file of nghost owner rows> the quaternions are registered as a CUSTOM per-atom
 // array (fix property/atom d2_quat 4 ghost yes) instead of an atom-style array and the stub Comm forwards owners'
 // values to the ghosts when the pair style asks for it: the bed file may then hold stale ghost orientations.
+// With LAMMPS_HOST_SHTYPE_CUSTOM=1 the shape index is a custom integer vector (fix property/atom i_shtype).
 // With LAMMPS_HOST_NSTEPS=<n> and LAMMPS_HOST_DT=<dt> in the environment it then runs n velocity-Verlet
 // steps with FixNVESH (fix nve/sh) from rest, the way Verlet::run orders them, and writes
 // x v quat angmom of the owned atoms to <out>.traj (ghost-free beds only: nghost = 0).
@@ -73,8 +74,16 @@ int main(int argc, char **argv)
   atom->f = f;
   atom->torque = tq;
   atom->type = type.data();
+  int *ivec[1] = {shtype.data()};
+#if SHPAIR_STUB_GEN >= 3
   double **darr[1] = {quat};
+#endif
   if (const char *gof = getenv("LAMMPS_HOST_GHOST_OWNERS")) {
+#if SHPAIR_STUB_GEN < 3
+    (void) gof;
+    fprintf(stderr, "this LAMMPS generation has no 2-d custom per-atom arrays: quaternions cannot be a custom property\n");
+    return 6;
+#else
     FILE *gp = fopen(gof, "r");
     if (!gp) return 3;
     lmp.comm->ghost_owner.resize(nghost);
@@ -85,10 +94,19 @@ int main(int argc, char **argv)
     atom->custom_flag.push_back(1);
     atom->custom_cols.push_back(4);
     atom->darray = darr;
+#endif
   } else {
     atom->extractable["quat"] = (void *) quat;        // as atom_style spherharm would expose them
   }
-  atom->extractable["shtype"] = (void *) shtype.data();
+  if (getenv("LAMMPS_HOST_SHTYPE_CUSTOM")) {          // fix property/atom i_shtype: a custom integer vector
+    atom->custom_names.push_back("shtype");
+    atom->custom_flag.push_back(0);
+    atom->custom_cols.push_back(0);
+    atom->ivector = ivec;
+    if (atom->custom_names.size() != 1) return 6;     // (index 0 of ivector: not together with the custom quaternions)
+  } else {
+    atom->extractable["shtype"] = (void *) shtype.data();
+  }
   lmp.force->newton_pair = newton;
 
   NeighList list;
@@ -114,6 +132,7 @@ int main(int argc, char **argv)
   for (int i = 1; i <= ntypes; i++)
     for (int j = i; j <= ntypes; j++) cut = pair.init_one(i, j);
 
+  fprintf(stderr, "lammps_host: stub generation %d\n", SHPAIR_STUB_GEN);
   pair.compute(eflag ? 3 : 0, eflag ? 3 : 0);    // step 1: global and per-atom tallies
   const double e1 = pair.eng_vdwl;
   std::vector<double> ea(nall, 0.0), va(6 * (size_t) nall, 0.0);

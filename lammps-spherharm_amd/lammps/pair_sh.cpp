@@ -20,6 +20,8 @@
 
 #include "pair_sh.h"
 
+#include "sh_lammps_compat.h"    // which LAMMPS API generation (SHPAIR_LAMMPS_VERSION / SHPAIR_LMP_* switches)
+
 #include "atom.h"
 #include "comm.h"
 #include "error.h"
@@ -239,7 +241,7 @@ void PairSH::coeff(int narg, char **arg)
   if (narg != 4) error->all(FLERR, "Incorrect args for pair coefficients: pair_coeff I J kn exponent");
   if (!allocated) allocate();
   int ilo, ihi, jlo, jhi;
-#ifdef SHPAIR_LAMMPS_OLD_API    // LAMMPS before 2020: Force::bounds; later: utils::bounds
+#if SHPAIR_LMP_FORCE_BOUNDS
   force->bounds(FLERR, arg[0], atom->ntypes, ilo, ihi);
   force->bounds(FLERR, arg[1], atom->ntypes, jlo, jhi);
 #else
@@ -266,18 +268,17 @@ void PairSH::coeff(int narg, char **arg)
 void PairSH::init_style()
 {
   if (!ctx) error->all(FLERR, "pair sh: pair_style sh was not processed");
-  int flag = 0, cols = 0;
-  const bool have_quat = atom->extract("quat") || atom->find_custom("quat", flag, cols) >= 0;
-  const bool have_shtype = atom->extract("shtype") || atom->find_custom("shtype", flag, cols) >= 0;
-  if (!have_quat) error->all(FLERR, "pair sh requires per-atom quaternions (atom_style spherharm, or fix property/atom d2_quat 4)");
-  if (!have_shtype) error->all(FLERR, "pair sh requires a per-atom shape index (atom_style spherharm, or fix property/atom i_shtype)");
+  int custom = 0;
+  if (!sh_lammps::find_quat(atom, custom)) error->all(FLERR, sh_lammps::quat_requirement());
+  if (!sh_lammps::find_shtype(atom))
+    error->all(FLERR, "pair sh requires a per-atom shape index (atom_style spherharm, or fix property/atom i_shtype)");
   load_shapes();    // also sizes the coefficient tables, so pair_coeff values go in afterwards
   for (int i = 1; i <= atom->ntypes; i++)
     for (int j = 1; j <= atom->ntypes; j++) {
       if (!setflag[i][j] && !setflag[j][i]) error->all(FLERR, "All pair coeffs are not set");
       check(shpair_set_coeff(ctx, i, j, kn[i][j], exponent[i][j]), "shpair_set_coeff");
     }
-#ifdef SHPAIR_LAMMPS_OLD_API
+#if SHPAIR_LMP_NEIGH_REQUEST
   neighbor->request(this, instance_me);    // default request: half list
 #else
   neighbor->add_request(this);    // default request: half list, newton follows the run
@@ -301,7 +302,12 @@ double PairSH::init_one(int i, int j)
 
 void PairSH::compute(int eflag, int vflag)
 {
+#if SHPAIR_LMP_EV_SETUP
+  if (eflag || vflag) ev_setup(eflag, vflag);
+  else evflag = vflag_fdotr = eflag_global = vflag_global = eflag_atom = vflag_atom = 0;
+#else
   ev_init(eflag, vflag);
+#endif
 
   const int nlocal = atom->nlocal;
   const int nall = nlocal + atom->nghost;
@@ -313,27 +319,20 @@ void PairSH::compute(int eflag, int vflag)
   }
 
   // per-atom orientation and shape index
-  int flag = 0, cols = 0, idx;
-  double **quat = (double **) atom->extract("quat");
-  quat_is_custom = 0;
-  if (!quat && (idx = atom->find_custom("quat", flag, cols)) >= 0 && flag == 1 && cols == 4) {
-    quat = atom->darray[idx];
-    quat_is_custom = 1;
-  }
+  double **quat = sh_lammps::find_quat(atom, quat_is_custom);
   if (!quat) error->one(FLERR, "pair sh: per-atom quaternions disappeared");
   // Collective: every rank calls it whenever the orientations live in a custom property — also a rank without
   // ghosts (or without atoms), whose owned atoms may be ghosts of a neighbour that waits for them.  Comm handles
   // zero-length swaps.
   if (quat_is_custom) {
     quat_comm = quat;
-#ifdef SHPAIR_LAMMPS_OLD_API
+#if SHPAIR_LMP_FORWARD_COMM_PAIR
     comm->forward_comm_pair(this);
 #else
     comm->forward_comm(this);
 #endif
   }
-  int *shtype = (int *) atom->extract("shtype");
-  if (!shtype && (idx = atom->find_custom("shtype", flag, cols)) >= 0 && flag == 0 && cols == 0) shtype = atom->ivector[idx];
+  int *shtype = sh_lammps::find_shtype(atom);
   if (!shtype) error->one(FLERR, "pair sh: per-atom shape index disappeared");
 
   double eng = 0.0, vir[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};

@@ -7,7 +7,20 @@
 // tests/lammps_host to drive PairSH::settings/coeff/init_style/compute on a
 // synthetic bed.  Nothing here is shipped or used outside that test; with a
 // real LAMMPS tree the adapter includes the real headers instead.
+//
+// SHPAIR_STUB_GEN selects which GENERATION of the LAMMPS API the stub offers — and ONLY that one, so that an adapter
+// compiled with the wrong switches (sh_lammps_compat.h) fails to compile here as it would against the real tree
+// ([PRIOR]: the dates are recollections, unverified; tests/test_lammps_adapter.py compiles and runs all five):
+//   4 (default)  2022-06 and later : Pair::ev_init, utils::bounds, Atom::find_custom(name, flag, cols) + 2-d custom
+//                                    arrays, Neighbor::add_request(this), Comm::forward_comm(Pair *)
+//   3            2021-07 .. 2022-03: as 4, but Neighbor::request(this, instance_me) and Comm::forward_comm_pair(this)
+//   2            2020-08 .. 2021-07: as 3, but Atom::find_custom(name, flag) — no 2-d custom arrays
+//   1            2019-04 .. 2020-08: as 2, but Force::bounds(FLERR, str, nmax, lo, hi)
+//   0            before 2019-03    : as 1, but Pair::ev_setup(eflag, vflag) (no ev_init)
 #pragma once
+#ifndef SHPAIR_STUB_GEN
+#define SHPAIR_STUB_GEN 4
+#endif
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -59,7 +72,6 @@ class Atom {
   int firstgroup = -1, nfirst = 0;
   int **iarray = nullptr;
   int **ivector = nullptr;      // custom per-atom int vectors
-  double ***darray = nullptr;   // custom per-atom double arrays
   std::map<std::string, void *> extractable;
   std::vector<std::string> custom_names;
   std::vector<int> custom_flag, custom_cols;
@@ -68,6 +80,8 @@ class Atom {
     auto it = extractable.find(name);
     return it == extractable.end() ? nullptr : it->second;
   }
+#if SHPAIR_STUB_GEN >= 3
+  double ***darray = nullptr;   // custom per-atom double arrays (fix property/atom d2_name N)
   int find_custom(const char *name, int &flag, int &cols)
   {
     for (size_t i = 0; i < custom_names.size(); i++)
@@ -78,6 +92,18 @@ class Atom {
       }
     return -1;
   }
+#else
+  // before the 2021 custom arrays: vectors only (i_name, d_name), two arguments
+  int find_custom(const char *name, int &flag)
+  {
+    for (size_t i = 0; i < custom_names.size(); i++)
+      if (custom_names[i] == name && custom_cols[i] == 0) {
+        flag = custom_flag[i];
+        return (int) i;
+      }
+    return -1;
+  }
+#endif
 };
 
 class Pair;
@@ -86,6 +112,7 @@ class Force {
   int newton_pair = 1;
   Pair *pair = nullptr;
   Pair *pair_match(const char *, int) { return pair; }
+#if SHPAIR_STUB_GEN <= 1
   void bounds(const char *, int, char *str, int nmax, int &nlo, int &nhi)
   {
     if (strcmp(str, "*") == 0) {
@@ -94,6 +121,7 @@ class Force {
     } else
       nlo = nhi = atoi(str);
   }
+#endif
 };
 
 class NeighList {
@@ -107,8 +135,11 @@ class Neighbor {
  public:
   bigint lastcall = 0;
   int nrequest = 0;
+#if SHPAIR_STUB_GEN >= 4
   void add_request(class Pair *) { nrequest++; }
-  void request(void *, int) { nrequest++; }
+#else
+  int request(void *, int) { return nrequest++; }
+#endif
 };
 
 // Comm::forward_comm(Pair *) as LAMMPS does it for a pair style with comm_forward > 0: pack the owners' values of the
@@ -119,8 +150,14 @@ class Comm {
   std::vector<int> ghost_owner;   // test scaffold: owner row of ghost nlocal + g
   class Atom *atom_for_comm = nullptr;
   int forward_calls = 0;
-  inline void forward_comm(class Pair *pair);
-  inline void forward_comm_pair(class Pair *pair) { forward_comm(pair); }   // pre-2020 name
+#if SHPAIR_STUB_GEN >= 4
+  inline void forward_comm(class Pair *pair) { do_forward(pair); }
+#else
+  inline void forward_comm_pair(class Pair *pair) { do_forward(pair); }     // the name before 2022
+#endif
+
+ private:
+  inline void do_forward(class Pair *pair);
 };
 class Update {
  public:
@@ -160,6 +197,7 @@ class Pointers {
   Update *&update;
 };
 
+#if SHPAIR_STUB_GEN >= 2
 namespace utils {
 inline void bounds(const char *, int, const char *str, int nmin, int nmax, int &nlo, int &nhi, Error *)
 {
@@ -170,6 +208,7 @@ inline void bounds(const char *, int, const char *str, int nmin, int nmax, int &
     nlo = nhi = atoi(str);
 }
 }    // namespace utils
+#endif
 
 class Pair : protected Pointers {
  public:
@@ -182,7 +221,7 @@ class Pair : protected Pointers {
   int instance_me = 0;
   NeighList *list = nullptr;
   int eflag_either = 0, eflag_global = 0, eflag_atom = 0, vflag_either = 0, vflag_global = 0, vflag_atom = 0;
-  int evflag = 0;
+  int evflag = 0, vflag_fdotr = 0;
   double *eatom = nullptr, **vatom = nullptr;    // per-atom tallies, (re)sized by ev_init as in LAMMPS
   int maxeatom = 0, maxvatom = 0;
 
@@ -196,7 +235,14 @@ class Pair : protected Pointers {
   int comm_forward = 0;    // doubles per atom in forward communication
   virtual int pack_forward_comm(int, int *, double *, int, int *) { return 0; }
   virtual void unpack_forward_comm(int, int, double *) {}
-  void ev_init(int eflag, int vflag)
+#if SHPAIR_STUB_GEN >= 1
+  void ev_init(int eflag, int vflag) { ev_setup_impl(eflag, vflag); }
+#else
+  void ev_setup(int eflag, int vflag) { ev_setup_impl(eflag, vflag); }     // before 2019: called only when a flag is set
+#endif
+
+ private:
+  void ev_setup_impl(int eflag, int vflag)
   {
     // LAMMPS bit convention: 1 = global, 2 = per-atom
     eflag_either = eflag ? 1 : 0;
@@ -227,9 +273,11 @@ class Pair : protected Pointers {
     eng_vdwl = eng_coul = 0.0;
     for (double &v : virial) v = 0.0;
   }
+
+ public:
 };
 
-inline void Comm::forward_comm(Pair *pair)
+inline void Comm::do_forward(Pair *pair)
 {
   ++forward_calls;
   const int ng = (int) ghost_owner.size();

@@ -220,7 +220,7 @@ def test_a_rank_that_loses_all_its_atoms_keeps_stepping(overlap):
     from shpair import shapes, mrank
     from shpair.run import DeviceRun
     grid, periodic, world = (2, 1, 1), (0, 0, 0), 2
-    lmax, nq, skin, dt, nsteps = 4, 8, 0.2, 2e-3, 320
+    lmax, nq, skin, dt, nsteps = 4, 8, 0.2, 2e-3, 480
     shp = [shapes.random_shape(lmax, 400 + s, amp=0.2) for s in range(2)]
     lo, hi = np.zeros(3), np.array([40.0, 9.5, 9.5])
     rng = np.random.default_rng(31)
