@@ -526,7 +526,12 @@ def host_path_leg(args, sb, kernel_ms_device, calls=7):
     from shpair import capi
     g = sb.gbed
     n = sb.nlocal
-    sp = make_ctx(args, sb.shp, 0)
+    # The headline's own context, as a LAMMPS rank has ONE: its two streams (compute, f / torque upload) were created
+    # first in this process and sit on hardware queues of their own.  (A second context's streams share queues with the
+    # first's — HIP maps streams onto a few hardware queues round robin — and the upload beside the set-up and rotation
+    # kernels then serialises with them: +0.11 ms per call, tools/host_path_probe.py, profiles/r05_e_host_path_probe.txt.)
+    sp = getattr(sb, "sp", None) or make_ctx(args, sb.shp, 0)
+    own_ctx = sp is not getattr(sb, "sp", None)
     lib = capi.load_library()
     il = np.ascontiguousarray(sb.il, dtype=np.int32)
     of = np.ascontiguousarray(sb.of, dtype=np.int32)
@@ -594,7 +599,9 @@ def host_path_leg(args, sb, kernel_ms_device, calls=7):
                 "shpair_compute() (upload, kernels, download, host-side synchronisation) minus the hipEvent time of its kernels; "
                 "set_neighbors = one call per reneighbouring, from firstneigh row pointers indexed by atom (min of 5 / median)",
     }
-    sp.close()
+    sp.set_option("timing", 0)
+    if own_ctx:
+        sp.close()
     return out
 
 

@@ -220,22 +220,23 @@ def test_a_rank_that_loses_all_its_atoms_keeps_stepping(overlap):
     from shpair import shapes, mrank
     from shpair.run import DeviceRun
     grid, periodic, world = (2, 1, 1), (0, 0, 0), 2
-    lmax, nq, skin, dt, nsteps = 4, 8, 0.2, 2e-3, 480
+    lmax, nq, skin, dt, nsteps = 4, 8, 0.2, 2e-3, 560
     shp = [shapes.random_shape(lmax, 400 + s, amp=0.2) for s in range(2)]
     lo, hi = np.zeros(3), np.array([40.0, 9.5, 9.5])
     rng = np.random.default_rng(31)
-    gy, gz = np.meshgrid(1.0 + 1.85 * np.arange(4), 1.0 + 1.85 * np.arange(4), indexing="ij")
+    # spacing 2.3: bounding spheres overlap a little (listed pairs, some of them touching lightly), the blocks stay blocks
+    gy, gz = np.meshgrid(1.0 + 2.3 * np.arange(4), 1.0 + 2.3 * np.arange(4), indexing="ij")
 
     def block(x0):
-        return np.concatenate([np.stack([np.full(16, x0 + 1.85 * k), gy.ravel(), gz.ravel()], axis=1) for k in range(2)])
-    x = np.concatenate([block(16.0), block(30.0)]) + rng.uniform(-0.03, 0.03, (64, 3))
+        return np.concatenate([np.stack([np.full(16, x0 + 2.3 * k), gy.ravel(), gz.ravel()], axis=1) for k in range(2)])
+    x = np.concatenate([block(15.0), block(30.0)]) + rng.uniform(-0.03, 0.03, (64, 3))
     n = x.shape[0]
     from shpair import bed
     quat = bed.random_quaternions(n, rng)
     sht = rng.integers(0, 2, n).astype(np.int32)
     tag = np.arange(n, dtype=np.int32)
     v0 = np.zeros((n, 3))
-    v0[:32, 0] = 6.0      # the left cluster crosses x = 20 after ~0.35 time units, whole
+    v0[:32, 0] = 6.0      # the left cluster crosses x = 20 between t = 0.45 and t = 0.85, whole by step ~430
     sp0 = _ctx(lmax, shp, nq)
     cut = 2.0 * max(sp0.rmax(s) for s in range(2)) + skin
     xw, owner = _distribute(grid, lo, hi, periodic, cut, x)

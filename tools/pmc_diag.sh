@@ -8,7 +8,7 @@ root=$(cd "$(dirname "$0")/.." && pwd)
 out=$root/gpurun_out
 mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp
-args="--cpu-seconds 0 --ts-steps 0 --peak-ms 0 --scale-ref 0 --steps 10 $*"
+args="--cpu-seconds 0 --ts-steps 0 --peak-ms 0 --scale-ref 0 --configs 0 --host-path 0 --steps 10 $*"
 i=0
 IFS=';' read -ra SETS <<< "$sets"
 for set in "${SETS[@]}"; do

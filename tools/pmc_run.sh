@@ -9,7 +9,7 @@ root=$(cd "$(dirname "$0")/.." && pwd)
 out=$root/gpurun_out
 mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp
-args="--cpu-seconds 0 --ts-steps 0 --peak-ms 0 --scale-ref 0 --steps 10 $*"
+args="--cpu-seconds 0 --ts-steps 0 --peak-ms 0 --scale-ref 0 --configs 0 --host-path 0 --steps 10 $*"
 python3 "$root/bench.py" $args > "$out/${tag}_bench.json"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/${tag}_trace" -o t -- python3 "$root/bench.py" $args > /dev/null
 for set in "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_SALU SQ_INSTS_SMEM" \
