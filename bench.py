@@ -131,6 +131,9 @@ def parse():
                     help="N > 1: option \"halo_overlap\" (1: the forward exchange runs on a stream of its own beside the pair "
                          "kernels of the slots that touch owned atoms only; 2: the reverse exchange hidden too, beside the second half of "
                          "those slots); -1 = auto: 2 if the in-run check against 0 passes AND the in-run A/B says it is not slower, else 0")
+    ap.add_argument("--halo-stream-priority", type=int, default=-1, choices=[-1, 0, 1], help="N > 1: option \"halo_stream_priority\" (the "
+                    "exchange stream of halo_overlap: 0 an ordinary stream, 1 one at the highest stream priority); -1 = both are "
+                    "checked and timed in the run, the faster correct one is used")
     ap.add_argument("--one-device", action="store_true", help="N > 1 with --transport rccl: every rank uses GPU 0 (only to probe "
                     "what RCCL does with several ranks on one device; RCCL normally refuses)")
     a = ap.parse_args()
@@ -142,6 +145,28 @@ def parse():
     if a.verify_overlap is None:
         a.verify_overlap = multi
     return a
+
+
+_OUT_FD = None
+
+
+def own_stdout():
+    """From here on file descriptor 1 of this process is stderr, and the JSON line goes out through a private copy of the
+    real stdout: RCCL prints a version banner on stdout when its first communicator comes up, gloo a line of its own —
+    libraries this script loads, writing into the stream whose ONE line the driver parses."""
+    global _OUT_FD
+    if _OUT_FD is None:
+        sys.stdout.flush()
+        _OUT_FD = os.dup(1)
+        os.dup2(2, 1)
+
+
+def emit(text):
+    if _OUT_FD is None:
+        print(text, flush=True)
+    else:
+        sys.stdout.flush()
+        os.write(_OUT_FD, (text + "\n").encode())
 
 
 def error_line(args, what):
@@ -199,7 +224,7 @@ class Watchdog:
         msg = f"rank {rank}: '{w}' {why}"
         print(f"bench.py: {msg}; giving up with exit code {code}", file=sys.stderr, flush=True)
         if self.emit and self.args is not None:
-            print(error_line(self.args, msg), flush=True)
+            emit(error_line(self.args, msg))
         os._exit(code)
 
     def _loop(self):
@@ -417,6 +442,7 @@ def main_single(args):
     if _kfd_gpu_nodes() == 0:    # sysfs only: the parent makes no HIP / HSA call before the scale_ref child has come and gone
         print("bench.py: no GPU visible; the HIP path has no CPU fallback", file=sys.stderr)
         sys.exit(3)
+    own_stdout()
     wd = Watchdog(args, emit=True)   # only the whole-run bound: one GPU, no peer to wait for
     scale_ref = scale_ref_leg(args) if args.scale_ref else None   # a fresh child process, before this one's first GPU call
     if scale_ref is not None:
@@ -471,7 +497,7 @@ def main_single(args):
     if args.cpu_seconds > 0:
         out["cpu_baseline"] = cpu_baseline(args, sb.shp, sb.rmax, sb.gbed, sb.il, sb.of, sb.jl)
     out["elapsed_s"] = round(time.monotonic() - T_START, 1)
-    print(json.dumps(out), flush=True)
+    emit(json.dumps(out))
     sp.close()
     del wd
 
@@ -665,6 +691,7 @@ def scale_ref_leg(args):
             "--ramp", str(args.ramp), "--lmax", str(args.lmax), "--nq", str(args.nq), "--nshapes", str(args.nshapes),
             "--exponent", repr(float(args.exponent)), "--jpoly", str(args.jpoly), "--rule", args.rule, "--vthermal", repr(float(args.vthermal)),
             "--no-verify", "--peak-ms", "0", "--wait-s", str(args.wait_s), "--halo-overlap", str(args.halo_overlap),
+            "--halo-stream-priority", str(args.halo_stream_priority),
             "--total-s", f"{max(20.0, min(3.0 * args.wait_s, 0.4 * args.total_s if args.total_s > 0 else 1e9)):.0f}"]
     try:
         rc, out = run_rank_children(argv, 1, max(25.0, min(3.0 * args.wait_s, 0.4 * args.total_s if args.total_s > 0 else 1e9) + 5.0))
@@ -678,6 +705,7 @@ def scale_ref_leg(args):
                 "steps": ln["steps"], "particles": ln["config"]["particles_all_ranks"],
                 "contact_pairs": ln["config"]["contact_pairs_all_ranks"], "ghost_atoms": ln["config"]["ghost_atoms_rank0"],
                 "pair_kernel_ms": ln["roofline"]["kernel_ms"], "overlap_used": ln.get("overlap_used"),
+                "overlap_stream_priority_used": ln.get("overlap_stream_priority_used"),
                 "verify_overlap_ok": ln.get("verify_overlap_ok"), "overlap_ab_ms": ln.get("overlap_ab_ms"),
                 "transport": ln["halo"]["transport"], "ranks_reported_by_transport": ln["halo"]["ranks_reported_by_transport"],
                 "rebuilds_in_timed_steps": ln["halo"]["rebuilds_in_timed_steps"][0], "workload": ln["config"]["workload"],
@@ -782,6 +810,7 @@ def multi_rank_body(args, rank, world, device, coll, hub, uid, result, wd=None):
     candidate = 2 if args.halo_overlap < 0 else args.halo_overlap
     check_overlap = bool(args.verify_overlap) and candidate > 0
     sp.set_option("halo_overlap", 0 if check_overlap else candidate)
+    sp.set_option("halo_stream_priority", max(0, args.halo_stream_priority))
     skin = 0.1
     grid = mrank.proc_grid(world)
     cfg = config4_bed(args, world, grid)
@@ -836,18 +865,28 @@ def multi_rank_body(args, rank, world, device, coll, hub, uid, result, wd=None):
         return st["n_contact"], st["n_touching"]
 
     # ---- the path the timed steps take, checked in the run itself: from ONE saved state, k timesteps of shhalo_run_device
-    # with "halo_overlap" 0 and again with the candidate; owned x / f / torque compared by tag on every rank (4 steps: no
-    # chaos yet); then both are timed.  A candidate that differs is not used (and the exit code says so).
-    ov = {"requested": args.halo_overlap, "candidate": candidate, "used": candidate, "checked": False}
+    # with "halo_overlap" 0 and again with every candidate mode — the overlap value on an ordinary second stream and on
+    # one at the highest stream priority ("halo_stream_priority") — owned x / f / torque compared by tag on every rank
+    # (4 steps: no chaos yet); then all modes are timed.  A candidate that differs is not used (and the exit code says so).
+    def mode_key(m):
+        return str(m[0]) + ("p" if m[1] else "")
+    prios = [0, 1] if args.halo_stream_priority < 0 else [args.halo_stream_priority]
+    cands = [(candidate, pr) for pr in prios] if candidate > 0 else []
+    used = cands[0] if cands else (0, 0)
+    ov = {"requested": args.halo_overlap, "candidate": candidate, "checked": False}
+
+    def set_mode(m):
+        sp.set_option("halo_overlap", m[0])
+        sp.set_option("halo_stream_priority", m[1])
     if check_overlap:
         box = float(np.max(cfg["hi"] - cfg["lo"]))
-        with wd.phase("halo_overlap check: 4 timesteps at 0 and at the candidate from one saved state", 2 * args.wait_s):
+        with wd.phase("halo_overlap check: 4 timesteps at 0 and at each candidate from one saved state", 2 * args.wait_s):
             run.run(4)                      # code objects loaded, clocks up
             state = run.save_state()
 
-            def leg(opt, nsteps):
-                sp.set_option("halo_overlap", opt)
-                run.restore_state(state)    # collective: migration, ghost plan, list (partitioned when opt > 0), forces
+            def leg(m, nsteps):
+                set_mode(m)
+                run.restore_state(state)    # collective: migration, ghost plan, list (partitioned when overlap > 0), forces
                 run.sync()
                 coll.barrier()
                 t0 = time.perf_counter()
@@ -855,37 +894,45 @@ def multi_rank_body(args, rank, world, device, coll, hub, uid, result, wd=None):
                 run.sync()
                 coll.barrier()
                 return time.perf_counter() - t0
-            leg(0, 4)
+            leg((0, 0), 4)
             ref_owned = run.owned()
-            leg(candidate, 4)
-            got = run.owned()
-            if os.environ.get("SHPAIR_BENCH_FAULT") == "overlap" and rank == 0 and got[4].size:
-                got[4][0, 0] += 1e-5 * max(1.0, float(np.abs(got[4]).max()))   # diagnostic hook (tests): a wrong candidate
-            errs = coll.gather(rank, _cmp_owned(ref_owned, got, box))
-            fscale = max(e[2] for e in errs) or 1.0
-            ov_err = max(max(e[0] for e in errs), max(e[1] for e in errs) / fscale)
-            ov_ok = bool(ov_err < 1e-9)
-            del ref_owned, got
-        ov.update(checked=True, rel_err=ov_err, ok=ov_ok, steps=4)
+            errs_of = {}
+            for m in cands:
+                leg(m, 4)
+                got = run.owned()
+                if os.environ.get("SHPAIR_BENCH_FAULT") == "overlap" and rank == 0 and got[4].size:
+                    got[4][0, 0] += 1e-5 * max(1.0, float(np.abs(got[4]).max()))   # diagnostic hook (tests): a wrong candidate
+                errs = coll.gather(rank, _cmp_owned(ref_owned, got, box))
+                fscale = max(e[2] for e in errs) or 1.0
+                errs_of[m] = max(max(e[0] for e in errs), max(e[1] for e in errs) / fscale)
+                del got
+            del ref_owned
+            good = [m for m in cands if errs_of[m] < 1e-9]
+        ov.update(checked=True, rel_err=max(errs_of.values()), ok=(len(good) == len(cands)), steps=4,
+                  rel_err_by_mode={mode_key(m): errs_of[m] for m in cands})
         with wd.phase("halo_overlap A/B timing", 2 * args.wait_s):
-            ab = {0: [], candidate: []}
-            for opt in (0, candidate, 0, candidate):
-                el = leg(opt, args.ab_steps)
-                ab[opt].append(max(coll.gather(rank, el)))     # max over ranks, as the timed region
-            ms = {str(k): 1e3 * min(v) / args.ab_steps for k, v in ab.items()}
-            ov["ab_ms_per_step"] = ms
+            modes = [(0, 0)] + cands
+            ab = {m: [] for m in modes}
+            for _ in range(2):
+                for m in modes:
+                    el = leg(m, args.ab_steps)
+                    ab[m].append(max(coll.gather(rank, el)))     # max over ranks, as the timed region
+            ms = {m: 1e3 * min(v) / args.ab_steps for m, v in ab.items()}
+            ov["ab_ms_per_step"] = {mode_key(m): ms[m] for m in modes}
             ov["ab_steps"] = args.ab_steps
-            if not ov_ok:
-                ov["used"] = 0
-                if rank == 0:
-                    print(f"bench.py: halo_overlap {candidate} differs from 0 after 4 timesteps (rel err {ov_err}): timing with 0",
+            for m in cands:
+                if m not in good and rank == 0:
+                    print(f"bench.py: halo_overlap {mode_key(m)} differs from 0 after 4 timesteps (rel err {errs_of[m]}): not used",
                           file=sys.stderr, flush=True)
-            elif args.halo_overlap < 0 and ms[str(candidate)] > ms["0"]:
-                ov["used"] = 0     # auto: correct, but not faster here
-            sp.set_option("halo_overlap", ov["used"])
+            pool = good + ([(0, 0)] if (args.halo_overlap < 0 or not good) else [])   # auto: 0 competes; asked for: only if nothing is right
+            used = min(pool, key=lambda m: ms[m])
+            set_mode(used)
             run.restore_state(state)
             del state
         lap("overlap_check")
+    else:
+        set_mode(used)
+    ov["used"], ov["prio_used"] = used
 
     with wd.phase("warm-up timesteps", 2 * args.wait_s):
         for _ in range(max(1, (args.ramp + args.warmup) // 4)):   # clock ramp and warm-up, in chunks so that rebuilds happen too
@@ -949,14 +996,16 @@ def multi_rank_body(args, rank, world, device, coll, hub, uid, result, wd=None):
                         "kernels of the owned-only slots",
             },
             "overlap_requested": ov["requested"], "overlap_candidate": ov["candidate"], "overlap_used": ov["used"],
-            "verify_overlap_rel_err": ov.get("rel_err"), "verify_overlap_ok": ov.get("ok"),
+            "overlap_stream_priority_used": ov["prio_used"],
+            "verify_overlap_rel_err": ov.get("rel_err"), "verify_overlap_ok": ov.get("ok"), "verify_overlap_rel_err_by_mode": ov.get("rel_err_by_mode"),
             "overlap_ab_ms": ov.get("ab_ms_per_step"), "overlap_ab_steps": ov.get("ab_steps"),
             "verify_overlap_note": "the path the timed steps take, checked in this run: from one saved state (x, v, quat, angmom of "
-                                   "every rank) 4 timesteps of shhalo_run_device with halo_overlap 0 and again with overlap_candidate; "
+                                   "every rank) 4 timesteps of shhalo_run_device with halo_overlap 0 and again with overlap_candidate — on an "
+                                   "ordinary second stream (key \"2\") and on one at the highest stream priority (key \"2p\"); "
                                    "owned positions (per box edge), forces and torques (per max |F|) compared by tag on every rank, bar "
                                    "1e-9; overlap_ab_ms: ms per timestep of both over overlap_ab_steps steps from that state (min of 2 "
-                                   "legs each, max over ranks).  overlap_used = 0 when the check fails (exit code 1) or, with "
-                                   "--halo-overlap -1, when the candidate is not faster",
+                                   "legs each, max over ranks).  A mode whose check fails is not used (and the exit code is 1); with "
+                                   "--halo-overlap -1 the fastest of 0 and the correct modes is used, else the fastest correct mode",
             "value_note": "contact pairs of all ranks (mean of the counts before and after the timed steps) x K / max-over-ranks time",
             "verify_rel_err": verify_err, "verify_ok": (None if verify_err is None else bool(verify_err < 1e-9)),
             "verify_note": "decomposed forces and torques of the initial configuration against a single-domain compute of the "
@@ -980,6 +1029,7 @@ def _line_rc(line):
 
 
 def main_multi(args):
+    own_stdout()
     wd = Watchdog(args, emit=(os.environ.get("RANK", "0") == "0"))
     wd.watch_sigterm()
     if os.environ.get("SHPAIR_BENCH_FAULT") == "stall":    # diagnostic hook (tests, no GPU needed): a rank that never comes back
@@ -1015,7 +1065,7 @@ def main_multi(args):
         if errs:
             print(errs[0], file=sys.stderr)
             sys.exit(1)
-        print(json.dumps(result["line"]), flush=True)
+        emit(json.dumps(result["line"]))
         hub.close()
         sys.exit(_line_rc(result["line"]))
     wsz = int(os.environ.get("WORLD_SIZE", "1"))
@@ -1056,10 +1106,10 @@ def main_multi(args):
         tb = traceback.format_exc()
         print(f"bench.py: rank {rank} failed:\n{tb}", file=sys.stderr, flush=True)
         if rank == 0:
-            print(error_line(args, f"rank 0 failed: {tb.strip().splitlines()[-1]}"), flush=True)
+            emit(error_line(args, f"rank 0 failed: {tb.strip().splitlines()[-1]}"))
         os._exit(1)
     if rank == 0:
-        print(json.dumps(result["line"]), flush=True)
+        emit(json.dumps(result["line"]))
         rc = _line_rc(result["line"])
     with wd.phase("shutdown barrier", args.wait_s):
         dist.barrier()

@@ -168,7 +168,10 @@ int shpair_compute_device(shpair_ctx *ctx, int nlocal, int nghost, const double 
  * slots run beside the forward exchange, the ghost slots follow it, the other half runs beside the reverse exchange,
  * whose unpack uses the same FP64 atomics (atomic accumulation only: with "deterministic" 2 behaves as 1); 0, the default: the
  * exchanges and the pair kernels follow each other on the caller's stream; same forces, another order of the per-atom
- * sums), "waves_per_block" (tuning: waves per workgroup of the one-wave contact kernels, default 1), "queue_slack"
+ * sums), "halo_stream_priority" (1: that second stream is one at the highest stream priority — a hardware queue of its
+ * own whatever other streams the process has, its few workgroups dispatched ahead of the pair kernels' backlog; 0, the
+ * default: an ordinary stream; takes effect at the next shhalo_run_device),
+ * "waves_per_block" (tuning: waves per workgroup of the one-wave contact kernels, default 1), "queue_slack"
  * (diagnostic, default 1: the node queue of the "jpoly" kernels takes what the wave's LDS layout leaves of its last
  * 1 280-byte allocation granule, up to 192 entries; 0: 128 entries).
  * Memory: the contact path keeps per-slot scratch in HBM — a 320-byte record and, for the "jpoly" family, two rotated

@@ -344,7 +344,8 @@ struct shhalo_ctx {
   shhalo_stats stats{};
   // option "halo_overlap" of the pair context: the forward exchange of a step runs on a stream of its own beside the
   // pair kernels of the slots that touch owned atoms only (made on first use)
-  hipStream_t st2 = nullptr;
+  hipStream_t st2x[2] = {nullptr, nullptr};   // the exchange stream of "halo_overlap": [0] ordinary, [1] at the highest stream priority
+  bool ev2 = false;
   hipEvent_t ev_ready = nullptr, ev_ghosts = nullptr, ev_bdone = nullptr, ev_rev = nullptr;
 };
 
@@ -667,7 +668,8 @@ void shhalo_destroy(shhalo_ctx* h)
   if (h->ev_ghosts) (void)hipEventDestroy(h->ev_ghosts);
   if (h->ev_bdone) (void)hipEventDestroy(h->ev_bdone);
   if (h->ev_rev) (void)hipEventDestroy(h->ev_rev);
-  if (h->st2) (void)hipStreamDestroy(h->st2);
+  for (hipStream_t s2 : h->st2x)
+    if (s2) (void)hipStreamDestroy(s2);
   delete h;
 }
 
@@ -1006,12 +1008,43 @@ int shhalo_run_device(shhalo_ctx* h, shhalo_arrays* a, const shhalo_run_params* 
   H_HIP(h, hipSetDevice(h->sp->device));
   hipStream_t st = (hipStream_t)stream;
   shpair_ctx* sp = h->sp;
-  if (sp->opt_overlap && !h->st2) {
-    H_HIP(h, hipStreamCreateWithFlags(&h->st2, hipStreamNonBlocking));
-    H_HIP(h, hipEventCreateWithFlags(&h->ev_ready, hipEventDisableTiming));
-    H_HIP(h, hipEventCreateWithFlags(&h->ev_ghosts, hipEventDisableTiming));
-    H_HIP(h, hipEventCreateWithFlags(&h->ev_bdone, hipEventDisableTiming));
-    H_HIP(h, hipEventCreateWithFlags(&h->ev_rev, hipEventDisableTiming));
+  // "halo_overlap": the exchange stream.  Two kinds, made on first use, chosen per call by "halo_stream_priority":
+  //  [0] an ordinary non-blocking stream.  HIP maps a process's streams round robin onto a few hardware queues, and one
+  //      created as the fifth or later of the process (torch's, the context's two, RCCL's own come first) shares a queue
+  //      with one of them — if that is the compute stream the exchange runs behind the pair kernels it is meant to run
+  //      beside (measured for the host-pointer path's upload stream: +0.11 ms per call when it shared,
+  //      tools/host_path_probe.py);
+  //  [1] a stream at the highest stream priority: a priority level of its own is a queue of its own, and the pack /
+  //      RCCL / unpack kernels — a few workgroups, latency-critical — are dispatched ahead of the pair kernels' backlog.
+  //  Which is better between GPUs is unmeasured here (one GPU per box).  In the rehearsal of 8 rank threads on ONE GPU
+  //  [1] costs 5 % (26.0 against 24.8 ms per timestep; [0]: 24.5 against 24.6 without overlap,
+  //  profiles/r05_g_local8_priority.txt) — there every rank's high-priority kernels pre-empt every other rank's pair
+  //  kernels — so [0] is the default and bench.py --gpus N times both in the run itself.
+  hipStream_t st2 = nullptr;
+  if (sp->opt_overlap) {
+    const int kind = sp->opt_halo_prio ? 1 : 0;
+    if (!h->st2x[kind]) {
+      if (kind == 1) {
+        int prio_least = 0, prio_greatest = 0;
+        if (hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest) != hipSuccess) {
+          (void)hipGetLastError();
+          prio_least = prio_greatest = 0;
+        }
+        if (hipStreamCreateWithPriority(&h->st2x[1], hipStreamNonBlocking, prio_greatest) != hipSuccess) {
+          (void)hipGetLastError();
+          h->st2x[1] = nullptr;
+        }
+      }
+      if (!h->st2x[kind]) H_HIP(h, hipStreamCreateWithFlags(&h->st2x[kind], hipStreamNonBlocking));
+    }
+    st2 = h->st2x[kind];
+    if (!h->ev2) {
+      H_HIP(h, hipEventCreateWithFlags(&h->ev_ready, hipEventDisableTiming));
+      H_HIP(h, hipEventCreateWithFlags(&h->ev_ghosts, hipEventDisableTiming));
+      H_HIP(h, hipEventCreateWithFlags(&h->ev_bdone, hipEventDisableTiming));
+      H_HIP(h, hipEventCreateWithFlags(&h->ev_rev, hipEventDisableTiming));
+      h->ev2 = true;
+    }
   }
   const bool body = p->gravity[0] != 0.0 || p->gravity[1] != 0.0 || p->gravity[2] != 0.0 || p->gamma_t != 0.0 || p->gamma_r != 0.0;
   int nghost = *nghost_io, nreb = 0;
@@ -1054,10 +1087,10 @@ int shhalo_run_device(shhalo_ctx* h, shhalo_arrays* a, const shhalo_run_params* 
     // "halo_overlap": the forward exchange (pack, ncclSend / ncclRecv per peer, unpack) goes to a second stream behind
     // this step's positions, and the pair kernels of the slots whose atoms are all owned — the front segment of the
     // partitioned list, down to a multiple of 32 slots — run beside it; the slots with a ghost wait for the exchange.
-    const bool overlap = sp->opt_overlap && h->st2 != nullptr;
-    hipStream_t sf = overlap ? h->st2 : st;
+    const bool overlap = sp->opt_overlap && st2 != nullptr;
+    hipStream_t sf = overlap ? st2 : st;
     if (overlap) {
-      if (hipEventRecord(h->ev_ready, st) != hipSuccess || hipStreamWaitEvent(h->st2, h->ev_ready, 0) != hipSuccess) {
+      if (hipEventRecord(h->ev_ready, st) != hipSuccess || hipStreamWaitEvent(st2, h->ev_ready, 0) != hipSuccess) {
         h->err = "hipEventRecord / hipStreamWaitEvent failed (halo_overlap)";
         rc = SHPAIR_EHIP;
         break;
@@ -1065,7 +1098,7 @@ int shhalo_run_device(shhalo_ctx* h, shhalo_arrays* a, const shhalo_run_params* 
     }
     rc = shhalo_forward_device(h, a->x, a->quat, sf);
     if (rc) break;
-    if (overlap && hipEventRecord(h->ev_ghosts, h->st2) != hipSuccess) {
+    if (overlap && hipEventRecord(h->ev_ghosts, st2) != hipSuccess) {
       h->err = "hipEventRecord failed (halo_overlap)";
       rc = SHPAIR_EHIP;
       break;
@@ -1104,14 +1137,14 @@ int shhalo_run_device(shhalo_ctx* h, shhalo_arrays* a, const shhalo_run_params* 
       }
       if (!rc && overlap_rev) {
         // every contribution to a ghost row is in: the reverse exchange starts on the second stream ...
-        if (hipEventRecord(h->ev_bdone, st) != hipSuccess || hipStreamWaitEvent(h->st2, h->ev_bdone, 0) != hipSuccess) {
+        if (hipEventRecord(h->ev_bdone, st) != hipSuccess || hipStreamWaitEvent(st2, h->ev_bdone, 0) != hipSuccess) {
           h->err = "hipEventRecord / hipStreamWaitEvent failed (halo_overlap 2)";
           rc = SHPAIR_EHIP;
           break;
         }
-        rc = shhalo_reverse_device(h, a->f, a->torque, h->st2);
+        rc = shhalo_reverse_device(h, a->f, a->torque, st2);
         if (rc) break;
-        if (hipEventRecord(h->ev_rev, h->st2) != hipSuccess) {
+        if (hipEventRecord(h->ev_rev, st2) != hipSuccess) {
           h->err = "hipEventRecord failed (halo_overlap 2)";
           rc = SHPAIR_EHIP;
           break;
@@ -1150,7 +1183,7 @@ int shhalo_run_device(shhalo_ctx* h, shhalo_arrays* a, const shhalo_run_params* 
   }
   const hipError_t es = hipStreamSynchronize(st);
   // a step that ended early may have left an exchange in flight on the second stream, reading the caller's arrays
-  if (rc != SHPAIR_OK && h->st2) (void)hipStreamSynchronize(h->st2);
+  if (rc != SHPAIR_OK && st2) (void)hipStreamSynchronize(st2);
   if (rc == SHPAIR_OK && es == hipSuccess && kernel_ms) {
     double sum = 0.0;
     for (int k = 0; k < ntimed; ++k)

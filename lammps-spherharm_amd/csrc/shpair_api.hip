@@ -1146,6 +1146,7 @@ int shpair_set_option(shpair_ctx* c, const char* key, int value)
   else if (!strcmp(key, "waves_per_block")) c->opt_wpb = value;
   else if (!strcmp(key, "queue_slack")) c->opt_queue_slack = value ? 1 : 0;
   else if (!strcmp(key, "halo_overlap")) c->opt_overlap = value <= 0 ? 0 : (value >= 2 ? 2 : 1);
+  else if (!strcmp(key, "halo_stream_priority")) c->opt_halo_prio = value != 0;   // takes effect at the next shhalo_run_device (both kinds of stream are kept)
   else CTX_FAIL(c, SHPAIR_EINVAL, "unknown option '%s'", key);
   return SHPAIR_OK;
 }

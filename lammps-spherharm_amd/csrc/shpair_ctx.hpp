@@ -101,6 +101,7 @@ struct shpair_ctx {
                          // stream; 1 / 2 are opt-in until a run between GPUs has measured them — bench.py --gpus N tries 2, checks it
                          // against 0 in the run itself and reports both): device-built lists are partitioned interior / boundary and
                          // shhalo_run_device runs the interior slots while the forward (2: and the reverse) exchange is in flight
+  int opt_halo_prio = 0; // "halo_stream_priority": 1 = the exchange stream of "halo_overlap" is one at the highest stream priority (a hardware queue of its own; shhalo_api.hip)
   int n_interior = 0;    // slots [0, n_interior) of the installed list touch owned atoms only (device-built lists)
   int opt_jpoly = -1;      // 1 / 0: compiled orders evaluate particle j from per-azimuth polynomials or not; -1: by the
                            // measured rule (shpair_api.hip use_jpoly)

@@ -52,7 +52,7 @@ def test_single_gpu_line_has_the_contract_fields():
     assert d["roofline"]["stale"] in (None, True, False) and d["utilisation"]["stale"] == d["roofline"]["stale"]
     assert sr["value"] > 1e7 and sr["steps"] == 20 and "configs[3]" in sr["workload"] and sr["ghost_atoms"] > 0
     assert abs(sr["value"] * sr["ms_per_step"] * 1e-3 - sr["contact_pairs"]) < 1e-6 * sr["contact_pairs"]
-    assert sr["verify_overlap_ok"] is True and sr["overlap_used"] in (0, 2) and set(sr["overlap_ab_ms"]) == {"0", "2"}
+    assert sr["verify_overlap_ok"] is True and sr["overlap_used"] in (0, 2) and set(sr["overlap_ab_ms"]) == {"0", "2", "2p"}
     # every other single-GPU workload of BASELINE.json, in the same line (3 warm-up + 5 timed steps each, after the headline)
     cf = d["configs"]
     assert cf["steps"] == 5 and cf["warmup"] == 3
@@ -131,7 +131,7 @@ def test_self_launcher_gives_the_line_of_torch_distributed_run():
     # the path the timed steps take was checked inside both runs: halo_overlap 2 against 0 from one saved state
     for d in (a, b):
         assert d["verify_overlap_ok"] is True and d["verify_overlap_rel_err"] < 1e-9 and d["overlap_candidate"] == 2
-        assert d["overlap_used"] in (0, 2) and d["halo"]["overlap_option"] == d["overlap_used"] and set(d["overlap_ab_ms"]) == {"0", "2"}
+        assert d["overlap_used"] in (0, 2) and d["halo"]["overlap_option"] == d["overlap_used"] and set(d["overlap_ab_ms"]) == {"0", "2", "2p"} and d["overlap_stream_priority_used"] in (0, 1)
         assert "first_build" in d["setup_s"]["rank0"] and "overlap_check" in d["setup_s"]["max_over_ranks"]
     assert a["scale_ref_cmd"] == b["scale_ref_cmd"] and a["library"] == b["library"] == "libshpair.so"
     assert 0.5 < a["value"] / b["value"] < 2.0
@@ -179,7 +179,7 @@ def test_multi_rank_line_rehearsed_as_rank_threads():
     assert d["verify_rel_err"] is not None and d["verify_rel_err"] < 1e-12
     # halo_overlap 2 (exchanges on a second stream beside the owned-only slots) against 0, 4 timesteps from one saved state
     assert d["verify_overlap_ok"] is True and d["verify_overlap_rel_err"] < 1e-9 and d["overlap_used"] in (0, 2)
-    assert set(d["overlap_ab_ms"]) == {"0", "2"} and min(d["overlap_ab_ms"].values()) > 0
+    assert set(d["overlap_ab_ms"]) == {"0", "2", "2p"} and d["overlap_stream_priority_used"] in (0, 1) and min(d["overlap_ab_ms"].values()) > 0
     h = d["halo"]
     assert h["transport"] == "local" and h["ranks_reported_by_transport"] == 8 and h["peers_rank0"] == 7
     assert min(h["ghost_atoms"]) > 0 and sum(h["owned_atoms"]) == d["config"]["particles_all_ranks"]
@@ -206,3 +206,4 @@ def test_a_wrong_overlap_result_is_not_used_and_fails_the_run():
     assert r.returncode == 0, r.stderr[-3000:]
     d = _last_json(r.stdout)
     assert d["verify_overlap_ok"] is True and d["overlap_used"] == 2 and d["halo"]["overlap_option"] == 2
+    assert set(d["verify_overlap_rel_err_by_mode"]) == {"2", "2p"}
