@@ -10,7 +10,8 @@
      orientation  atom->extract("quat")  or custom d2_quat   (nall x 4, w x y z)
      shape index  atom->extract("shtype") or custom i_shtype (0-based)
    Shape tables: the files named after `shapes`, one per shape index, text:
-     line 1: lmax ; then one line per (n, m >= 0): n m Re(a_nm) Im(a_nm)
+     [line 1: lmax ;] then one line per coefficient: n m Re(a_nm) Im(a_nm) — m >= 0, or the whole range -n..n of a
+     real radius (load_shapes below)
    (the reference's own shape-file format is unknown: its reader is absent
    from the mount).
 
@@ -182,49 +183,80 @@ void PairSH::load_shapes()
   for (int s = 0; s < nshapes; s++) {
     FILE *fp = fopen(shape_files[s].c_str(), "r");
     if (!fp) error->one(FLERR, "pair sh: cannot open shape file");
-    // line based: `#` starts a comment, blank lines are skipped; first data line `lmax`, then `n m Re Im`
-    // for any subset of the coefficients (the others are zero); anything else is an error, not an end of file
+    // line based: `#` starts a comment, blank lines are skipped.  Data lines are `n m Re Im` for any subset of the
+    // coefficients (the others are zero).  An optional FIRST data line with a single integer names lmax (this repo's
+    // writer puts it there); without it lmax is the largest n in the file.  m may be negative: files that list the whole
+    // range -n..n (a common layout of SH coefficient tables; [PRIOR]: the reference's own format is unknown, its reader
+    // is absent from the mount) are accepted when they describe a REAL radius, a_{n,-m} = (-1)^m conj(a_{n,m}) — checked
+    // to 1e-9 of the largest coefficient where both are listed; a coefficient listed only at -m fills +m.  Anything
+    // else is an error, not an end of file.
     int lmax = -1;
-    std::vector<double> anm;
+    bool first = true;
+    struct Entry { int n, m; double re, im; };
+    std::vector<Entry> ent;
     char line[512];
     while (fgets(line, sizeof(line), fp)) {
       if (char *hash = strchr(line, '#')) *hash = '\0';
       char *p = line;
       while (*p == ' ' || *p == '\t' || *p == '\r' || *p == '\n') ++p;
       if (*p == '\0') continue;
-      if (lmax < 0) {
-        char extra;
-        if (sscanf(p, "%d %c", &lmax, &extra) != 1 || lmax < 0 || lmax > SHPAIR_MAX_LMAX) {
-          fclose(fp);
-          error->one(FLERR, "pair sh: bad lmax in shape file");
-        }
-        anm.assign((size_t) (lmax + 1) * (lmax + 2), 0.0);
-        continue;
-      }
       int n, m;
       double re, im;
       char extra;
+      if (first) {
+        first = false;
+        int l0;
+        if (sscanf(p, "%d %c", &l0, &extra) == 1) {
+          if (l0 < 0 || l0 > SHPAIR_MAX_LMAX) {
+            fclose(fp);
+            error->one(FLERR, "pair sh: bad lmax in shape file");
+          }
+          lmax = l0;
+          continue;
+        }
+      }
       if (sscanf(p, "%d %d %lf %lf %c", &n, &m, &re, &im, &extra) != 4) {
         fclose(fp);
         error->one(FLERR, "pair sh: malformed line in shape file (expected: n m Re Im)");
       }
-      if (n < 0 || n > lmax || m < 0 || m > n) {
+      if (n < 0 || n > SHPAIR_MAX_LMAX || m < -n || m > n || (lmax >= 0 && n > lmax)) {
         fclose(fp);
         error->one(FLERR, "pair sh: (n, m) out of range in shape file");
       }
-      if (m == 0 && im != 0.0) {
-        fclose(fp);
-        error->one(FLERR, "pair sh: a_n0 must be real in shape file");
-      }
-      const int k = n * (n + 1) / 2 + m;
-      anm[2 * k] = re;
-      anm[2 * k + 1] = im;
-    }
-    if (lmax < 0) {
-      fclose(fp);
-      error->one(FLERR, "pair sh: empty shape file");
+      ent.push_back({n, m, re, im});
     }
     fclose(fp);
+    if (lmax < 0) {
+      if (ent.empty()) error->one(FLERR, "pair sh: empty shape file");
+      for (const Entry &e : ent) lmax = e.n > lmax ? e.n : lmax;
+    }
+    std::vector<double> anm((size_t) (lmax + 1) * (lmax + 2), 0.0);
+    std::vector<char> have((size_t) (lmax + 1) * (lmax + 2) / 2, 0);
+    double amax = 0.0;
+    for (const Entry &e : ent) amax = fmax(amax, fmax(fabs(e.re), fabs(e.im)));
+    for (const Entry &e : ent) {    // m >= 0 first
+      if (e.m < 0) continue;
+      if (e.m == 0 && fabs(e.im) > 1e-9 * amax) error->one(FLERR, "pair sh: a_n0 must be real in shape file");
+      const int k = e.n * (e.n + 1) / 2 + e.m;
+      anm[2 * k] = e.re;
+      anm[2 * k + 1] = e.m == 0 ? 0.0 : e.im;
+      have[k] = 1;
+    }
+    for (const Entry &e : ent) {    // then the mirror half, checked against it
+      if (e.m >= 0) continue;
+      const int mp = -e.m;
+      const int k = e.n * (e.n + 1) / 2 + mp;
+      const double sgn = (mp & 1) ? -1.0 : 1.0;
+      const double re = sgn * e.re, im = -sgn * e.im;    // (-1)^m conj(a_{n,-m})
+      if (have[k]) {
+        if (fabs(anm[2 * k] - re) > 1e-9 * amax || fabs(anm[2 * k + 1] - im) > 1e-9 * amax)
+          error->one(FLERR, "pair sh: shape file does not describe a real radius: a_{n,-m} != (-1)^m conj(a_{n,m})");
+      } else {
+        anm[2 * k] = re;
+        anm[2 * k + 1] = im;
+        have[k] = 1;
+      }
+    }
     check(shpair_set_shape(ctx, s, lmax, anm.data(), 0.0), "shpair_set_shape");
     double r = 0.0;
     check(shpair_get_rmax(ctx, s, &r), "shpair_get_rmax");

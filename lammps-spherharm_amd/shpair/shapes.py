@@ -120,20 +120,52 @@ def write_shape_file(path, lmax, anm):
 
 
 def read_shape_file(path):
-    """Returns (lmax, anm). Coefficients that the file does not list are zero; Im(a_n0) must be zero."""
+    """Returns (lmax, anm).  Same grammar as PairSH::load_shapes (lammps/pair_sh.cpp): data lines `n m Re Im`, an optional
+    first line with lmax alone (else lmax = the largest n), `#` comments; coefficients that the file does not list are
+    zero; m < 0 is accepted when a_{n,-m} = (-1)^m conj(a_{n,m}) (a real radius), and fills +m when only -m is listed."""
     with open(path) as fp:
         lines = [ln.split("#")[0].strip() for ln in fp]
     lines = [ln for ln in lines if ln]
-    lmax = int(lines[0])
-    a = np.zeros((nterms(lmax), 2))
-    for ln in lines[1:]:
+    if not lines:
+        raise ValueError(f"{path}: empty shape file")
+    lmax = None
+    if len(lines[0].split()) == 1:
+        lmax = int(lines[0])
+        lines = lines[1:]
+    ent = []
+    for ln in lines:
         n, m, re, im = ln.split()
         n, m = int(n), int(m)
-        if not (0 <= m <= n <= lmax):
-            raise ValueError(f"{path}: (n, m) = ({n}, {m}) outside lmax {lmax}")
-        if m == 0 and float(im) != 0.0:
+        if not (-n <= m <= n) or n < 0 or (lmax is not None and n > lmax):
+            raise ValueError(f"{path}: (n, m) = ({n}, {m}) out of range")
+        ent.append((n, m, float(re), float(im)))
+    if lmax is None:
+        if not ent:
+            raise ValueError(f"{path}: empty shape file")
+        lmax = max(e[0] for e in ent)
+    a = np.zeros((nterms(lmax), 2))
+    have = np.zeros(nterms(lmax), dtype=bool)
+    amax = max([max(abs(e[2]), abs(e[3])) for e in ent] + [0.0])
+    for n, m, re, im in ent:
+        if m < 0:
+            continue
+        if m == 0 and abs(im) > 1e-9 * amax:
             raise ValueError(f"{path}: a_{n}0 must be real")
-        a[n * (n + 1) // 2 + m] = (float(re), float(im))
+        k = n * (n + 1) // 2 + m
+        a[k] = (re, 0.0 if m == 0 else im)
+        have[k] = True
+    for n, m, re, im in ent:
+        if m >= 0:
+            continue
+        k = n * (n + 1) // 2 - m
+        sg = -1.0 if (-m) & 1 else 1.0
+        v = (sg * re, -sg * im)
+        if have[k]:
+            if abs(a[k, 0] - v[0]) > 1e-9 * amax or abs(a[k, 1] - v[1]) > 1e-9 * amax:
+                raise ValueError(f"{path}: not a real radius: a_({n},{m}) != (-1)^m conj(a_({n},{-m}))")
+        else:
+            a[k] = v
+            have[k] = True
     return lmax, a.ravel()
 
 

@@ -49,6 +49,10 @@ def write_inputs(tmp_path, case, nlocal, newton, eflag):
         # the adapter's reader takes comments and blank lines too
         txt = open(p).read().split("\n")
         open(p, "w").write("# shape %d of the test bed\n\n" % s + txt[0] + "   # lmax\n" + "\n".join(txt[1:]))
+        if s % 2 == 1:
+            # ... and tables over the whole range m = -n..n without an lmax line (PairSH::load_shapes, [PRIOR] layout)
+            from test_shape_io import _full_range_text
+            open(p, "w").write("# whole range of m, no header\n" + _full_range_text(case["lmax"], a))
         shapes.append(str(p))
     return str(bedf), shapes
 

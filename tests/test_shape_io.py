@@ -24,6 +24,46 @@ def test_shape_file_round_trip(tmp_path):
     assert lmax == 2 and a[0] == 3.5449077018110318 and a[2 * 4] == 0.1 and a[2 * 4 + 1] == -0.05 and np.count_nonzero(a) == 3
 
 
+def _full_range_text(lmax, a, header=False):
+    """The same coefficients as a table over the whole range m = -n..n (a common layout of SH coefficient files)."""
+    a = np.asarray(a).reshape(-1, 2)
+    out = [f"{lmax}"] if header else []
+    for n in range(lmax + 1):
+        for m in range(-n, n + 1):
+            re, im = a[n * (n + 1) // 2 + abs(m)]
+            if m < 0:
+                sg = -1.0 if (-m) & 1 else 1.0
+                re, im = sg * re, -sg * im
+            out.append(f"{n} {m} {float(re)!r} {float(im)!r}")
+    return "\n".join(out) + "\n"
+
+
+def test_shape_file_over_the_whole_range_of_m_and_without_a_header(tmp_path):
+    """[PRIOR] the reference's shape-file format is unknown (its reader is absent from the mount); tables `n m Re Im` over
+    m = -n..n without an lmax line are a common layout.  Accepted when they describe a real radius; the mirror half is
+    checked, not trusted."""
+    lmax = 5
+    a = shapes.random_shape(lmax, 17, amp=0.3)
+    for header in (False, True):
+        p = tmp_path / f"full{int(header)}.txt"
+        p.write_text(_full_range_text(lmax, a, header))
+        l2, b = shapes.read_shape_file(p)
+        assert l2 == lmax and np.array_equal(a, b)
+    # only the negative half listed: it fills the positive one
+    lines = [ln for ln in _full_range_text(lmax, a).split("\n") if ln and int(ln.split()[1]) <= 0]
+    (tmp_path / "neg.txt").write_text("\n".join(lines) + "\n")
+    l3, c = shapes.read_shape_file(tmp_path / "neg.txt")
+    assert l3 == lmax and np.abs(c - a).max() == 0.0
+    # a table that is not a real function is refused
+    bad = _full_range_text(lmax, a).split("\n")
+    k = next(i for i, ln in enumerate(bad) if ln.startswith("3 -2 "))
+    n_, m_, re_, im_ = bad[k].split()
+    bad[k] = f"{n_} {m_} {float(re_) + 0.01!r} {im_}"
+    (tmp_path / "notreal.txt").write_text("\n".join(bad))
+    with pytest.raises(ValueError, match="not a real radius"):
+        shapes.read_shape_file(tmp_path / "notreal.txt")
+
+
 def test_basis_matrix_reproduces_the_radius():
     lmax = 7
     a = shapes.random_shape(lmax, 9, amp=0.3)
