@@ -511,19 +511,19 @@ CONFIG_LEGS = (
 
 
 def configs_leg(args, warm=3, steps=5):
-    """The other single-GPU workloads of BASELINE.json, each through the very code of the headline (StaticBed): 3 warm-up
-    + 5 timed steps, a few seconds in all, run after the headline's timed region.  Numbers of a 5-step sample: they
+    """The other single-GPU workloads of BASELINE.json, each through the very code of the headline (StaticBed): the
+    headline's clock-ramp passes + 3 warm-up + 5 timed steps, a few seconds in all, run after the headline's timed region.  Numbers of a 5-step sample: they
     put every BASELINE config into the driver's own record; the headline stays the K-step figure."""
-    out = {"steps": steps, "warmup": warm,
+    out = {"steps": steps, "warmup": warm, "ramp_passes": args.ramp,
            "note": "same step as the headline (initial_integrate + clear + pair compute + final_integrate), same bed generator and "
                    "force law (kn=1000, exponent as --exponent), fresh context per workload; valu_f64_frac / roofline_frac as in the "
                    "headline's objects; utilisation from the static PMC table with its own `stale` flag"}
     for key, what, over in CONFIG_LEGS:
         a2 = argparse.Namespace(**{**vars(args), **over, "particles": 100000, "jpoly": -1, "rule": "sharp", "peak_ms": 0.0})
         try:
-            sb = StaticBed(a2, warm + steps + 1)
+            sb = StaticBed(a2, args.ramp + warm + steps + 1)
             nc, nt = sb.count()
-            el, kms = sb.timed(warm, steps)
+            el, kms = sb.timed(args.ramp + warm, steps)   # the clock-ramp passes too: the GPU idled while the host built this bed
             roof, valu, occ, util = roofline_objects(a2, sb.sp, nc, kms, 1)
             out[key] = {
                 "workload": what, "lmax": a2.lmax, "nq": a2.nq, "nshapes": a2.nshapes, "exponent": a2.exponent,
