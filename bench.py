@@ -485,7 +485,7 @@ def main_single(args):
     # everything below comes AFTER the headline's timed region and cannot disturb it
     if args.host_path:
         try:
-            out["host_path"] = host_path_leg(args, sb, kernel_ms)
+            out["host_path"] = host_path_leg(args, sb, kernel_ms, n_contact)
         except Exception as e:  # noqa: BLE001 — an extra leg never takes the headline with it
             out["host_path"] = {"error": repr(e)}
     if args.configs:
@@ -542,7 +542,7 @@ def configs_leg(args, warm=3, steps=5):
     return out
 
 
-def host_path_leg(args, sb, kernel_ms_device, calls=7):
+def host_path_leg(args, sb, kernel_ms_device, n_contact=0, calls=7):
     """What an UNMODIFIED LAMMPS pays on top of the kernels (north_star's boundary: PairSH::compute on host arrays): per
     call, shpair_compute() with LAMMPS-layout host arrays page-locked by shpair_pin_host (x, quat, type, shtype up;
     f, torque up, added to on the device, down) — wall time minus the kernels' time = the staging overhead; and, per
@@ -617,7 +617,7 @@ def host_path_leg(args, sb, kernel_ms_device, calls=7):
         "compute_call_ms_pinned": w_pin[i_pin], "compute_call_ms_pinned_median": float(np.median(w_pin)),
         "compute_kernel_ms": k_pin[i_pin], "compute_overhead_ms_pinned": w_pin[i_pin] - k_pin[i_pin],
         "compute_call_ms_pageable": w_page[i_page], "compute_overhead_ms_pageable": w_page[i_page] - k_page[i_page],
-        "contact_pairs_per_sec_pinned": None, "bytes_up_per_call": int(up), "bytes_down_per_call": int(down), "calls": calls,
+        "contact_pairs_per_sec_pinned": (n_contact / (w_pin[i_pin] * 1e-3) if n_contact else None), "bytes_up_per_call": int(up), "bytes_down_per_call": int(down), "calls": calls,
         "set_neighbors_ms": rows_min, "set_neighbors_ms_median": rows_med, "set_neighbors_csr_ms": csr_min,
         "set_neighbors_bytes_uploaded": int(4 * (2 * il.size + 1 + jl.size)), "half_list_pairs": int(jl.size),
         "device_resident_kernel_ms": kernel_ms_device,
