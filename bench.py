@@ -397,8 +397,7 @@ class StaticBed:
 
     def step(self, events=None):
         self.integrate(0)
-        self.f.zero_()
-        self.tq.zero_()
+        self.sp.force_clear_device(self.nlocal, self.f.data_ptr(), self.tq.data_ptr(), stream=self.stream.cuda_stream)   # Verlet::force_clear
         if events:
             events[0].record(self.stream)   # HIP events on the stream the pair kernel is launched on
         self.sp.compute_device(self.nlocal, 0, self.x.data_ptr(), self.q.data_ptr(), self.ty.data_ptr(), self.sh.data_ptr(),

@@ -50,6 +50,9 @@ int shstep_nve(shpair_ctx *ctx, int phase, int nlocal, double dt, double *x, dou
                double *angmom, const double *f, const double *torque, const int *shtype, const int *mask,
                int groupbit);
 
+/* Verlet::force_clear: zeroes f and torque of nall atoms (owned + ghost) in one launch on `stream`. */
+int shstep_force_clear_device(shpair_ctx *ctx, int nall, double *f_dev, double *torque_dev, void *stream);
+
 /* Fix::post_force of `fix gravity` + `fix viscous` in one pass: f += m g - gamma_t v,
  * torque += s x (m g - gamma_t v) - gamma_r omega  (s = R c: both act at the centre of mass). */
 int shstep_post_force_device(shpair_ctx *ctx, int nlocal, const double *gravity3, double gamma_t, double gamma_r,

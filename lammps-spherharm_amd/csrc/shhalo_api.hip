@@ -1104,12 +1104,8 @@ int shhalo_run_device(shhalo_ctx* h, shhalo_arrays* a, const shhalo_run_params* 
       break;
     }
     const size_t nall = (size_t)a->nlocal + nghost;
-    if (hipMemsetAsync(a->f, 0, 3 * nall * sizeof(double), st) != hipSuccess ||
-        hipMemsetAsync(a->torque, 0, 3 * nall * sizeof(double), st) != hipSuccess) {
-      h->err = "hipMemsetAsync failed";
-      rc = SHPAIR_EHIP;
-      break;
-    }
+    rc = shstep_force_clear_device(sp, (int)nall, a->f, a->torque, st);   // one launch (two memsets are four fill kernels)
+    if (rc) { h->err = sp->err; break; }
     const int ef = (p->eflag_last && step == nsteps - 1) ? 1 : 0;
     // "halo_overlap" 2 (atomic accumulation only): the REVERSE exchange is hidden too — the owned-only slots are cut in
     // two, [0, a) runs beside the forward exchange, the ghost slots follow it, and [a, split) runs beside the reverse

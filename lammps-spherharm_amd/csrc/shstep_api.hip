@@ -282,6 +282,21 @@ int shstep_nve(shpair_ctx* c, int phase, int nlocal, double dt, double* x, doubl
   return SHPAIR_OK;
 }
 
+int shstep_force_clear_device(shpair_ctx* c, int nall, double* f, double* torque, void* stream)
+{
+  if (!c) return SHPAIR_EINVAL;
+  if (nall < 0) CTX_FAIL(c, SHPAIR_EINVAL, "negative atom count");
+  if (nall == 0) return SHPAIR_OK;
+  if (!f || !torque) CTX_FAIL(c, SHPAIR_EINVAL, "null array pointer");
+  HIPCHK(c, hipSetDevice(c->device));
+  const long long n3 = 3LL * nall;
+  long long blocks = (n3 + kStepBlock - 1) / kStepBlock;
+  if (blocks > 4096) blocks = 4096;   // grid-stride: 16 workgroups per CU are plenty for a store-only kernel
+  hipLaunchKernelGGL(force_clear_kernel, dim3((unsigned)blocks), dim3(kStepBlock), 0, (hipStream_t)stream, n3, f, torque);
+  HIPCHK(c, hipGetLastError());
+  return SHPAIR_OK;
+}
+
 int shstep_post_force_device(shpair_ctx* c, int nlocal, const double* g, double gamma_t, double gamma_r, const double* v,
                              const double* quat, const double* angmom, const int* shtype, const int* mask, int groupbit,
                              double* f, double* torque, void* stream)
@@ -602,8 +617,7 @@ static int enqueue_b(shpair_ctx* c, shstep_state* s, const shstep_arrays* a, int
 {
   const size_t nall = (size_t)a->nlocal + nghost;
   RC(shstep_forward_device(c, a->x, a->quat, st));
-  HIPCHK(c, hipMemsetAsync(a->f, 0, 3 * nall * sizeof(double), st));
-  HIPCHK(c, hipMemsetAsync(a->torque, 0, 3 * nall * sizeof(double), st));
+  RC(shstep_force_clear_device(c, (int)nall, a->f, a->torque, st));
   RC(shpair_compute_device(c, a->nlocal, nghost, a->x, a->quat, a->type, a->shtype, 1, 0, 0, a->f, a->torque, nullptr, st));
   RC(shstep_reverse_device(c, a->f, a->torque, st));
   if (body)

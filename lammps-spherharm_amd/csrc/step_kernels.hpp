@@ -491,6 +491,18 @@ __global__ __launch_bounds__(kStepBlock) void part_scatter_kernel(int np, int nl
   out_j[dst] = j;
 }
 
+// Verlet::force_clear: f and torque of n atoms (3 n doubles each, 16-byte aligned arrays of an even number of doubles or
+// not: handled per double) in ONE launch — two hipMemsetAsync are four fill kernels of ~5 us each in front of every
+// pair compute (rocprofv3 trace of a one-rank timestep, profiles/r05_r_step_trace.txt).
+__global__ __launch_bounds__(kStepBlock) void force_clear_kernel(const long long n3, double* __restrict__ f, double* __restrict__ torque)
+{
+  const long long stride = (long long)gridDim.x * kStepBlock;
+  for (long long k = (long long)blockIdx.x * kStepBlock + threadIdx.x; k < n3; k += stride) {
+    f[k] = 0.0;
+    torque[k] = 0.0;
+  }
+}
+
 __global__ __launch_bounds__(kStepBlock) void copy_x_kernel(int n, const double* __restrict__ x, double* __restrict__ xhold)
 {
   const int k = blockIdx.x * kStepBlock + threadIdx.x;

@@ -120,6 +120,7 @@ SYMBOLS = {
     "shstep_get_body": (C.c_int, [C.c_void_p, C.c_int, _dp, _dp, _dp]),
     "shstep_nve_device": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_double] + [C.c_void_p] * 8 + [C.c_int, C.c_void_p]),
     "shstep_nve": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_double, _dp, _dp, _dp, _dp, _dp, _dp, _ip, _ip, C.c_int]),
+    "shstep_force_clear_device": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "shstep_post_force_device": (C.c_int, [C.c_void_p, C.c_int, _dp, C.c_double, C.c_double] + [C.c_void_p] * 5 +
                                  [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "shstep_energies_device": (C.c_int, [C.c_void_p, C.c_int, _dp] + [C.c_void_p] * 6 + [C.c_int, C.c_void_p, C.c_void_p]),
@@ -437,6 +438,10 @@ class ShPair:
         self._chk(self._lib.shstep_nve(self._h, int(phase), x.shape[0], float(dt), x.ctypes.data_as(_dp),
                                        v.ctypes.data_as(_dp), quat.ctypes.data_as(_dp), angmom.ctypes.data_as(_dp),
                                        pf, pt, ps, pm, int(groupbit)))
+
+    def force_clear_device(self, nall, f, torque, stream=None):
+        """Verlet::force_clear: f and torque of nall atoms zeroed in one launch (raw device addresses)."""
+        self._chk(self._lib.shstep_force_clear_device(self._h, int(nall), f, torque, stream))
 
     def post_force_device(self, nlocal, gravity, gamma_t, gamma_r, v, quat, angmom, shtype, mask, f, torque,
                           groupbit=1, stream=None):
