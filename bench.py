@@ -538,6 +538,71 @@ def configs_leg(args, warm=3, steps=5):
             del sb
         except Exception as e:  # noqa: BLE001 — an extra leg never takes the headline with it
             out[key] = {"workload": what, "error": repr(e)}
+    try:
+        out["configs[0]"] = config0_leg()
+    except Exception as e:  # noqa: BLE001
+        out["configs[0]"] = {"error": repr(e)}
+    return out
+
+
+def config0_leg(steps=200):
+    """BASELINE configs[0] itself — 1000 identical L_max = 4 ellipsoid-like particles, gravity-settled on a frozen floor
+    (tests/golden/settled_cfg1_L4.npz: positions, orientations and the oracle's forces of the settled bed, a committed data
+    file) — on the GPU: ghosts and half list built on the device, then `steps` passes of clear + pair compute + ghost
+    reverse.  A 10k-pair list is launch-bound on an MI355X (three kernels of a few microseconds): the number says what
+    a small system costs, not what the kernels can do.  The forces are held to the fixture's in the run."""
+    import torch
+    from shpair import ShPair
+    g = np.load(os.path.join(ROOT, "tests", "golden", "settled_cfg1_L4.npz"))
+    lmax, nq, n = int(g["lmax"]), int(g["nq"]), g["x"].shape[0]
+    sp = ShPair(0)
+    sp.settings(nq)
+    sp.set_ntypes(1, 1)
+    sp.set_shape(0, lmax, g["anm"][0])
+    sp.coeff(1, 1, float(g["kn"]), float(g["exponent"]))
+    sp.set_box(g["lo"], g["hi"], g["periodic"], float(g["skin"]))
+    nmax = 3 * n
+    dev = torch.device("cuda", 0)
+    x = torch.zeros(nmax, 3, dtype=torch.float64, device=dev)
+    q = torch.zeros(nmax, 4, dtype=torch.float64, device=dev)
+    x[:n] = torch.from_numpy(g["x"]).to(dev)
+    q[:n] = torch.from_numpy(g["quat"]).to(dev)
+    ty = torch.ones(nmax, dtype=torch.int32, device=dev)
+    sh = torch.zeros(nmax, dtype=torch.int32, device=dev)
+    f = torch.zeros(nmax, 3, dtype=torch.float64, device=dev)
+    tq = torch.zeros_like(f)
+    torch.cuda.synchronize()
+    ng = sp.borders_device(n, nmax, x.data_ptr(), q.data_ptr(), ty.data_ptr(), sh.data_ptr())
+    npairs = sp.neighbor_build_device(n, ng, x.data_ptr(), sh.data_ptr())
+    st = torch.cuda.current_stream()
+
+    def one():
+        sp.force_clear_device(n + ng, f.data_ptr(), tq.data_ptr(), stream=st.cuda_stream)
+        sp.compute_device(n, ng, x.data_ptr(), q.data_ptr(), ty.data_ptr(), sh.data_ptr(), f.data_ptr(), tq.data_ptr(), stream=st.cuda_stream)
+        sp.reverse_device(f.data_ptr(), tq.data_ptr(), stream=st.cuda_stream)
+    sp.set_option("count", 1)
+    one()
+    torch.cuda.synchronize()
+    c = sp.stats()
+    sp.set_option("count", 0)
+    fs = float(np.abs(g["f"]).max())
+    err = float(max(np.abs(f[:n].cpu().numpy() - g["f"]).max(), np.abs(tq[:n].cpu().numpy() - g["torque"]).max()) / fs)
+    for _ in range(20):
+        one()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        one()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    out = {"workload": "BASELINE configs[0]: 1000 identical L_max=4 ellipsoid-like particles settled under gravity on a 400-particle "
+                       "frozen floor (tests/golden/settled_cfg1_L4.npz), n_q=10, periodic in x,y: clear + pair compute + ghost reverse",
+           "particles": int(n), "ghosts": int(ng), "half_list_pairs": int(npairs), "contact_pairs": int(c["n_contact"]),
+           "touching_pairs": int(c["n_touching"]), "steps": steps, "value": c["n_contact"] * steps / el, "unit": "contact-pairs/s",
+           "us_per_step": 1e6 * el / steps, "rel_err_vs_fixture": err, "fixture_ok": bool(err < 1e-9),
+           "counts_match_fixture": bool([c["n_candidates"], c["n_contact"], c["n_touching"]] == g["counts"].tolist()),
+           "note": "launch-bound (a few microseconds of kernels per pass); the reference's own form of this config is its CPU pair style"}
+    sp.close()
     return out
 
 

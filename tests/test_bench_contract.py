@@ -63,6 +63,10 @@ def test_single_gpu_line_has_the_contract_fields():
             assert k in c, (key, k)
         assert (c["lmax"], c["nq"], c["nshapes"]) == (lmax, nq, nshapes) and c["value"] > 1e6 and 0 < c["kernel_ms"] <= c["ms_per_step"]
         assert c["stale"] in (None, True, False) and c["utilisation"]["stale"] == c["stale"] and c["contact_pairs"] > 500000
+    c0 = cf["configs[0]"]      # the settled 1000-particle bed itself, held to the committed fixture inside the run
+    assert "error" not in c0, c0
+    assert c0["fixture_ok"] is True and c0["counts_match_fixture"] is True and c0["rel_err_vs_fixture"] < 1e-9
+    assert c0["particles"] == 1400 and c0["half_list_pairs"] == 10168 and c0["value"] > 1e6 and c0["us_per_step"] > 0
     assert cf["configs[4]"]["waves_per_pair"] == 2 and cf["configs[4]"]["ms_per_step"] > 3 * cf["configs[2]"]["ms_per_step"]
     # the boundary north_star names: host arrays in, host arrays out (what an unmodified LAMMPS pays); never `value`
     hp = d["host_path"]
