@@ -90,8 +90,11 @@ def parse():
     ap.add_argument("--jpoly", type=int, default=-1, choices=[-1, 0, 1],
                     help="kernel family of the compiled orders (shpair_set_option \"jpoly\"): -1 the library's rule")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg (0 = skip)")
-    ap.add_argument("--transport", default="rccl", choices=["rccl", "local"],
-                    help="N > 1: rccl = one process per GPU, ncclSend/ncclRecv over xGMI (the product path); local = "
+    ap.add_argument("--transport", default="rccl", choices=["rccl", "local", "staged"],
+                    help="N > 1: rccl = one process per GPU, ncclSend/ncclRecv over xGMI (the product path; if ncclCommInitRank "
+                         "fails on any rank, or the forces over it are wrong, every rank falls back to `staged` and the line says "
+                         "so); staged = one process per rank, the bytes between ranks staged through host memory and "
+                         "torch.distributed's CPU backend (shhalo_create_staged: what a host without RCCL uses); local = "
                          "rehearsal: the N ranks are threads of this one process on GPU 0 (no torch.distributed.run)")
     ap.add_argument("--verify", dest="verify", action="store_true", default=None,
                     help="N > 1: compare the decomposed initial forces with a single-domain compute on rank 0 (untimed; the "
@@ -141,7 +144,7 @@ def parse():
     if a.particles <= 0:
         a.particles = 125000 if multi else 100000
     if a.verify is None:
-        a.verify = multi and a.transport == "rccl"
+        a.verify = multi and a.transport in ("rccl", "staged")
     if a.verify_overlap is None:
         a.verify_overlap = multi
     return a
@@ -855,9 +858,16 @@ def _cmp_owned(a, b, box):
     return ex, ef, float(np.abs(a[4]).max())
 
 
-def multi_rank_body(args, rank, world, device, coll, hub, uid, result, wd=None):
+def multi_rank_body(args, rank, world, device, coll, hub, uid, result, wd=None, dist=None):
+    """One rank of the N > 1 run.  Transports (include/shhalo.h): uid given -> RCCL (ncclSend / ncclRecv between the GPUs);
+    hub given -> rank threads of one process; neither, with `dist` -> host-staged through torch.distributed's CPU
+    backend (--transport staged).  An RCCL attempt that fails cleanly on any rank (ncclCommInitRank returns an error),
+    or whose decomposed forces are wrong, is replaced by the host-staged transport on EVERY rank — agreed on through the
+    control plane — and the line says so (`halo.transport`, `transport_fallback`): a slower curve with a flag instead
+    of none."""
     import torch
     from shpair import shapes, bed, mrank
+    from shpair.capi import ShPairError
     wd = wd or Watchdog(args)
     setup = {}
     t_lap = [time.perf_counter()]
@@ -884,20 +894,51 @@ def multi_rank_body(args, rank, world, device, coll, hub, uid, result, wd=None):
     xw, owner = mrank.plan_owner(geo, cfg["x"])
     mine = owner == rank
     lap("owner_plan")
-    with wd.phase("ncclCommInitRank (shhalo_create_rccl)" if uid is not None else "shhalo_create_local", args.wait_s):
-        halo = mrank.Halo(sp, rank, world, grid, cfg["lo"], cfg["hi"], cfg["periodic"], skin, hub=hub, unique_id_bytes=uid)
-    lap("comm_init")
     dt = 1.0e-3
-    with wd.phase("first migration + ghost plan + list build + forces (RankRun)", args.wait_s):
-        run = mrank.RankRun(sp, halo, xw[mine], cfg["quat"][mine], cfg["shtype"][mine], cfg["tag"][mine], v=cfg["v"][mine],
-                            mask=cfg["mask"][mine], dt=dt, gravity=(0.0, 0.0, -1.0), device=f"cuda:{device}",
-                            capacity=int(1.5 * mine.sum()) + 4096)
-    lap("first_build")
-    verify_err = None
-    if args.verify:
+    fallback = None
+    staged_keep = []
+
+    def make_halo(kind, ctx):
+        """kind: "rccl" | "local" | "staged".  Collective.  Returns (halo or None, error text or None) — agreed on by all ranks."""
+        what = {"rccl": "ncclCommInitRank (shhalo_create_rccl)", "local": "shhalo_create_local", "staged": "shhalo_create_staged"}[kind]
+        with wd.phase(what, args.wait_s):
+            h, err = None, None
+            try:
+                if kind == "rccl":
+                    if os.environ.get("SHPAIR_BENCH_FAULT") == "rccl_init":    # diagnostic hook (tests): RCCL refuses on every rank
+                        raise ShPairError(-5, "diagnostic: ncclCommInitRank refused (SHPAIR_BENCH_FAULT=rccl_init)")
+                    h = mrank.Halo(ctx, rank, world, grid, cfg["lo"], cfg["hi"], cfg["periodic"], skin, unique_id_bytes=uid)
+                elif kind == "staged":
+                    g = mrank.GlooStaged(dist)
+                    staged_keep.append(g)
+                    h = mrank.Halo(ctx, rank, world, grid, cfg["lo"], cfg["hi"], cfg["periodic"], skin, staged=g)
+                else:
+                    h = mrank.Halo(ctx, rank, world, grid, cfg["lo"], cfg["hi"], cfg["periodic"], skin, hub=hub)
+            except ShPairError as e:
+                err = f"rank {rank}: {e}"
+            if kind == "local":
+                if err:
+                    raise RuntimeError(err)
+                return h, None
+            errs = [e for e in coll.gather(rank, err) if e]
+            if errs:
+                if h is not None:
+                    h.close()
+                return None, errs[0]
+            return h, None
+
+    def make_run(h, ctx):
+        with wd.phase("first migration + ghost plan + list build + forces (RankRun)", args.wait_s):
+            return mrank.RankRun(ctx, h, xw[mine], cfg["quat"][mine], cfg["shtype"][mine], cfg["tag"][mine], v=cfg["v"][mine],
+                                 mask=cfg["mask"][mine], dt=dt, gravity=(0.0, 0.0, -1.0), device=f"cuda:{device}",
+                                 capacity=int(1.5 * mine.sum()) + 4096)
+
+    def verify_forces(r):
+        """Decomposed forces of the initial configuration against a single-domain compute on rank 0; the same number on every rank."""
         with wd.phase("gather of the initial forces (verify)", args.wait_s):
-            t, _, _, _, f0, tq0 = run.owned()
+            t, _, _, _, f0, tq0 = r.owned()
             parts = coll.gather(rank, (t, f0, tq0))
+        verr = None
         if rank == 0:
             with wd.phase("single-domain reference forces on rank 0 (verify)", args.wait_s):
                 from shpair.run import DeviceRun
@@ -913,12 +954,49 @@ def multi_rank_body(args, rank, world, device, coll, hub, uid, result, wd=None):
                 for t_, f_, q_ in parts:
                     fg[t_] = f_
                     tg[t_] = q_
-                verify_err = float(max(np.abs(fg - fr).max(), np.abs(tg - tr).max()) / np.abs(fr).max())
-                if not verify_err < 1e-9:   # reported in the line (verify_ok) and by the exit code; the run goes on so that every rank ends together
-                    print(f"bench.py: decomposed forces differ from single-domain forces: rel err {verify_err}", file=sys.stderr, flush=True)
+                verr = float(max(np.abs(fg - fr).max(), np.abs(tg - tr).max()) / np.abs(fr).max())
+                if os.environ.get("SHPAIR_BENCH_FAULT") == "rccl_forces" and r.halo.stats()["transport"] == 1:
+                    verr = 1.0    # diagnostic hook (tests): the RCCL attempt's forces are declared wrong
+                if not verr < 1e-9:   # reported in the line (verify_ok) and by the exit code; the run goes on so that every rank ends together
+                    print(f"bench.py: decomposed forces differ from single-domain forces: rel err {verr}", file=sys.stderr, flush=True)
                 ref_sp.close()
                 del ref
-        del parts
+        with wd.phase("agreement on the verification (verify)", 2 * args.wait_s):
+            verr = [v for v in coll.gather(rank, verr) if v is not None][0]
+        return verr
+
+    kind = "rccl" if uid is not None else ("local" if (hub is not None or dist is None) else "staged")
+    halo, herr = make_halo(kind, sp)
+    if halo is None and kind == "rccl" and dist is not None:
+        fallback = f"shhalo_create_rccl failed ({herr})"
+        if rank == 0:
+            print(f"bench.py: {fallback}: every rank falls back to the host-staged transport", file=sys.stderr, flush=True)
+        kind = "staged"
+        halo, herr = make_halo(kind, sp)
+    if halo is None:
+        raise RuntimeError(f"no transport: {herr}")
+    lap("comm_init")
+    run = make_run(halo, sp)
+    lap("first_build")
+    verify_err = None
+    if args.verify:
+        verify_err = verify_forces(run)
+        if not verify_err < 1e-9 and kind == "rccl" and dist is not None:
+            fallback = f"the decomposed forces over RCCL were wrong (rel err {verify_err:.3g})"
+            if rank == 0:
+                print(f"bench.py: {fallback}: every rank falls back to the host-staged transport", file=sys.stderr, flush=True)
+            del run
+            halo.close()
+            sp.close()
+            sp = make_ctx(args, shp, device)
+            sp.set_option("halo_overlap", 0 if check_overlap else candidate)
+            sp.set_option("halo_stream_priority", max(0, args.halo_stream_priority))
+            kind = "staged"
+            halo, herr = make_halo(kind, sp)
+            if halo is None:
+                raise RuntimeError(f"no transport: {herr}")
+            run = make_run(halo, sp)
+            verify_err = verify_forces(run)
         lap("verify")
 
     def count_contacts():
@@ -1042,13 +1120,14 @@ def multi_rank_body(args, rank, world, device, coll, hub, uid, result, wd=None):
                             "migration, ghost exchange (shhalo_run_device); arrays resident in HBM",
                 "particles_per_gpu": args.particles, "particles_all_ranks": int(cfg["n"]), "lmax": args.lmax, "nq": args.nq,
                 "nshapes": args.nshapes, "exponent": args.exponent, "rule": args.rule, "proc_grid": list(grid),
-                "backend": "rccl" if args.transport == "rccl" else "local-hub-rehearsal (rank threads on one GPU)",
+                "backend": {1: "rccl", 2: "host-staged (torch.distributed gloo) — " + ("FALLBACK: " + fallback if fallback else "asked for"),
+                            0: "local-hub-rehearsal (rank threads on one GPU)"}[st["transport"]],
                 "contact_pairs_rank0": int(allr[0]["contact"]), "contact_pairs_all_ranks": int(contact_all),
                 "ghost_atoms_rank0": int(allr[0]["nghost"]), "half_list_pairs_rank0": int(allr[0]["npairs"]),
             },
             "timesteps_per_sec": args.steps / el,
             "halo": {
-                "transport": "rccl" if st["transport"] == 1 else "local",
+                "transport": {0: "local", 1: "rccl", 2: "staged"}.get(st["transport"], str(st["transport"])),
                 "ranks_reported_by_transport": st["nranks_transport"], "rccl_version": st["rccl_version"],
                 "overlap_option": ov["used"], "peers_rank0": st["npeers"], "send_rows_rank0": st["nsend_rows"], "ghost_rows_rank0": st["nghost_rows"],
                 "forward_bytes_per_step_rank0": st["forward_bytes_per_step"], "reverse_bytes_per_step_rank0": st["reverse_bytes_per_step"],
@@ -1059,6 +1138,7 @@ def multi_rank_body(args, rank, world, device, coll, hub, uid, result, wd=None):
                         "the compute stream; 1 / 2: the forward (and the reverse) exchange on a second stream beside the pair "
                         "kernels of the owned-only slots",
             },
+            "transport_fallback": fallback,
             "overlap_requested": ov["requested"], "overlap_candidate": ov["candidate"], "overlap_used": ov["used"],
             "overlap_stream_priority_used": ov["prio_used"],
             "verify_overlap_rel_err": ov.get("rel_err"), "verify_overlap_ok": ov.get("ok"), "verify_overlap_rel_err_by_mode": ov.get("rel_err_by_mode"),
@@ -1159,12 +1239,12 @@ def main_multi(args):
     with wd.phase("gloo rendezvous (torch.distributed.init_process_group) + ncclGetUniqueId broadcast", args.wait_s):
         # control plane only: id broadcast, barriers, timings
         dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=args.wait_s))
-        box = [mrank.unique_id() if rank == 0 else None]
+        box = [mrank.unique_id() if (rank == 0 and args.transport == "rccl") else None]
         dist.broadcast_object_list(box, src=0)
     coll = _Collective(world, dist)
     rc = 0
     try:
-        multi_rank_body(args, rank, world, local_rank, coll, None, box[0], result, wd)
+        multi_rank_body(args, rank, world, local_rank, coll, None, box[0], result, wd, dist=dist)
     except BaseException:  # noqa: BLE001 — a rank that failed must not leave the others in a collective for ever: say why, then end
         import traceback
         tb = traceback.format_exc()
@@ -1390,7 +1470,7 @@ if __name__ == "__main__":
     _args = parse()
     if _args.gpus == 1 and not _args.multi:
         main_single(_args)
-    elif _args.transport == "rccl" and "WORLD_SIZE" not in os.environ and (_args.gpus > 1 or _args.launch):
+    elif _args.transport in ("rccl", "staged") and "WORLD_SIZE" not in os.environ and (_args.gpus > 1 or _args.launch):
         self_launch(_args)
     else:
         main_multi(_args)

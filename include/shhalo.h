@@ -39,6 +39,7 @@
 #ifndef SHHALO_H
 #define SHHALO_H
 
+#include <stddef.h>
 #include "shpair.h"
 #include "shstep.h"
 
@@ -117,6 +118,21 @@ int shhalo_hub_create(shhalo_hub **out, int nranks);
 void shhalo_hub_destroy(shhalo_hub *hub);
 int shhalo_create_local(shhalo_ctx **out, shpair_ctx *sp, shhalo_hub *hub, int rank, int nranks, const int grid[3],
                         const double lo[3], const double hi[3], const int periodic[3], double skin);
+/* Host-staged form: the bytes between ranks travel through functions of the CALLER — MPI_Isend / MPI_Irecv /
+ * MPI_Allreduce in a LAMMPS host without GPU-aware MPI or RCCL, torch.distributed (gloo) in bench.py --transport
+ * staged.  Per exchange the library copies its packed send buffers to page-locked host memory, waits for the stream,
+ * calls `exchange` once with every message of the exchange (at most one send and one receive per peer; it returns when
+ * all of them are complete; 0 = success), and copies the received bytes up.  `allreduce` combines n host values over
+ * all ranks in place: kind 0 = max of int32, 1 = sum of double.  Same plan, same kernels, same loop as the other
+ * transports; a host wait per exchange instead of none — the way to run N ranks where RCCL cannot (and the fallback
+ * bench.py takes, and says it took, when ncclCommInitRank fails on any rank).  Collective only through the callbacks. */
+typedef int (*shhalo_exchange_fn)(void *user, int nsend, const int *send_peer, void *const *send_ptr,
+                                  const size_t *send_bytes, int nrecv, const int *recv_peer, void *const *recv_ptr,
+                                  const size_t *recv_bytes);
+typedef int (*shhalo_allreduce_fn)(void *user, void *data, int n, int kind);
+int shhalo_create_staged(shhalo_ctx **out, shpair_ctx *sp, shhalo_exchange_fn exchange, shhalo_allreduce_fn allreduce,
+                         void *user, int rank, int nranks, const int grid[3], const double lo[3], const double hi[3],
+                         const int periodic[3], double skin);
 void shhalo_destroy(shhalo_ctx *h);
 const char *shhalo_last_error(const shhalo_ctx *h);
 int shhalo_get_geometry(const shhalo_ctx *h, shhalo_geometry *out);
@@ -165,7 +181,7 @@ typedef struct shhalo_stats {
   int nsend_rows, nghost_rows; /* current plan */
   long long rebuilds, migrated_out, migrated_in;
   long long forward_bytes_per_step, reverse_bytes_per_step; /* bytes this rank sends to remote peers */
-  int transport;               /* 0 local, 1 RCCL */
+  int transport;               /* 0 local, 1 RCCL, 2 host-staged */
   int rccl_version;            /* ncclGetVersion, 0 for the local transport */
 } shhalo_stats;
 int shhalo_get_stats(const shhalo_ctx *h, shhalo_stats *out);

@@ -313,6 +313,105 @@ struct LocalTransport : Transport {
   int kind() const override { return 0; }
 };
 
+// Host-staged transport: the caller's functions move the bytes (MPI in a LAMMPS host, gloo in bench.py); the library
+// stages through page-locked host memory around them.  Every call blocks the host until its messages are complete.
+struct StagedTransport : Transport {
+  shhalo_exchange_fn xfn = nullptr;
+  shhalo_allreduce_fn rfn = nullptr;
+  void* user = nullptr;
+  int rank = 0, nranks = 1;
+  unsigned char* hbuf = nullptr;   // pinned: [send bytes | recv bytes]
+  size_t hcap = 0;
+  ~StagedTransport() override
+  {
+    if (hbuf) (void)hipHostFree(hbuf);
+  }
+  int ensure(size_t bytes)
+  {
+    if (bytes <= hcap) return SHPAIR_OK;
+    if (hbuf) (void)hipHostFree(hbuf);
+    hbuf = nullptr;
+    hcap = 0;
+    const size_t want = bytes + bytes / 2 + 4096;
+    if (hipHostMalloc((void**)&hbuf, want) != hipSuccess) {
+      (void)hipGetLastError();
+      err = "staged transport: hipHostMalloc of " + std::to_string(want) + " bytes failed";
+      return SHPAIR_ENOMEM;
+    }
+    hcap = want;
+    return SHPAIR_OK;
+  }
+  int exchange(const std::vector<Msg>& sends, const std::vector<Msg>& recvs, hipStream_t st) override
+  {
+    if (sends.empty() && recvs.empty()) return SHPAIR_OK;
+    size_t sb = 0, rb = 0;
+    for (const Msg& m : sends) sb += (m.bytes + 15) & ~(size_t)15;
+    for (const Msg& m : recvs) rb += (m.bytes + 15) & ~(size_t)15;
+    // the previous exchange's upward copies read this buffer: they are complete (this call ended with a stream wait)
+    if (const int rc = ensure(sb + rb)) return rc;
+    std::vector<int> sp_, rp_;
+    std::vector<void*> sptr, rptr;
+    std::vector<size_t> sby, rby;
+    size_t off = 0;
+    for (const Msg& m : sends) {
+      if (hipMemcpyAsync(hbuf + off, m.ptr, m.bytes, hipMemcpyDeviceToHost, st) != hipSuccess) {
+        err = "staged transport: copy of a send buffer to the host failed";
+        return SHPAIR_EHIP;
+      }
+      sp_.push_back(m.peer); sptr.push_back(hbuf + off); sby.push_back(m.bytes);
+      off += (m.bytes + 15) & ~(size_t)15;
+    }
+    for (const Msg& m : recvs) {
+      rp_.push_back(m.peer); rptr.push_back(hbuf + off); rby.push_back(m.bytes);
+      off += (m.bytes + 15) & ~(size_t)15;
+    }
+    if (hipStreamSynchronize(st) != hipSuccess) {
+      err = "staged transport: hipStreamSynchronize failed";
+      return SHPAIR_EHIP;
+    }
+    const int xrc = xfn(user, (int)sends.size(), sp_.data(), sptr.data(), sby.data(), (int)recvs.size(), rp_.data(), rptr.data(),
+                        rby.data());
+    if (xrc != 0) {
+      err = "staged transport: the caller's exchange function returned " + std::to_string(xrc) + " on rank " + std::to_string(rank);
+      return SHPAIR_ESTATE;
+    }
+    for (size_t k = 0; k < recvs.size(); ++k)
+      if (hipMemcpyAsync(recvs[k].ptr, rptr[k], recvs[k].bytes, hipMemcpyHostToDevice, st) != hipSuccess) {
+        err = "staged transport: copy of a received buffer to the device failed";
+        return SHPAIR_EHIP;
+      }
+    if (hipStreamSynchronize(st) != hipSuccess) {   // the host buffer is free again, and the caller's next call may be another exchange
+      err = "staged transport: hipStreamSynchronize failed";
+      return SHPAIR_EHIP;
+    }
+    return SHPAIR_OK;
+  }
+  template <typename T>
+  int allreduce(T* dev, int n, int kind, hipStream_t st)
+  {
+    if (nranks == 1) return SHPAIR_OK;
+    if (const int rc = ensure((size_t)n * sizeof(T))) return rc;
+    if (hipMemcpyAsync(hbuf, dev, (size_t)n * sizeof(T), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
+      err = "staged transport: all-reduce read-back failed";
+      return SHPAIR_EHIP;
+    }
+    const int rrc = rfn(user, hbuf, n, kind);
+    if (rrc != 0) {
+      err = "staged transport: the caller's all-reduce function returned " + std::to_string(rrc) + " on rank " + std::to_string(rank);
+      return SHPAIR_ESTATE;
+    }
+    if (hipMemcpyAsync(dev, hbuf, (size_t)n * sizeof(T), hipMemcpyHostToDevice, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
+      err = "staged transport: all-reduce write-back failed";
+      return SHPAIR_EHIP;
+    }
+    return SHPAIR_OK;
+  }
+  int allreduce_max_i32(int* dev, int n, hipStream_t st) override { return allreduce(dev, n, 0, st); }
+  int allreduce_sum_f64(double* dev, int n, hipStream_t st) override { return allreduce(dev, n, 1, st); }
+  int size() const override { return nranks; }
+  int kind() const override { return 2; }
+};
+
 inline unsigned nblk(long long n, int b) { return (unsigned)((n + b - 1) / b > 0 ? (n + b - 1) / b : 1); }
 
 }  // namespace
@@ -624,6 +723,38 @@ int shhalo_hub_create(shhalo_hub** out, int nranks)
 }
 
 void shhalo_hub_destroy(shhalo_hub* hub) { delete hub; }
+
+int shhalo_create_staged(shhalo_ctx** out, shpair_ctx* sp, shhalo_exchange_fn exchange, shhalo_allreduce_fn allreduce, void* user,
+                         int rank, int nranks, const int grid[3], const double lo[3], const double hi[3], const int periodic[3],
+                         double skin)
+{
+  if (!out) return SHPAIR_EINVAL;
+  *out = nullptr;
+  if (!sp || !grid || !lo || !hi || !periodic || rank < 0 || rank >= nranks) return SHPAIR_EINVAL;
+  if (nranks > 1 && (!exchange || !allreduce)) CTX_FAIL(sp, SHPAIR_EINVAL, "the staged transport needs an exchange and an all-reduce function");
+  if (hipSetDevice(sp->device) != hipSuccess) CTX_FAIL(sp, SHPAIR_EHIP, "hipSetDevice(%d) failed", sp->device);
+  shhalo_ctx* h = new (std::nothrow) shhalo_ctx();
+  StagedTransport* t = new (std::nothrow) StagedTransport();
+  if (!h || !t) {
+    delete h;
+    delete t;
+    return SHPAIR_ENOMEM;
+  }
+  t->xfn = exchange;
+  t->rfn = allreduce;
+  t->user = user;
+  t->rank = rank;
+  t->nranks = nranks;
+  h->tr = t;
+  const int rc = finish_create(h, sp, rank, grid, lo, hi, periodic, skin);
+  if (rc) {
+    sp->err = h->err;
+    shhalo_destroy(h);
+    return rc;
+  }
+  *out = h;
+  return SHPAIR_OK;
+}
 
 int shhalo_create_local(shhalo_ctx** out, shpair_ctx* sp, shhalo_hub* hub, int rank, int nranks, const int grid[3],
                         const double lo[3], const double hi[3], const int periodic[3], double skin)

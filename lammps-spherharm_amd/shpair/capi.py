@@ -144,6 +144,8 @@ SYMBOLS = {
                                      C.c_double]),
     "shhalo_hub_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int]),
     "shhalo_hub_destroy": (None, [C.c_void_p]),
+    "shhalo_create_staged": (C.c_int, [C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, _ip, _dp,
+                                       _dp, _ip, C.c_double]),
     "shhalo_create_local": (C.c_int, [C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p, C.c_int, C.c_int, _ip, _dp, _dp, _ip,
                                       C.c_double]),
     "shhalo_destroy": (None, [C.c_void_p]),

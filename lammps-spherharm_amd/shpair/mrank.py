@@ -75,6 +75,56 @@ def unique_id():
     return buf.raw
 
 
+_szp = C.POINTER(C.c_size_t)
+_vpp = C.POINTER(C.c_void_p)
+EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, _ip, _vpp, _szp, C.c_int, _ip, _vpp, _szp)
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int)
+
+
+class GlooStaged:
+    """The caller's side of the host-staged transport (shhalo_create_staged) on torch.distributed's CPU backend: the
+    library hands over page-locked host buffers, this class moves them with isend / irecv and combines the all-reduce
+    values — what MPI_Isend / MPI_Irecv / MPI_Allreduce would do in a LAMMPS host without GPU-aware MPI.  One instance
+    per rank; keep it alive as long as the halo context."""
+
+    def __init__(self, dist, group=None):
+        import torch
+        self.dist, self.group, self.torch = dist, group, torch
+        self.calls = 0
+        self.last_error = ""
+
+        def _view(ptr, nbytes, dtype):
+            buf = (C.c_char * int(nbytes)).from_address(int(ptr))
+            return torch.frombuffer(buf, dtype=dtype)
+
+        def _exchange(user, ns, speer, sptr, sbytes, nr, rpeer, rptr, rbytes):
+            try:
+                reqs = [dist.irecv(_view(rptr[k], rbytes[k], torch.uint8), src=int(rpeer[k]), group=group) for k in range(nr)]
+                reqs += [dist.isend(_view(sptr[k], sbytes[k], torch.uint8), dst=int(speer[k]), group=group) for k in range(ns)]
+                for r in reqs:
+                    r.wait()
+                self.calls += 1
+                return 0
+            except BaseException as e:  # noqa: BLE001 — never let an exception cross the C frame
+                self.last_error = repr(e)
+                return 1
+
+        def _allreduce(user, data, n, kind):
+            try:
+                if kind == 0:
+                    t = _view(data, 4 * n, torch.int32)
+                    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+                else:
+                    t = _view(data, 8 * n, torch.float64)
+                    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+                return 0
+            except BaseException as e:  # noqa: BLE001
+                self.last_error = repr(e)
+                return 1
+        self.exchange_fn = EXCHANGE_FN(_exchange)
+        self.allreduce_fn = ALLREDUCE_FN(_allreduce)
+
+
 class Hub:
     """In-process transport between the rank THREADS of one process (rehearsal of N ranks on one GPU)."""
 
@@ -93,11 +143,15 @@ class Hub:
 class Halo:
     """One rank's shhalo context."""
 
-    def __init__(self, sp, rank, nranks, grid, lo, hi, periodic, skin, hub=None, unique_id_bytes=None):
+    def __init__(self, sp, rank, nranks, grid, lo, hi, periodic, skin, hub=None, unique_id_bytes=None, staged=None):
         self._lib = capi.load_library()
         self.sp = sp
         h = C.c_void_p()
-        if unique_id_bytes is not None:
+        self._staged = staged    # keeps the callbacks alive
+        if staged is not None:
+            rc = self._lib.shhalo_create_staged(C.byref(h), sp._h, C.cast(staged.exchange_fn, C.c_void_p), C.cast(staged.allreduce_fn, C.c_void_p),
+                                                None, int(rank), int(nranks), _i3(grid), _d3(lo), _d3(hi), _i3(periodic), float(skin))
+        elif unique_id_bytes is not None:
             idb = C.create_string_buffer(bytes(unique_id_bytes), 128)
             rc = self._lib.shhalo_create_rccl(C.byref(h), sp._h, idb, int(rank), int(nranks), _i3(grid), _d3(lo), _d3(hi),
                                               _i3(periodic), float(skin))

@@ -211,3 +211,49 @@ def test_a_wrong_overlap_result_is_not_used_and_fails_the_run():
     d = _last_json(r.stdout)
     assert d["verify_overlap_ok"] is True and d["overlap_used"] == 2 and d["halo"]["overlap_option"] == 2
     assert set(d["verify_overlap_rel_err_by_mode"]) == {"2", "2p"}
+
+
+def test_real_rank_processes_on_one_gpu_through_the_host_staged_transport():
+    """The N > 1 door with N REAL processes — everything the driver's 8-GPU run goes through except the RCCL wire: the
+    self-launcher (2 ranks) and torch.distributed.run (4 ranks), gloo rendezvous, one context per process, the plan and the
+    pack / unpack kernels per process, the bytes between ranks staged through host memory and torch.distributed's CPU
+    backend (shhalo_create_staged), the in-run force verification and the halo_overlap check, the gathered line.  All
+    ranks share the box's one GPU (--one-device; rank threads in one process would share an address space, and bugs that
+    only separate processes show stay hidden)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    common = ["--transport", "staged", "--one-device", "--particles", "6000", "--steps", "10", "--warmup", "1", "--ramp", "3", "--peak-ms", "0",
+              "--ab-steps", "6"]
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"] + common, capture_output=True, text=True, timeout=900,
+                       cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = _last_json(r.stdout)
+    assert d["n_gpus"] == 2 and d["halo"]["transport"] == "staged" and d["halo"]["ranks_reported_by_transport"] == 2
+    assert d["transport_fallback"] is None and "host-staged" in d["config"]["backend"] and "self-launch" in d["launcher"]
+    assert d["verify_ok"] is True and d["verify_rel_err"] < 1e-12 and d["verify_overlap_ok"] is True
+    assert sum(d["halo"]["owned_atoms"]) == d["config"]["particles_all_ranks"] and min(d["halo"]["ghost_atoms"]) > 0
+    assert d["halo"]["forward_bytes_per_step_rank0"] > 0 and d["value"] > 1e6
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "4"] + common
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=dict(env, MASTER_ADDR="127.0.0.1"))
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = _last_json(r.stdout)     # ONE line on the launcher's stdout: RCCL's and gloo's banners went to stderr
+    assert d["n_gpus"] == 4 and d["config"]["proc_grid"] == [2, 2, 1] and d["halo"]["transport"] == "staged" and d["halo"]["peers_rank0"] == 3
+    assert d["verify_ok"] is True and d["verify_overlap_ok"] is True and len(d["halo"]["owned_atoms"]) == 4
+    assert max(d["halo"]["rebuilds_in_timed_steps"]) >= 1 and len(set(d["halo"]["rebuilds_in_timed_steps"])) == 1
+    assert d["halo"]["atoms_migrated_in_timed_steps"] >= 0 and sum(d["halo"]["owned_atoms"]) == d["config"]["particles_all_ranks"]
+
+
+@pytest.mark.parametrize("fault", ["rccl_init", "rccl_forces"])
+def test_an_rccl_attempt_that_fails_falls_back_to_the_staged_transport_on_every_rank(fault):
+    """ncclCommInitRank returning an error on any rank, or decomposed forces over RCCL that are wrong, must not cost the run:
+    every rank — agreed on through the control plane — takes the host-staged transport instead and the line says so
+    (diagnostic hooks stand in for the failures: SHPAIR_BENCH_FAULT=rccl_init / rccl_forces)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--multi", "--particles", "8000", "--steps", "6", "--warmup", "1",
+                        "--ramp", "2", "--peak-ms", "0", "--ab-steps", "4"], capture_output=True, text=True, timeout=900, cwd=ROOT,
+                       env=dict(env, SHPAIR_BENCH_FAULT=fault))
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = _last_json(r.stdout)
+    assert d["halo"]["transport"] == "staged" and d["transport_fallback"] and "FALLBACK" in d["config"]["backend"]
+    assert ("shhalo_create_rccl failed" in d["transport_fallback"]) == (fault == "rccl_init")
+    assert d["verify_ok"] is True and d["value"] > 1e6 and "falls back to the host-staged transport" in r.stderr

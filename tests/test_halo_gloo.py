@@ -153,6 +153,53 @@ def test_decomposed_forces_equal_single_domain_gloo(oracle, tmp_path, grid, peri
     _check(c, oracle, parts)
 
 
+def _staged_worker(rank, world, port, out_dir):
+    for p in (os.path.join(ROOT, "lammps-spherharm_amd"), ROOT):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import ctypes as C
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        g = mrank.GlooStaged(dist)
+        peers = [q for q in range(world) if q != rank]
+        send = [np.full(1000 + 16 * q, 10 * rank + q, dtype=np.uint8) for q in peers]       # to q: the byte 10 rank + q
+        recv = [np.zeros(1000 + 16 * rank, dtype=np.uint8) for q in peers]
+        n = len(peers)
+        pr = (C.c_int * n)(*peers)
+        sp_ = (C.c_void_p * n)(*[a.ctypes.data for a in send])
+        rp_ = (C.c_void_p * n)(*[a.ctypes.data for a in recv])
+        sb = (C.c_size_t * n)(*[a.size for a in send])
+        rb = (C.c_size_t * n)(*[a.size for a in recv])
+        for _ in range(3):      # consecutive exchanges stay matched (forward, reverse, forward ...)
+            rc = g.exchange_fn(None, n, pr, sp_, sb, n, pr, rp_, rb)
+            assert rc == 0, g.last_error
+            for q, a in zip(peers, recv):
+                assert np.all(a == 10 * q + rank), (rank, q, a[:4])
+                a[:] = 0
+        v = np.array([rank + 1, 100 - rank], dtype=np.int32)
+        assert g.allreduce_fn(None, v.ctypes.data, 2, 0) == 0 and list(v) == [world, 100]
+        d = np.array([0.5 * (rank + 1)], dtype=np.float64)
+        assert g.allreduce_fn(None, d.ctypes.data, 1, 1) == 0 and d[0] == 0.25 * world * (world + 1)
+        open(os.path.join(out_dir, f"ok{rank}"), "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_staged_transport_callbacks_over_gloo(tmp_path):
+    """The caller's half of the host-staged transport (shhalo_create_staged: the library stages its packed buffers through
+    page-locked host memory and hands them to two functions of the caller) as bench.py --transport staged provides it:
+    mrank.GlooStaged's exchange and all-reduce functions, called through their C function pointers as the library calls
+    them, between four real gloo processes.  (The library's half needs a GPU: tests/test_bench_contract.py.)"""
+    import torch.multiprocessing as mp
+    mp.spawn(_staged_worker, args=(4, _free_port(), str(tmp_path)), nprocs=4, join=True)
+    assert all((tmp_path / f"ok{r}").exists() for r in range(4))
+
+
 def test_proc_grid_and_geometry():
     assert mrank.proc_grid(1) == (1, 1, 1) and mrank.proc_grid(2) == (2, 1, 1) and mrank.proc_grid(4) == (2, 2, 1)
     assert mrank.proc_grid(8) == (2, 2, 2) and mrank.proc_grid(6) == (3, 2, 1)
