@@ -978,6 +978,9 @@ def multi_rank_body(args, rank, world, device, coll, hub, uid, result, wd=None, 
     lap("comm_init")
     run = make_run(halo, sp)
     lap("first_build")
+    if os.environ.get("SHPAIR_BENCH_FAULT") == "die_rank1" and rank == 1:    # diagnostic hook (tests): a rank is lost in mid-run
+        print("bench.py: rank 1: diagnostic exit (SHPAIR_BENCH_FAULT=die_rank1)", file=sys.stderr, flush=True)
+        os._exit(9)
     verify_err = None
     if args.verify:
         verify_err = verify_forces(run)

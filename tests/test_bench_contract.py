@@ -257,3 +257,32 @@ def test_an_rccl_attempt_that_fails_falls_back_to_the_staged_transport_on_every_
     assert d["halo"]["transport"] == "staged" and d["transport_fallback"] and "FALLBACK" in d["config"]["backend"]
     assert ("shhalo_create_rccl failed" in d["transport_fallback"]) == (fault == "rccl_init")
     assert d["verify_ok"] is True and d["value"] > 1e6 and "falls back to the host-staged transport" in r.stderr
+
+
+@pytest.mark.parametrize("launcher", ["self", "torchrun"])
+def test_a_rank_lost_in_mid_run_leaves_one_line_that_says_so(launcher):
+    """Three real rank processes (host-staged transport, one GPU); rank 1 dies after the first build (diagnostic hook).  No
+    hang: the survivors sit in a gloo collective until their launcher ends them — torch.distributed.run and the
+    self-launcher both send SIGTERM — and rank 0, the owner of stdout's line, still prints ONE line with `value` null and
+    the phase it was in (a thread on the signal wake-up pipe answers while the main thread is inside the C call)."""
+    import time
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env["SHPAIR_BENCH_FAULT"] = "die_rank1"
+    common = ["--gpus", "3", "--transport", "staged", "--one-device", "--particles", "4000", "--steps", "4", "--warmup", "1", "--ramp", "1",
+              "--peak-ms", "0", "--wait-s", "60"]
+    if launcher == "self":
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py")] + common
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "3", "--master-addr", "127.0.0.1",
+               "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py")] + common
+        env["MASTER_ADDR"] = "127.0.0.1"
+    t0 = time.monotonic()
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert r.returncode != 0 and time.monotonic() - t0 < 150, (r.returncode, r.stderr[-2000:])
+    assert "diagnostic exit" in r.stderr
+    d = _last_json(r.stdout)
+    assert d["value"] is None and d["n_gpus"] == 3 and d["error"]
+    # what rank 0 saw first: its launcher's SIGTERM, or the dead peer's closed connection inside a gloo collective
+    assert any(k in d["error"] for k in ("SIGTERM", "rank(s) [1]", "did not finish", "rank 0 failed")), d["error"]
+    if launcher == "self":
+        assert any("[1] ended with exit code(s) [9]" in n for n in d.get("error_notes", [])), d
