@@ -286,3 +286,17 @@ def test_a_rank_lost_in_mid_run_leaves_one_line_that_says_so(launcher):
     assert any(k in d["error"] for k in ("SIGTERM", "rank(s) [1]", "did not finish", "rank 0 failed")), d["error"]
     if launcher == "self":
         assert any("[1] ended with exit code(s) [9]" in n for n in d.get("error_notes", [])), d
+
+
+def test_a_real_rccl_refusal_takes_the_fallback():
+    """No hook: two rank processes on ONE device is something RCCL itself refuses (ncclCommInitRank: invalid usage — two ranks
+    of a communicator on one GPU).  Every rank gets the error, the ranks agree on it, close what they have and run the
+    host-staged transport; the line carries the reason."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--transport", "rccl", "--one-device", "--particles", "6000",
+                        "--steps", "6", "--warmup", "1", "--ramp", "2", "--peak-ms", "0", "--ab-steps", "4", "--wait-s", "60"],
+                       capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = _last_json(r.stdout)
+    assert d["halo"]["transport"] == "staged" and "ncclCommInitRank failed" in d["transport_fallback"]
+    assert d["verify_ok"] is True and d["verify_overlap_ok"] is True and d["n_gpus"] == 2 and d["value"] > 1e6
