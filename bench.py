@@ -1086,7 +1086,7 @@ def multi_rank_body(args, rank, world, device, coll, hub, uid, result, wd=None, 
     lap("warm_up")
     b0, k0 = run.builds, run.kernel_ms
     s0 = halo.stats()
-    with wd.phase("timed timesteps", 2 * args.wait_s):
+    with wd.phase("timed timesteps", 2 * args.wait_s + 0.1 * args.steps):   # (a long run asked for by hand gets a bound that grows with it; --total-s still applies)
         run.sync()
         coll.barrier()
         torch.cuda.synchronize()
