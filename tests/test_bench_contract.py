@@ -221,7 +221,7 @@ def test_real_rank_processes_on_one_gpu_through_the_host_staged_transport():
     ranks share the box's one GPU (--one-device; rank threads in one process would share an address space, and bugs that
     only separate processes show stay hidden)."""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
-    common = ["--transport", "staged", "--one-device", "--particles", "6000", "--steps", "10", "--warmup", "1", "--ramp", "3", "--peak-ms", "0",
+    common = ["--transport", "staged", "--one-device", "--particles", "6000", "--steps", "24", "--warmup", "1", "--ramp", "3", "--peak-ms", "0",
               "--ab-steps", "6"]
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"] + common, capture_output=True, text=True, timeout=900,
                        cwd=ROOT, env=env)
@@ -300,3 +300,19 @@ def test_a_real_rccl_refusal_takes_the_fallback():
     d = _last_json(r.stdout)
     assert d["halo"]["transport"] == "staged" and "ncclCommInitRank failed" in d["transport_fallback"]
     assert d["verify_ok"] is True and d["verify_overlap_ok"] is True and d["n_gpus"] == 2 and d["value"] > 1e6
+
+
+def test_an_optional_leg_that_hangs_does_not_cost_the_run_its_number():
+    """The K timed steps come FIRST, in the plain mode, and their line is secured; the halo_overlap check and A/B are optional
+    legs after it.  Here the last rank never comes back from the check (diagnostic hook): every rank's watchdog gives up
+    after the phase bound, rank 0 leaves with the secured line plus `experiment_error`, and the exit code is 0."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--transport", "staged", "--one-device", "--particles", "5000",
+                        "--steps", "8", "--warmup", "1", "--ramp", "3", "--peak-ms", "0", "--wait-s", "8"], capture_output=True, text=True,
+                       timeout=600, cwd=ROOT, env=dict(env, SHPAIR_BENCH_FAULT="overlap_stall"))
+    assert r.returncode == 0, (r.returncode, r.stderr[-3000:])
+    d = _last_json(r.stdout)
+    assert d["value"] > 1e6 and d["steps"] == 8 and d["verify_ok"] is True and d["overlap_used"] == 0
+    # (which rank speaks first: the stalled rank's peer gives up inside the gloo exchange, or a watchdog at the phase bound)
+    assert "halo_overlap check" in d["experiment_error"] and d["verify_overlap_ok"] is None and set(d["timed_by_mode"]) == {"0"}
+    assert "the measurement taken before it stands" in r.stderr
