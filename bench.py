@@ -915,6 +915,7 @@ def multi_rank_body(args, rank, world, device, coll, hub, uid, result, wd=None, 
     dt = 1.0e-3
     fallback = None
     staged_keep = []
+    selftest = {}
 
     def make_halo(kind, ctx):
         """kind: "rccl" | "local" | "staged".  Collective.  Returns (halo or None, error text or None) — agreed on by all ranks."""
@@ -926,6 +927,10 @@ def multi_rank_body(args, rank, world, device, coll, hub, uid, result, wd=None, 
                     if os.environ.get("SHPAIR_BENCH_FAULT") == "rccl_init":    # diagnostic hook (tests): RCCL refuses on every rank
                         raise ShPairError(-5, "diagnostic: ncclCommInitRank refused (SHPAIR_BENCH_FAULT=rccl_init)")
                     h = mrank.Halo(ctx, rank, world, grid, cfg["lo"], cfg["hi"], cfg["periodic"], skin, unique_id_bytes=uid)
+                    # a megabyte to itself through ncclSend / ncclRecv, and an all-reduce over all ranks, checked byte by byte,
+                    # before anything depends on the wire (shhalo_transport_selftest)
+                    h.transport_selftest(1 << 20, ctx.own_stream())
+                    selftest["rccl"] = "ok: 1 MiB sent to self through ncclSend / ncclRecv and all-reduces over all ranks, checked"
                 elif kind == "staged":
                     g = mrank.GlooStaged(dist)
                     staged_keep.append(g)
@@ -1103,7 +1108,7 @@ def multi_rank_body(args, rank, world, device, coll, hub, uid, result, wd=None, 
                         "the compute stream; 1 / 2: the forward (and the reverse) exchange on a second stream beside the pair "
                         "kernels of the owned-only slots",
             },
-            "transport_fallback": fallback, "timed_by_mode": timed_by_mode,
+            "transport_fallback": fallback, "transport_selftest": selftest.get("rccl"), "timed_by_mode": timed_by_mode,
             "overlap_requested": ov["requested"], "overlap_candidate": ov["candidate"], "overlap_used": ov["used"],
             "overlap_stream_priority_used": ov["prio_used"],
             "verify_overlap_rel_err": ov.get("rel_err"), "verify_overlap_ok": ov.get("ok"), "verify_overlap_rel_err_by_mode": ov.get("rel_err_by_mode"),

@@ -174,6 +174,14 @@ int shhalo_check_rebuild_device(shhalo_ctx *h, int nlocal, const double *x_dev, 
 /* Thermo sums: in-place sum over all ranks of n doubles on the device.  Enqueue only. */
 int shhalo_allreduce_sum_device(shhalo_ctx *h, double *data_dev, int n, void *stream);
 
+/* Transport self-test: one exchange() of the context's transport in which this rank sends `nbytes` bytes to ITSELF and
+ * receives them (RCCL: ncclGroupStart, ncclRecv from self, ncclSend to self, ncclGroupEnd — point-to-point calls whose
+ * peer is the caller are legal inside one group), plus an in-place max / sum all-reduce, all checked against what was
+ * sent.  The halo loop never sends to self (periodic self-images are local copies), so on a one-GPU box this is the only
+ * way the ncclSend / ncclRecv binding executes at all.  Not collective beyond the all-reduce (every rank calls it or none).
+ * Returns 0, or SHPAIR_ESTATE with the mismatch in shhalo_last_error. */
+int shhalo_transport_selftest(shhalo_ctx *h, int nbytes, void *stream);
+
 /* Counters since creation (host values, no synchronisation). */
 typedef struct shhalo_stats {
   int nranks_transport;        /* what the transport reports (ncclCommCount for RCCL) */

@@ -158,6 +158,7 @@ SYMBOLS = {
     "shhalo_reverse_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "shhalo_check_rebuild_device": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, _ip, C.c_void_p]),
     "shhalo_allreduce_sum_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "shhalo_transport_selftest": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "shhalo_get_stats": (C.c_int, [C.c_void_p, C.POINTER(HaloStats)]),
     "shhalo_run_device": (C.c_int, [C.c_void_p, C.POINTER(HaloArrays), C.POINTER(HaloRunParams), C.c_int, _ip, _ip, _dp,
                                     C.c_void_p]),

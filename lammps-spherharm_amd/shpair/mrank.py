@@ -205,6 +205,11 @@ class Halo:
     def allreduce_sum(self, data_ptr, n, stream=None):
         self._chk(self._lib.shhalo_allreduce_sum_device(self._h, data_ptr, int(n), stream))
 
+    def transport_selftest(self, nbytes=1 << 20, stream=None):
+        """shhalo_transport_selftest: this rank sends nbytes to itself through the transport's exchange (RCCL: ncclSend /
+        ncclRecv with the caller as peer) and all-reduces three doubles and two ints; raises on a mismatch."""
+        self._chk(self._lib.shhalo_transport_selftest(self._h, int(nbytes), stream))
+
     def stats(self):
         s = HaloStats()
         self._chk(self._lib.shhalo_get_stats(self._h, C.byref(s)))

@@ -100,7 +100,7 @@ def test_rccl_body_at_world_1_under_torch_distributed_run():
     h = d["halo"]
     assert h["transport"] == "rccl" and h["ranks_reported_by_transport"] == 1 and h["rccl_version"] > 20000
     assert h["owned_atoms"] == [d["config"]["particles_all_ranks"]] and h["ghost_atoms"][0] > 0     # no atom lost
-    assert d["verify_ok"] is True and d["verify_rel_err"] < 1e-12
+    assert d["verify_ok"] is True and d["verify_rel_err"] < 1e-12 and d["transport_selftest"].startswith("ok")
     assert d["value"] > 1e6 and h["rebuilds_in_timed_steps"][0] >= 1
     # the same without a launcher (bench.py picks its own rendezvous port)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--multi", "--particles", "8000", "--steps", "4",

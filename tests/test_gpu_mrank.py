@@ -276,6 +276,37 @@ def test_a_rank_that_loses_all_its_atoms_keeps_stepping(overlap):
     hub.close()
 
 
+def test_rccl_send_recv_to_self_and_allreduce_through_the_transport():
+    """The only way ncclSend / ncclRecv execute on a one-GPU box: shhalo_transport_selftest — this rank, its own
+    communicator (world 1), sends a megabyte to ITSELF through RcclTransport::exchange (ncclGroupStart, ncclRecv from
+    self, ncclSend to self, ncclGroupEnd: the very calls, argument types and byte counts of the halo's exchange) and
+    all-reduces doubles and ints in place; every byte and value is checked.  (Between two devices: never run here.)"""
+    from shpair import shapes, mrank
+    lmax, nq = 4, 8
+    shp = [shapes.random_shape(lmax, 400, amp=0.2)]
+    sp = _ctx(lmax, shp, nq)
+    lo, hi = np.zeros(3), np.array([30.0, 30.0, 30.0])
+    halo = mrank.Halo(sp, 0, 1, (1, 1, 1), lo, hi, (1, 1, 1), 0.2, unique_id_bytes=mrank.unique_id())
+    st = halo.stats()
+    assert st["transport"] == 1 and st["nranks_transport"] == 1 and st["rccl_version"] > 20000
+    for nbytes in (8, 4096, 1 << 20, (1 << 20) + 13):
+        halo.transport_selftest(nbytes, sp.own_stream())
+    halo.close()
+    # the hub transport between rank threads: send to self goes through the same post / match code as any peer
+    hub = mrank.Hub(2)
+
+    def body(rank):
+        spr = _ctx(lmax, shp, nq)
+        h = mrank.Halo(spr, rank, 2, (2, 1, 1), lo, hi, (1, 1, 1), 0.2, hub=hub)
+        h.transport_selftest(1 << 16, spr.own_stream())
+        h.close()
+        spr.close()
+        return True
+    assert all(_run_ranks(2, body))
+    hub.close()
+    sp.close()
+
+
 def test_config4_one_million_particles_eight_ranks():
     """BASELINE configs[3] as a rehearsal: 1 M particles, L_max = 6, 2x2x2 bricks, periodic in x and y, gravity;
     eight rank threads on the one GPU.  A few steps of the C++ loop, then: no atom lost, the forces of a sample of
