@@ -325,7 +325,7 @@ def roofline_objects(args, sp, n_contact, kernel_ms, world):
     ki = sp.kernel_info()
     from shpair import capi, codeobj
     ksym, khash = codeobj.contact_kernel_hash(capi.library_path(), ki["lmax"] if ki["compiled_order"] else -1, ki["needv"], ki["weighted"],
-                                              ki["family"], ki["waves_per_pair"])
+                                              ki["family"], ki["waves_per_pair"], ki.get("specialised", 0))
     # is the static PMC table's entry a measurement of the code that just ran?  (hash of the kernel's machine code + the
     # launch shape; tools/pmc_table.py stores both with every entry)
     stale = None

@@ -168,7 +168,10 @@ int shpair_compute_device(shpair_ctx *ctx, int nlocal, int nghost, const double 
  * slots run beside the forward exchange, the ghost slots follow it, the other half runs beside the reverse exchange,
  * whose unpack uses the same FP64 atomics (atomic accumulation only: with "deterministic" 2 behaves as 1); 0, the default: the
  * exchanges and the pair kernels follow each other on the caller's stream; same forces, another order of the per-atom
- * sums), "halo_stream_priority" (1: that second stream is one at the highest stream priority — a hardware queue of its
+ * sums), "spec" (default 1: a launch whose order, n_q, ring rows and queue capacity are those of a specialised instance — the
+ * BASELINE shapes L = 4 / n_q = 10, L = 6 / n_q = 16, L = 12 / n_q = 32 — runs that instance, in which the three are
+ * compile-time constants: same arithmetic, bitwise-equal results, fewer index instructions; 0: always the general kernels),
+ * "halo_stream_priority" (1: that second stream is one at the highest stream priority — a hardware queue of its
  * own whatever other streams the process has, its few workgroups dispatched ahead of the pair kernels' backlog; 0, the
  * default: an ordinary stream; takes effect at the next shhalo_run_device),
  * "waves_per_block" (tuning: waves per workgroup of the one-wave contact kernels, default 1), "queue_slack"
@@ -199,6 +202,8 @@ typedef struct shpair_kernel_info {
                                  pair_contact_kernel instance that ran — profiles/pmc_traffic.json is keyed to its code */
   int queue_entries;          /* entries of a wave's node queue: 128, or for the "jpoly" family 128 + what the layout leaves
                                  of its last LDS granule (at most 192; option "queue_slack") */
+  int specialised;            /* 1: the instance with n_q, ring rows and queue capacity as compile-time constants ran (the order's
+                                 BASELINE shape: L = 4 / n_q = 10, L = 6 / n_q = 16, L = 12 / n_q = 32; option "spec") */
 } shpair_kernel_info;
 int shpair_get_kernel_info(shpair_ctx *ctx, shpair_kernel_info *out);
 

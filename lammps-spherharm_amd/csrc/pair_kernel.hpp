@@ -90,6 +90,7 @@ struct PairParams {
   int ring_rows;         // quadrature rings whose tables are resident at a time (<= nq)
   int qcap;              // per-azimuth kernels: entries of a wave's node queue (queue_capacity)
   int waves_per_block;
+  int spec;              // 1: a launch whose (n_q, ring_rows, qcap) are those of PairSpec<L> takes the specialised instance
   // quadrature tables
   const double* glt;    // nq Gauss-Legendre nodes on [-1,1]
   const double* glw;    // nq weights
@@ -1344,9 +1345,35 @@ __device__ __forceinline__ void jpoly_eval2(const double* __restrict__ row, cons
 // WPP = 2 (JPT kernels): two waves per pair, see pair_lds_layout2 — the workgroup is the pair, `half` the wave's half
 // of the azimuths; every table build runs on 128 lanes and every hand-over between the waves is a workgroup barrier
 // that BOTH waves reach the same number of times (the ring-group loop advances identically in both).
-template <int L, bool NEEDV, bool WEIGHTED = false, bool JPT = false, int WPP = 1>
+// Specialised instances (round 5).  n_q, the resident ring rows and the queue capacity are launch parameters of the
+// per-azimuth kernels: every node's (ring, azimuth) comes out of a multiply-shift division by 2 n_q or n_q, every row
+// address out of a multiplication by the row length, every ring-group bound out of a compare with the group size.
+// With the three as compile-time constants the divisions become shifts and masks, the products immediates, the
+// one-group case loses its group loop: -4.3 % at the headline with bitwise-equal results (profiles/r05_ab_nq_const.txt,
+// an experiment build with the constants forced).  One instance per compiled order, for the (n_q, rows, queue) the
+// host's rules pick at that order's BASELINE shape — PairSpec<L> — launched when the launch's parameters are exactly
+// those (pair_spec_matches; option "spec" 0 keeps the general kernels, which every other (L, n_q) runs anyway).
+template <int L> struct PairSpec { static constexpr int nq = 0, rr = 0, qc = 0, wpp = 1; };
+template <> struct PairSpec<4> { static constexpr int nq = 10, rr = 10, qc = 128, wpp = 1; };    // configs[0]'s shape
+template <> struct PairSpec<6> { static constexpr int nq = 16, rr = 16, qc = 172, wpp = 1; };    // configs[1], [2], [3]
+template <> struct PairSpec<12> { static constexpr int nq = 32, rr = 12, qc = 148, wpp = 2; };   // configs[4]
+template <int L>
+inline bool pair_spec_matches(const PairParams& P)
+{
+  typedef PairSpec<(L >= 0 ? L : 0)> S;
+  return L >= 0 && S::nq > 0 && P.spec && P.jpoly && !P.rule && P.nq == S::nq && P.ring_rows == S::rr && P.qcap == S::qc &&
+         (P.split ? 2 : 1) == S::wpp && P.waves_per_block == 1;
+}
+inline bool pair_spec_matches_rt(const int L, const PairParams& P)
+{
+  return L == 4 ? pair_spec_matches<4>(P) : (L == 6 ? pair_spec_matches<6>(P) : (L == 12 ? pair_spec_matches<12>(P) : false));
+}
+
+template <int L, bool NEEDV, bool WEIGHTED = false, bool JPT = false, int WPP = 1, bool SPEC = false>
 __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L, NEEDV, WPP) : (WEIGHTED ? SHP_WMIN_WAVES(L) : SHP_MIN_WAVES(L, NEEDV))) pair_contact_kernel(const PairParams P)
 {
+  static_assert(!SPEC || (JPT && L >= 0 && !WEIGHTED && PairSpec<(L >= 0 ? L : 0)>::nq > 0 && PairSpec<(L >= 0 ? L : 0)>::wpp == WPP),
+                "specialised instances: per-azimuth kernels of the orders PairSpec names");
   static_assert(WPP == 1 || (WPP == 2 && JPT && L >= 0 && !WEIGHTED), "two waves per pair: compiled-order JPT kernels only");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   int lane = threadIdx.x & 63;
@@ -1358,7 +1385,10 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
   (void)tid;
   if (w >= P.npairs) return;
   const int LL = (L >= 0) ? L : P.lmax;
-  const int nq = P.nq;
+  typedef PairSpec<(L >= 0 ? L : 0)> Spec;
+  const int nq = SPEC ? Spec::nq : P.nq;                    // (SPEC: compile-time constants, see PairSpec)
+  const int P_ring_rows = SPEC ? Spec::rr : P.ring_rows;
+  const int P_qcap = SPEC ? Spec::qc : P.qcap;
   // compiled orders: particle j from per-azimuth polynomials in the pair's common frame (jpoly_build above); the
   // run-time-order kernel keeps the body-frame evaluation sh_eval_rt
   constexpr bool JP = JPT && (L >= 0) && !WEIGHTED;
@@ -1376,8 +1406,8 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
   constexpr bool DIRECT = SHP_DIRECT(L) && JP && !WEIGHTED;
   constexpr int FRAME = JP ? kFrameJ : kFrame;   // doubles of the frame in LDS; FRM(slot): where a record slot sits in it
 #define FRM(slot) (JP ? frj(slot) : (slot))
-  WaveLdsLayout W = (WPP == 2) ? pair_lds_layout2(LL, P.ring_rows, nq, P.qcap)
-                               : wave_lds_layout(LL, P.ring_rows, WEIGHTED, JP ? nq : 0, JP ? P.qcap : kQueue);
+  WaveLdsLayout W = (WPP == 2) ? pair_lds_layout2(LL, P_ring_rows, nq, P_qcap)
+                               : wave_lds_layout(LL, P_ring_rows, WEIGHTED, JP ? nq : 0, JP ? P_qcap : kQueue);
   if constexpr (WPP == 2) {   // this wave's queue
     W.qri += half * W.qstride;
     W.qrj += half * W.qstride;
@@ -1433,12 +1463,12 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
         vj[t] = P.rot[at + rot_row_doubles(L)];
       }
     }
-    pre.fetch(P, lane, P.nq);
+    pre.fetch(P, lane, nq);
   }
   double glt_first = 0.0, glw_first = 0.0;
-  if constexpr (JPT && L >= 0 && !WEIGHTED) glw_first = P.glw[tid < P.nq ? tid : 0];   // the weight of ring `tid`, stored after the first stage
+  if constexpr (JPT && L >= 0 && !WEIGHTED) glw_first = P.glw[tid < nq ? tid : 0];   // the weight of ring `tid`, stored after the first stage
   if constexpr (JPT && L >= 0 && L <= 8 && !WEIGHTED && WPP == 1) {
-    const int nr0 = P.ring_rows < P.nq ? P.ring_rows : P.nq;   // rings of the first group
+    const int nr0 = P_ring_rows < nq ? P_ring_rows : nq;   // rings of the first group
     const int lg0 = ring_poly_map(nr0, L + 1, 64);             // cap_frame_rings_poly's lane map of that group's first pass
     const int kr = lg0 >= 1 ? (lane >> lg0) : lane / (L + 1);
     glt_first = P.glt[kr < nr0 ? kr : nr0 - 1];
@@ -1534,7 +1564,7 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
   // rings resident (the common case) that is the only build of the pair, and nothing has to be parked around it (round
   // 3 parked two sums in the queue for every build: 128 doubles of LDS beside the polynomials the build reads)
   if constexpr (JP) {
-    const int kend0 = (P.ring_rows < nq) ? P.ring_rows : nq;
+    const int kend0 = (P_ring_rows < nq) ? P_ring_rows : nq;
     cap_frame_rings_poly<LJ, WPP>(P, SHP_LDS(), W, lane, tid, 0, kend0, fr[FRM(FR_HW)], fr[FRM(FR_HM)], L <= 8 && WPP == 1);
   }
   bool first_group = true;   // wave-uniform
@@ -1552,7 +1582,7 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
   while (WEIGHTED ? (slab <= nslabs) : (slab < nslabs)) {
   const int sfirst = (WEIGHTED && slab > 0) ? slab - 1 : slab;
   const int k0 = (int)(((unsigned)(sfirst << 6) * magicr) >> 24);
-  const int kend = (k0 + P.ring_rows < nq) ? k0 + P.ring_rows : nq;
+  const int kend = (k0 + P_ring_rows < nq) ? k0 + P_ring_rows : nq;
   const int slab_end = (kend == nq) ? (WEIGHTED ? nslabs + 1 : nslabs) : ((kend * per_ring) >> 6);
   if (slab_end <= slab) return;  // cannot happen with the host's ring_rows; never spin
   __builtin_amdgcn_s_setprio(3);
@@ -2345,15 +2375,23 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock, JPT ? SHP_JMIN_WAVES(L
 // Host-callable launcher, one per compiled order (pair_kernels_L*.hip).
 typedef void (*pair_launch_fn)(const PairParams&, bool needv, hipStream_t, hipEvent_t wait_before_contact);
 // Register / LDS footprint of the kernel that launch would pick (occupancy evidence for bench.py).
-typedef hipError_t (*pair_attr_fn)(bool needv, bool weighted, hipFuncAttributes*, bool jpoly, bool split);
+typedef hipError_t (*pair_attr_fn)(bool needv, bool weighted, hipFuncAttributes*, bool jpoly, bool split, bool spec);
 
 // Orders for which the two-waves-per-pair kernels are compiled (they pay where one wave's private tables starve the CU
 // of waves: large L with large n_q; the host's rule is use_split in shpair_api.hip)
 __host__ __device__ constexpr bool split_compiled(int L) { return L >= 7; }
 
 template <int L>
-hipError_t pair_contact_attributes(bool needv, bool weighted, hipFuncAttributes* a, bool jpoly = false, bool split = false)
+hipError_t pair_contact_attributes(bool needv, bool weighted, hipFuncAttributes* a, bool jpoly = false, bool split = false,
+                                   bool spec = false)
 {
+  if constexpr (L >= 0) {
+    if constexpr (PairSpec<L>::nq > 0) {
+      if (spec && jpoly && !weighted && (split ? 2 : 1) == PairSpec<L>::wpp)
+        return needv ? hipFuncGetAttributes(a, (const void*)pair_contact_kernel<L, true, false, true, PairSpec<L>::wpp, true>)
+                     : hipFuncGetAttributes(a, (const void*)pair_contact_kernel<L, false, false, true, PairSpec<L>::wpp, true>);
+    }
+  }
   if constexpr (split_compiled(L)) {
     if (split && jpoly && !weighted)
       return needv ? hipFuncGetAttributes(a, (const void*)pair_contact_kernel<L, true, false, true, 2>)
@@ -2402,6 +2440,16 @@ void launch_pair_contact(const PairParams& P, bool needv, hipStream_t st, hipEve
       hipLaunchKernelGGL((pair_rotate_lane_kernel<L>), dim3((2 * (unsigned)nslots + 63) / 64), dim3(64),
                          RotLaneLds<L>::bytes(), st, P, const_cast<double*>(P.rot));
       if (wait_before_contact) (void)hipStreamWaitEvent(st, wait_before_contact, 0);
+      if constexpr (PairSpec<L>::nq > 0) {
+        if (pair_spec_matches<L>(P)) {   // the order's BASELINE shape: n_q, ring rows and queue capacity are compile-time constants
+          constexpr int SW = PairSpec<L>::wpp;
+          const dim3 gs(SW == 2 ? nslots : (int)grid.x), bs(64 * SW);
+          const size_t ls = SW == 2 ? (size_t)P.wave_lds_bytes : lds;
+          if (needv) launch_contact_one(pair_contact_kernel<L, true, false, true, SW, true>, gs, bs, ls, st, P);
+          else launch_contact_one(pair_contact_kernel<L, false, false, true, SW, true>, gs, bs, ls, st, P);
+          return;
+        }
+      }
       if constexpr (split_compiled(L)) {
         if (P.split) {   // two waves per pair: the workgroup is the pair
           const dim3 grid2(nslots), block2(128);

@@ -19,5 +19,5 @@
 
 namespace shp {
 void SHP_FN(const PairParams& P, bool needv, hipStream_t st, hipEvent_t w) { launch_pair_contact<SHP_L>(P, needv, st, w); }
-hipError_t SHP_AFN(bool needv, bool weighted, hipFuncAttributes* a, bool jpoly, bool split) { return pair_contact_attributes<SHP_L>(needv, weighted, a, jpoly, split); }
+hipError_t SHP_AFN(bool needv, bool weighted, hipFuncAttributes* a, bool jpoly, bool split, bool spec) { return pair_contact_attributes<SHP_L>(needv, weighted, a, jpoly, split, spec); }
 }  // namespace shp

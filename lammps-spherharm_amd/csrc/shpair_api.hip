@@ -25,12 +25,12 @@
 
 namespace shp {
 #define SHP_DECL(L) void shp_launch_L##L(const PairParams&, bool, hipStream_t, hipEvent_t); \
-  hipError_t shp_attr_L##L(bool, bool, hipFuncAttributes*, bool, bool);
+  hipError_t shp_attr_L##L(bool, bool, hipFuncAttributes*, bool, bool, bool);
 SHP_DECL(0) SHP_DECL(1) SHP_DECL(2) SHP_DECL(3) SHP_DECL(4) SHP_DECL(5) SHP_DECL(6)
 SHP_DECL(7) SHP_DECL(8) SHP_DECL(9) SHP_DECL(10) SHP_DECL(11) SHP_DECL(12)
 #undef SHP_DECL
 void shp_launch_Lrt(const PairParams&, bool, hipStream_t, hipEvent_t);
-hipError_t shp_attr_Lrt(bool, bool, hipFuncAttributes*, bool, bool);
+hipError_t shp_attr_Lrt(bool, bool, hipFuncAttributes*, bool, bool, bool);
 
 constexpr int kMaxUnrolledL = 12;
 static const pair_launch_fn kLaunch[kMaxUnrolledL + 1] = {
@@ -788,7 +788,7 @@ int shp_compute_range(shpair_ctx* c, int nlocal, int nghost, const double* x, co
       int wsimd = 4;
       {
         hipFuncAttributes fa;
-        if (kAttr[c->lmax](true, false, &fa, true, true) == hipSuccess && fa.numRegs > 0) {
+        if (kAttr[c->lmax](true, false, &fa, true, true, false) == hipSuccess && fa.numRegs > 0) {
           wsimd = 512 / (((fa.numRegs + 7) / 8) * 8);
           if (wsimd > 8) wsimd = 8;
           if (wsimd < 1) wsimd = 1;
@@ -829,9 +829,11 @@ int shp_compute_range(shpair_ctx* c, int nlocal, int nghost, const double* x, co
     P.wave_lds_bytes = wl.bytes;
     P.waves_per_block = wpb;
     P.ring_rows = rows;
+    P.spec = c->opt_spec ? 1 : 0;
     c->last_lds_bytes = P.wave_lds_bytes;
     c->last_ring_rows = rows;
     c->last_qcap = qcap;
+    c->last_spec = c->lmax <= kMaxUnrolledL && c->opt_variant != 1 && pair_spec_matches_rt(c->lmax, P);
   }
   P.pair_ft = nullptr;
   if (c->opt_deterministic) {
@@ -1038,8 +1040,8 @@ int shpair_get_kernel_info(shpair_ctx* c, shpair_kernel_info* out)
   HIPCHK(c, hipSetDevice(c->device));
   hipFuncAttributes a;
   const bool compiled = c->lmax <= kMaxUnrolledL && c->opt_variant != 1;
-  HIPCHK(c, compiled ? kAttr[c->lmax](c->last_needv, c->opt_rule != 0, &a, c->last_jpoly, c->last_split)
-                     : shp_attr_Lrt(c->last_needv, false, &a, false, false));
+  HIPCHK(c, compiled ? kAttr[c->lmax](c->last_needv, c->opt_rule != 0, &a, c->last_jpoly, c->last_split, c->last_spec)
+                     : shp_attr_Lrt(c->last_needv, false, &a, false, false, false));
   out->lmax = c->lmax;
   out->compiled_order = compiled ? 1 : 0;
   out->vgprs = a.numRegs;
@@ -1064,6 +1066,7 @@ int shpair_get_kernel_info(shpair_ctx* c, shpair_kernel_info* out)
   out->family = (compiled && c->last_jpoly) ? 1 : 0;
   out->needv = c->last_needv ? 1 : 0;
   out->weighted = (compiled && c->opt_rule != 0) ? 1 : 0;
+  out->specialised = (compiled && c->last_spec) ? 1 : 0;
   return SHPAIR_OK;
 }
 
@@ -1145,6 +1148,7 @@ int shpair_set_option(shpair_ctx* c, const char* key, int value)
   }
   else if (!strcmp(key, "waves_per_block")) c->opt_wpb = value;
   else if (!strcmp(key, "queue_slack")) c->opt_queue_slack = value ? 1 : 0;
+  else if (!strcmp(key, "spec")) c->opt_spec = value != 0;
   else if (!strcmp(key, "halo_overlap")) c->opt_overlap = value <= 0 ? 0 : (value >= 2 ? 2 : 1);
   else if (!strcmp(key, "halo_stream_priority")) c->opt_halo_prio = value != 0;   // takes effect at the next shhalo_run_device (both kinds of stream are kept)
   else CTX_FAIL(c, SHPAIR_EINVAL, "unknown option '%s'", key);

@@ -117,6 +117,8 @@ struct shpair_ctx {
   bool last_split = false;
   int last_lds_bytes = 0, last_ring_rows = 0, last_qcap = 0;  // of the last launch (shpair_get_kernel_info)
   bool last_needv = false;
+  int opt_spec = 1;        // "spec": launches whose (n_q, ring rows, queue) are PairSpec<L>'s take the specialised instance (pair_kernel.hpp)
+  bool last_spec = false;
   double* pair_out = nullptr;
   double *eatom_dev = nullptr, *vatom_dev = nullptr;    // shpair_set_peratom_output
   double *eatom_host = nullptr, *vatom_host = nullptr;  // shpair_set_peratom_host

@@ -31,7 +31,7 @@ class Stats(C.Structure):
 class KernelInfo(C.Structure):
     _fields_ = [(n, C.c_int) for n in ("lmax", "compiled_order", "vgprs", "scratch_bytes", "lds_bytes_per_wave", "ring_rows",
                                        "waves_per_simd_vgpr", "waves_per_cu_lds", "waves_per_cu", "family", "waves_per_pair",
-                                       "needv", "weighted", "queue_entries")]
+                                       "needv", "weighted", "queue_entries", "specialised")]
 
 
 class StepArrays(C.Structure):

@@ -80,16 +80,16 @@ def kernel_hashes(lib_path, target="gfx950"):
     return res
 
 
-def contact_kernel_symbol_fragment(order, needv, weighted, family, waves_per_pair):
-    """Itanium-mangled template-argument list of shp::pair_contact_kernel<L, NEEDV, WEIGHTED, JPT, WPP>."""
+def contact_kernel_symbol_fragment(order, needv, weighted, family, waves_per_pair, specialised=0):
+    """Itanium-mangled template-argument list of shp::pair_contact_kernel<L, NEEDV, WEIGHTED, JPT, WPP, SPEC>."""
     lit = "n{}".format(-int(order)) if int(order) < 0 else str(int(order))   # the run-time-order kernel is instantiated with L = -1
-    return "pair_contact_kernelILi{}ELb{}ELb{}ELb{}ELi{}EE".format(lit, int(bool(needv)), int(bool(weighted)), int(bool(family)),
-                                                                   int(waves_per_pair))
+    return "pair_contact_kernelILi{}ELb{}ELb{}ELb{}ELi{}ELb{}EE".format(lit, int(bool(needv)), int(bool(weighted)), int(bool(family)),
+                                                                        int(waves_per_pair), int(bool(specialised)))
 
 
-def contact_kernel_hash(lib_path, order, needv, weighted, family, waves_per_pair):
+def contact_kernel_hash(lib_path, order, needv, weighted, family, waves_per_pair, specialised=0):
     """(symbol, hash) of the contact-kernel instance a workload launches, or (None, None) if the library has none."""
-    frag = contact_kernel_symbol_fragment(order, needv, weighted, family, waves_per_pair)
+    frag = contact_kernel_symbol_fragment(order, needv, weighted, family, waves_per_pair, specialised)
     for sym, h in kernel_hashes(lib_path).items():
         if frag in sym:
             return sym, h

@@ -130,6 +130,48 @@ def test_two_waves_per_pair_match_oracle(oracle, lmax, nq, rows, expo):
     assert np.abs(out[1][0] - out[0][0]).max() < 1e-12 * fs
 
 
+@pytest.mark.parametrize("lmax,nq,expo,nshapes", [(6, 16, 1.25, 1), (6, 16, 1.0, 4), (4, 10, 1.25, 2), (4, 10, 1.0, 1), (12, 32, 1.25, 1),
+                                                   (12, 32, 1.0, 2)])
+def test_specialised_instances_match_oracle_and_the_general_kernels(oracle, lmax, nq, expo, nshapes):
+    """The BASELINE shapes run instances in which n_q, the resident ring rows and the queue capacity are compile-time
+    constants (pair_kernel.hpp PairSpec; option "spec", default 1): the same arithmetic with fewer index instructions.
+    Both force laws (NEEDV true / false instances), one and several shapes; against the oracle, against the general
+    kernels of the same library (option "spec" 0), per pair — and the library must say which one ran."""
+    import torch
+    case = make_case(260, lmax, nshapes, seed=700 + lmax, rmax_fn=oracle.shape_rmax)
+    K, E = coeff_tables(1, 1000.0, expo)
+    b = case["bed"]
+    out = {}
+    npairs = case["jlist"].size
+    for spec in (1, 0):
+        sp = make_ctx(case, nq, K, E)
+        sp.set_option("spec", spec)
+        sp.set_option("count", 1)
+        pairs = torch.zeros(max(npairs, 1), 7, dtype=torch.float64, device="cuda:0")
+        sp.set_pair_output(pairs.data_ptr())
+        f, tq, eng, vir = sp.compute(case["n"], b["x"], b["quat"], b["type"], b["shtype"], eflag=True, vflag=True)
+        ki = sp.kernel_info()
+        assert ki["specialised"] == spec and ki["family"] == 1 and ki["scratch_bytes"] == 0, ki
+        assert ki["waves_per_pair"] == (2 if lmax == 12 else 1)
+        st = sp.stats()
+        out[spec] = (f, tq, eng, (st["n_candidates"], st["n_contact"], st["n_touching"]), pairs.cpu().numpy())
+        sp.close()
+    o = oracle_compute(oracle, case, nq, K, E, eflag=True, vflag=True, want_pairs=True)
+    for spec in (1, 0):
+        f, tq, eng, counts, pr = out[spec]
+        check(f, tq, o)
+        assert abs(eng - o["eng_virial"][0]) < TOL * abs(o["eng_virial"][0]) and counts == tuple(o["counts"])
+    # same instructions on the data path: per pair the two agree to the last bits of the sums' order, and with the oracle
+    scale = np.abs(o["pairs"]).max(axis=0) + 1e-300
+    assert (np.abs(out[1][4] - out[0][4]) / scale).max() < 1e-13
+    assert (np.abs(out[1][4] - o["pairs"]) / scale).max() < TOL
+    # a launch that is NOT the order's BASELINE shape keeps the general kernel, whatever the option says
+    sp = make_ctx(case, nq + 2, K, E)
+    sp.compute(case["n"], b["x"], b["quat"], b["type"], b["shtype"])
+    assert sp.kernel_info()["specialised"] == 0
+    sp.close()
+
+
 def test_two_waves_per_pair_random_configurations_agree_with_one_wave(oracle):
     """A wider net for the two-wave kernels' barriers, queues and ring groups: pseudo-random (order, even n_q, resident
     rows, exponent) — including n_q / 2 that do not divide 64, single-slab caps and many short ring groups — each compared

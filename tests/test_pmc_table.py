@@ -36,4 +36,5 @@ def test_the_table_is_not_stale_at_head():
 
 def test_symbol_fragment_of_the_run_time_order_kernel():
     assert "ILin1E" in codeobj.contact_kernel_symbol_fragment(-1, True, False, 0, 1)
-    assert codeobj.contact_kernel_symbol_fragment(6, True, False, 1, 1) == "pair_contact_kernelILi6ELb1ELb0ELb1ELi1EE"
+    assert codeobj.contact_kernel_symbol_fragment(6, True, False, 1, 1) == "pair_contact_kernelILi6ELb1ELb0ELb1ELi1ELb0EE"
+    assert codeobj.contact_kernel_symbol_fragment(6, True, False, 1, 1, 1) == "pair_contact_kernelILi6ELb1ELb0ELb1ELi1ELb1EE"
