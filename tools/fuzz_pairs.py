@@ -13,7 +13,7 @@ from shpair import ShPair, shapes  # noqa: E402
 from oracle import oracle as O  # noqa: E402  (checker)
 
 npair = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
-CONFIGS = ((6, 16, 1.25), (5, 9, 1.5), (3, 12, 1.0), (8, 7, 1.25))
+CONFIGS = ((6, 16, 1.25), (5, 9, 1.5), (3, 12, 1.0), (8, 7, 1.25), (4, 10, 1.25), (12, 32, 1.25), (6, 16, 1.0))   # (6, 16), (4, 10), (12, 32): the specialised instances
 if os.environ.get("SHP_FUZZ_MORE"):   # dense slabs (direct batches), ring groups, two waves per pair, the rules' other choices
     CONFIGS += ((6, 24, 1.25), (4, 16, 1.0), (8, 20, 1.25), (12, 16, 1.25), (2, 16, 1.5), (9, 12, 1.25), (11, 22, 1.25), (10, 5, 1.0))
 for lmax, nq, expo in CONFIGS:
